@@ -1,0 +1,83 @@
+/*
+ * mfgm -- MI355X-native block-tri-diagonal Gauss-Markov kernels (C ABI).
+ *
+ * Drop-in boundary for the native layer under the reference's block_tri_diag / state_space_model /
+ * kalman_filter / ssm_gaussian_transformations modules, i.e. for the TF custom ops of
+ * banded-matrices==0.0.6 that AaltoML/vi-diffusion-processes binds at
+ *     markovflow/block_tri_diag.py:22-31        (cholesky_band, solve_triang_mat, product_band_mat,
+ *                                                inverse_from_cholesky_band, block_to_band, band_to_block)
+ *     markovflow/ssm_gaussian_transformations.py:23 (inverse_from_cholesky_band, solve_triang_band)
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (fp64, contiguous); `stream` is a
+ *     hipStream_t passed as void*; calls are asynchronous on that stream and re-entrant across streams
+ *     as long as each in-flight call has its own workspace;
+ *   - no hidden allocation: scratch comes from the caller (`ws`, mfgm_plan_workspace_bytes());
+ *   - return value: 0 ok, 1 bad argument / unsupported shape, 3 HIP runtime error.  A block that is not
+ *     positive definite does not abort the sweep: the optional device word `info` becomes non-zero
+ *     (the Python wrapper turns that into ArithmeticError, the stand-in for TF's Cholesky failure);
+ *   - "natural" layout = the reference's row-major [B, T, d, d] / [B, T-1, d, d] / [B, T, d] tensors;
+ *     "packed" layout = the segment-interleaved layout the sweeps run on (csrc/mfgm_layout.h):
+ *     element (chain b, node t = p*R + s, e) of a per-node quantity with E doubles is at
+ *     ((s*E + e)*Lpad + b*P + p).  Symmetric and lower-triangular blocks are stored as packed lower
+ *     triangles (E = d(d+1)/2) in the packed layout.
+ */
+#ifndef MFGM_H
+#define MFGM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mfgm_plan mfgm_plan;
+
+/* kinds of per-node quantities */
+#define MFGM_VEC 0  /* [d]                                   */
+#define MFGM_FULL 1 /* [d, d] general block                  */
+#define MFGM_SYM 2  /* [d, d] symmetric: lower triangle read, both triangles written */
+#define MFGM_TRI 3  /* [d, d] lower-triangular: upper triangle written as zero       */
+
+/* Partition plan for B chains of T nodes with d x d blocks.  R0 = nodes per lane segment at the finest
+ * level (0 = choose so that about 64 Ki lanes exist), Rup = segment length of the coarser levels (0 = 32).
+ * Supported d: 1..8. */
+int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out);
+void mfgm_plan_destroy(mfgm_plan* plan);
+/* out[0..5] = nlevels, R (level 0), P (level 0), Lpad (level 0), B, T */
+int mfgm_plan_describe(const mfgm_plan* plan, int* out6);
+size_t mfgm_plan_workspace_bytes(const mfgm_plan* plan);
+/* number of doubles of a level-0 packed array of the given kind */
+size_t mfgm_packed_doubles(const mfgm_plan* plan, int kind);
+
+/* natural -> packed and back.  n_nodes = T for per-state tensors, T-1 for per-transition tensors
+ * (block_tri_diag.py:206-237 `_convert_to_band`, :553-596 `_banded_to_block_tri` are the reference's
+ * re-layout steps these replace). */
+int mfgm_pack(const mfgm_plan* plan, int kind, const double* natural, int n_nodes, double* packed, void* stream);
+int mfgm_unpack(const mfgm_plan* plan, int kind, const double* packed, double* natural, int n_nodes, void* stream);
+
+/* Block Cholesky of the symmetric block-tri-diagonal matrix with diagonal blocks aD*D_t and
+ * sub-diagonal blocks aS*S_t (packed), plus y = L^{-1} (aR*r) when r != NULL:
+ *   replaces SymmetricBlockTriDiagonal.cholesky (block_tri_diag.py:428-440 -> cholesky_band),
+ *   LowerTriangularBlockTriDiagonal.solve(transpose_left=False) (:339-351 -> solve_triang_mat) and
+ *   abs_log_det (:353-366).
+ * Outputs (packed): L (TRI), G = L_{t+1,t} at node t (FULL), y (VEC, may be NULL iff r is NULL),
+ * logdet[B] = sum log diag(L) and quad[B] = |y|^2 (either may be NULL). */
+int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, const double* r, double aD,
+                       double aS, double aR, double* L, double* G, double* y, double* logdet, double* quad,
+                       void* ws, int* info, void* stream);
+
+/* Diagonal and sub-diagonal blocks of (L L^T)^{-1} and x = L^{-T} y from the factor above:
+ *   replaces block_diagonal_of_inverse (block_tri_diag.py:318-337 -> inverse_from_cholesky_band),
+ *   the sub-diagonal read at ssm_gaussian_transformations.py:443-458, and solve(transpose_left=True).
+ * Must follow mfgm_packed_factor with the same plan and workspace (coarse-level factors live in ws).
+ * Outputs (packed): Sig (SYM), Sub = Sigma_{t+1,t} at node t (FULL, may be NULL), x (VEC, NULL iff y NULL). */
+int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, const double* y, double* Sig,
+                       double* Sub, double* x, void* ws, void* stream);
+
+const char* mfgm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFGM_H */

@@ -1,0 +1,138 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP sweeps, called through the C ABI, against the
+NumPy oracle on the same seeded inputs.  Tolerance: fp64, 1e-7 relative on random blocks (partitioned elimination order differs from the sequential oracle)
+(the north-star bound is 1e-5 relative).
+"""
+import numpy as np
+import pytest
+
+from oracle import np_btd
+from tests.helpers import assert_close, random_dominant_btd, random_spd_btd
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-7, 1e-9
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+    import vidp_amd
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    vidp_amd._lib.load()
+    return vidp_amd
+
+
+def _dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("B,T,d,R0", [(1, 1, 1, 0), (3, 17, 3, 4), (2, 130, 6, 8), (5, 64, 2, 64), (70, 9, 4, 2)])
+def test_pack_round_trip(amd, rng, kind, B, T, d, R0):
+    plan = amd.Plan(B, T, d, R0=R0)
+    for n_nodes in (T, T - 1):
+        if n_nodes < 1:
+            continue
+        shape = (B, n_nodes, d) if kind == 0 else (B, n_nodes, d, d)
+        x = rng.normal(size=shape)
+        back = plan.unpack(kind, plan.pack(kind, _dev(x)), n_nodes).cpu().numpy()
+        if kind == 2:
+            low = np.tril(x)
+            ref = low + np.swapaxes(np.tril(x, -1), -1, -2)
+        elif kind == 3:
+            ref = np.tril(x)
+        else:
+            ref = x
+        np.testing.assert_array_equal(back, ref)
+
+
+CASES = [
+    # B, T, d, R0, Rup
+    (1, 1, 1, 0, 0),
+    (1, 4, 1, 0, 0),
+    (3, 4, 3, 0, 0),
+    (2, 5, 2, 2, 2),        # many tiny levels
+    (3, 37, 3, 4, 3),       # ragged last segment, 3+ levels
+    (4, 64, 5, 8, 4),
+    (2, 129, 6, 8, 8),
+    (65, 20, 4, 5, 0),      # more than one wavefront of lanes
+    (1, 1000, 1, 0, 0),     # config-1 size
+    (2, 300, 6, 16, 0),
+    (1, 200, 8, 10, 0),
+    (1, 150, 7, 10, 0),
+]
+
+
+@pytest.mark.parametrize("B,T,d,R0,Rup", CASES)
+@pytest.mark.parametrize("with_rhs", [True, False])
+def test_factor_and_selinv(amd, rng, B, T, d, R0, Rup, with_rhs):
+    if T <= 5:
+        diag, sub, _, _ = random_spd_btd(rng, (B,), T, d)   # the reference's own generator (KA1)
+    else:
+        diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    plan = amd.Plan(B, T, d, R0=R0, Rup=Rup)
+    Dp = plan.pack(amd.SYM, _dev(diag))
+    Sp = plan.pack(amd.FULL, _dev(sub)) if T > 1 else plan.zeros(amd.FULL)
+    rp = plan.pack(amd.VEC, _dev(r)) if with_rhs else None
+    f = plan.factor(Dp, Sp, rp, want_logdet=True, want_quad=True)
+    plan.check_info()
+
+    Ld, Ls = np_btd.cholesky(diag, sub)
+    assert_close(plan.unpack(amd.TRI, f["L"]).cpu().numpy(), Ld)
+    if T > 1:
+        assert_close(plan.unpack(amd.FULL, f["G"], T - 1).cpu().numpy(), Ls)
+    np.testing.assert_allclose(f["logdet"].cpu().numpy(), np_btd.abs_log_det(Ld), rtol=1e-8, atol=1e-8)
+    if with_rhs:
+        y = np_btd.solve(Ld, Ls, r)
+        assert_close(plan.unpack(amd.VEC, f["y"]).cpu().numpy(), y)
+        np.testing.assert_allclose(f["quad"].cpu().numpy(), np.sum(y * y, axis=(-1, -2)), rtol=1e-7)
+
+    s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True)
+    Sd, Ss = np_btd.inverse_blocks(Ld, Ls)
+    assert_close(plan.unpack(amd.SYM, s["Sig"]).cpu().numpy(), Sd)
+    if T > 1:
+        assert_close(plan.unpack(amd.FULL, s["Sub"], T - 1).cpu().numpy(), Ss)
+    if with_rhs:
+        x = np_btd.solve(Ld, Ls, np_btd.solve(Ld, Ls, r), transpose_left=True)
+        assert_close(plan.unpack(amd.VEC, s["x"]).cpu().numpy(), x)
+
+
+def test_scaled_inputs_and_not_pd(amd, rng):
+    """aD / aS / aR scale on load (natural parameters -> precision), and the non-PD flag."""
+    B, T, d = 2, 40, 3
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    plan = amd.Plan(B, T, d, R0=8)
+    f = plan.factor(plan.pack(amd.SYM, _dev(-0.5 * diag)), plan.pack(amd.FULL, _dev(-sub)), plan.pack(amd.VEC, _dev(2 * r)),
+                    aD=-2.0, aS=-1.0, aR=0.5)
+    plan.check_info()
+    Ld, Ls = np_btd.cholesky(diag, sub)
+    assert_close(plan.unpack(amd.TRI, f["L"]).cpu().numpy(), Ld)
+    assert_close(plan.unpack(amd.VEC, f["y"]).cpu().numpy(), np_btd.solve(Ld, Ls, r))
+    plan.factor(plan.pack(amd.SYM, _dev(-diag)), plan.pack(amd.FULL, _dev(sub)))
+    with pytest.raises(ArithmeticError):
+        plan.check_info()
+
+
+def test_partition_invariance_large(amd, rng):
+    """Size-independent property at a size the dense oracle cannot reach: different partitions agree, and
+    K * (K^{-1} r) == r through the block-tri-diagonal product."""
+    B, T, d = 4, 20000, 6
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    outs = []
+    for R0, Rup in ((0, 0), (50, 8), (T, 0)):
+        plan = amd.Plan(B, T, d, R0=R0, Rup=Rup)
+        f = plan.factor(plan.pack(amd.SYM, _dev(diag)), plan.pack(amd.FULL, _dev(sub)), plan.pack(amd.VEC, _dev(r)))
+        plan.check_info()
+        s = plan.selinv(f["L"], f["G"], f["y"])
+        outs.append((f["logdet"].cpu().numpy(), plan.unpack(amd.VEC, s["x"]).cpu().numpy(),
+                     plan.unpack(amd.SYM, s["Sig"]).cpu().numpy(), plan.unpack(amd.FULL, s["Sub"], T - 1).cpu().numpy()))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert_close(a, b)
+    x = outs[0][1]
+    np.testing.assert_allclose(np_btd.dense_mult(diag, sub, x, symmetric=True), r, rtol=1e-7, atol=1e-8)

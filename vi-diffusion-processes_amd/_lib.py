@@ -1,0 +1,62 @@
+"""
+ctypes binding of libmfgm.so (C ABI declared in include/mfgm.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C csrc``.  There is no CPU
+fallback: when the shared object is missing every call raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmfgm.so")
+
+VEC, FULL, SYM, TRI = 0, 1, 2, 3
+
+_lib = None
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "mfgm_version": (ctypes.c_char_p, []),
+    "mfgm_plan_create": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_void_p)]),
+    "mfgm_plan_destroy": (None, [ctypes.c_void_p]),
+    "mfgm_plan_describe": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
+    "mfgm_plan_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "mfgm_packed_doubles": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_int]),
+    "mfgm_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                 ctypes.c_void_p]),
+    "mfgm_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                   ctypes.c_void_p]),
+    "mfgm_packed_factor": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 8),
+    "mfgm_packed_selinv": (ctypes.c_int, [ctypes.c_void_p] * 9),
+}
+
+
+class MfgmError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmfgm.so (once) and declare every exported signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MfgmError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = {1: "bad argument / unsupported shape", 3: "HIP runtime error"}.get(rc, f"error {rc}")
+    if rc == 1:
+        raise ValueError(f"{what}: {msg}")
+    raise MfgmError(f"{what}: {msg}")

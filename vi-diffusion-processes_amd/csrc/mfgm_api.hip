@@ -1,0 +1,314 @@
+// C-ABI entry points (include/mfgm.h): plan construction, re-layout, and the multi-level drivers that
+// chain the reduce / forward / backward sweeps.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/mfgm.h"
+#include "mfgm_layout.h"
+#include "mfgm_pack.h"
+#include "mfgm_sweeps.h"
+
+using namespace mfgm;
+
+struct mfgm_plan {
+    Plan p;
+};
+
+namespace {
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+#define MFGM_CHECK_LAUNCH()                        \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return 3;           \
+    } while (0)
+
+void fill_level(LevelDesc& lv, int B, int n, int R) {
+    lv.n = n;
+    lv.R = R;
+    lv.P = ceil_div(n, R);
+    lv.L = B * lv.P;
+    lv.Lpad = ceil_div(lv.L, 64) * 64;
+}
+
+template <int D>
+int launch_reduce(const SweepArgs& a, bool has_rhs, bool has_corr, hipStream_t st) {
+    dim3 grid(a.lv.Lpad / 64), block(64);
+    if (has_rhs) {
+        if (has_corr) hipLaunchKernelGGL((k_reduce<D, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_reduce<D, true, false>), grid, block, 0, st, a);
+    } else {
+        if (has_corr) hipLaunchKernelGGL((k_reduce<D, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_reduce<D, false, false>), grid, block, 0, st, a);
+    }
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int D>
+int launch_forward(const SweepArgs& a, bool has_rhs, bool has_corr, bool has_up, hipStream_t st) {
+    dim3 grid(a.lv.Lpad / 64), block(64);
+#define FW(R_, C_, U_) hipLaunchKernelGGL((k_forward<D, R_, C_, U_>), grid, block, 0, st, a)
+    if (has_rhs) {
+        if (has_corr) { if (has_up) FW(true, true, true); else FW(true, true, false); }
+        else { if (has_up) FW(true, false, true); else FW(true, false, false); }
+    } else {
+        if (has_corr) { if (has_up) FW(false, true, true); else FW(false, true, false); }
+        else { if (has_up) FW(false, false, true); else FW(false, false, false); }
+    }
+#undef FW
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int D>
+int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub, hipStream_t st) {
+    dim3 grid(a.lv.Lpad / 64), block(64);
+#define BW(R_, U_, S_) hipLaunchKernelGGL((k_backward<D, R_, U_, S_>), grid, block, 0, st, a)
+    if (has_rhs) {
+        if (has_up) { if (want_sub) BW(true, true, true); else BW(true, true, false); }
+        else { if (want_sub) BW(true, false, true); else BW(true, false, false); }
+    } else {
+        if (has_up) { if (want_sub) BW(false, true, true); else BW(false, true, false); }
+        else { if (want_sub) BW(false, false, true); else BW(false, false, false); }
+    }
+#undef BW
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+// fills the coarse-level pointers of `a` for level l from the workspace
+void bind_level_inputs(const Plan& P, int l, double* ws, SweepArgs& a) {
+    // inputs of level l >= 1 are the reduced system written by reduce(l-1)
+    a.Dg = ws + P.off_Dhat[l];
+    a.Dcorr = ws + P.off_Rsub[l];
+    a.Sg = ws + P.off_S[l];
+    a.rg = ws + P.off_rhat[l];
+    a.rcorr = ws + P.off_rho[l];
+    a.aD = a.aS = a.aR = 1.0;
+    a.Lg = ws + P.off_L[l];
+    a.Gg = ws + P.off_G[l];
+    a.yg = ws + P.off_y[l];
+    a.Sigg = ws + P.off_Sig[l];
+    a.Subg = nullptr;
+    a.mug = ws + P.off_mu[l];
+    a.part = nullptr;
+}
+
+void bind_up(const Plan& P, int l, double* ws, SweepArgs& a) {
+    // coarser level l+1
+    a.up = P.lv[l + 1];
+    a.uDhat = ws + P.off_Dhat[l + 1];
+    a.uRsub = ws + P.off_Rsub[l + 1];
+    a.uS = ws + P.off_S[l + 1];
+    a.urhat = ws + P.off_rhat[l + 1];
+    a.urho = ws + P.off_rho[l + 1];
+    a.uL = ws + P.off_L[l + 1];
+    a.uy = ws + P.off_y[l + 1];
+    a.uSig = ws + P.off_Sig[l + 1];
+    a.umu = ws + P.off_mu[l + 1];
+}
+
+template <int D>
+int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
+                double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info,
+                hipStream_t st) {
+    const bool has_rhs = (rg != nullptr);
+    const int K = P.nlevels - 1;  // top level index (single segment per chain)
+    auto make = [&](int l) {
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.lv = P.lv[l];
+        a.info = info;
+        if (l == 0) {
+            a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
+            a.Lg = Lg; a.Gg = Gg; a.yg = yg;
+            a.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
+        } else {
+            bind_level_inputs(P, l, ws, a);
+        }
+        if (l < K) bind_up(P, l, ws, a);
+        return a;
+    };
+    for (int l = 0; l < K; ++l) {
+        SweepArgs a = make(l);
+        int rc = launch_reduce<D>(a, has_rhs, l > 0, st);
+        if (rc) return rc;
+    }
+    for (int l = K; l >= 0; --l) {
+        SweepArgs a = make(l);
+        int rc = launch_forward<D>(a, has_rhs, l > 0, l < K, st);
+        if (rc) return rc;
+    }
+    if (logdet || quad) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad,
+                           logdet, quad);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+template <int D>
+int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub,
+                double* x, double* ws, hipStream_t st) {
+    const bool has_rhs = (yg != nullptr);
+    const int K = P.nlevels - 1;
+    for (int l = K; l >= 0; --l) {
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.lv = P.lv[l];
+        if (l == 0) {
+            a.Lg = const_cast<double*>(Lg); a.Gg = const_cast<double*>(Gg); a.yg = const_cast<double*>(yg);
+            a.Sigg = Sig; a.Subg = Sub; a.mug = x;
+        } else {
+            bind_level_inputs(P, l, ws, a);
+        }
+        if (l < K) bind_up(P, l, ws, a);
+        int rc = launch_backward<D>(a, has_rhs, l < K, l == 0 && Sub != nullptr, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mfgm_version(void) { return "mfgm 0.1 (gfx950)"; }
+
+int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
+    if (!out || B < 1 || T < 1 || d < 1 || d > 8) return 1;
+    mfgm_plan* h = new mfgm_plan();
+    Plan& P = h->p;
+    memset(&P, 0, sizeof(P));
+    P.B = B; P.T = T; P.d = d;
+    if (Rup <= 1) Rup = 32;
+    if (const char* e = getenv("MFGM_RUP")) { int v = atoi(e); if (v > 1) Rup = v; }
+    if (R0 <= 0) {
+        if (const char* e = getenv("MFGM_R0")) R0 = atoi(e);
+    }
+    if (R0 <= 0) {
+        const long long target = 65536;  // ~ one wavefront per SIMD on 256 CUs
+        long long r = ((long long)B * T + target - 1) / target;
+        R0 = (int)std::min<long long>(std::max<long long>(r, 8), 1 << 20);
+    }
+    int n = T, l = 0;
+    const int top = 48;  // chains this short are swept by one lane
+    while (true) {
+        int R = (l == 0) ? R0 : Rup;
+        if (R < 2) R = 2;
+        const bool single = (n <= R) || (l > 0 && n <= top) || (l == kMaxLevels - 1);
+        if (single) {
+            fill_level(P.lv[l], B, n, n);  // one segment per chain: plain sequential sweep
+            ++l;
+            break;
+        }
+        fill_level(P.lv[l], B, n, R);
+        n = P.lv[l].P;
+        ++l;
+    }
+    P.nlevels = l;
+    const int ET = d * (d + 1) / 2, EF = d * d;
+    size_t off = 0;
+    auto take = [&](size_t nd) { size_t o = off; off += (nd + 63) / 64 * 64; return o; };
+    P.off_part[0] = take(2 * (size_t)P.lv[0].Lpad);
+    for (int i = 1; i < P.nlevels; ++i) {
+        const LevelDesc& lv = P.lv[i];
+        P.off_Dhat[i] = take(packed_elems(lv, ET));
+        P.off_Rsub[i] = take(packed_elems(lv, ET));
+        P.off_S[i] = take(packed_elems(lv, EF));
+        P.off_rhat[i] = take(packed_elems(lv, d));
+        P.off_rho[i] = take(packed_elems(lv, d));
+        P.off_L[i] = take(packed_elems(lv, ET));
+        P.off_G[i] = take(packed_elems(lv, EF));
+        P.off_y[i] = take(packed_elems(lv, d));
+        P.off_Sig[i] = take(packed_elems(lv, ET));
+        P.off_mu[i] = take(packed_elems(lv, d));
+    }
+    P.ws_doubles = off;
+    *out = h;
+    return 0;
+}
+
+void mfgm_plan_destroy(mfgm_plan* plan) { delete plan; }
+
+int mfgm_plan_describe(const mfgm_plan* plan, int* out6) {
+    if (!plan || !out6) return 1;
+    const Plan& P = plan->p;
+    out6[0] = P.nlevels; out6[1] = P.lv[0].R; out6[2] = P.lv[0].P; out6[3] = P.lv[0].Lpad; out6[4] = P.B; out6[5] = P.T;
+    return 0;
+}
+
+size_t mfgm_plan_workspace_bytes(const mfgm_plan* plan) { return plan ? plan->p.ws_doubles * sizeof(double) : 0; }
+
+size_t mfgm_packed_doubles(const mfgm_plan* plan, int kind) {
+    if (!plan || kind < 0 || kind > 3) return 0;
+    return packed_elems(plan->p.lv[0], kind_epack(kind, plan->p.d));
+}
+
+static int repack(const mfgm_plan* plan, int kind, const double* src, double* dst, int n_nodes, bool pack, void* stream) {
+    if (!plan || !src || !dst || kind < 0 || kind > 3) return 1;
+    const Plan& P = plan->p;
+    if (n_nodes < 0 || n_nodes > P.T) return 1;
+    const LevelDesc& lv = P.lv[0];
+    const int En = kind_enat(kind, P.d);
+    int CH = std::max(1, 64 / En);
+    CH = std::min(CH, lv.R);
+    dim3 grid(lv.Lpad / 64, ceil_div(lv.R, CH)), block(256);
+    size_t shmem = (size_t)64 * (CH * En + 1) * sizeof(double);
+    hipStream_t st = (hipStream_t)stream;
+    if (pack) hipLaunchKernelGGL((k_repack<true>), grid, block, shmem, st, src, dst, lv, P.d, kind, n_nodes, CH);
+    else hipLaunchKernelGGL((k_repack<false>), grid, block, shmem, st, src, dst, lv, P.d, kind, n_nodes, CH);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_pack(const mfgm_plan* plan, int kind, const double* natural, int n_nodes, double* packed, void* stream) {
+    return repack(plan, kind, natural, packed, n_nodes, true, stream);
+}
+
+int mfgm_unpack(const mfgm_plan* plan, int kind, const double* packed, double* natural, int n_nodes, void* stream) {
+    return repack(plan, kind, packed, natural, n_nodes, false, stream);
+}
+
+#define MFGM_DISPATCH_D(d, CALL)             \
+    switch (d) {                             \
+        case 1: { constexpr int DD = 1; return CALL; } \
+        case 2: { constexpr int DD = 2; return CALL; } \
+        case 3: { constexpr int DD = 3; return CALL; } \
+        case 4: { constexpr int DD = 4; return CALL; } \
+        case 5: { constexpr int DD = 5; return CALL; } \
+        case 6: { constexpr int DD = 6; return CALL; } \
+        case 7: { constexpr int DD = 7; return CALL; } \
+        case 8: { constexpr int DD = 8; return CALL; } \
+        default: return 1;                   \
+    }
+
+int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, const double* r, double aD, double aS,
+                       double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                       void* stream) {
+    if (!plan || !D || !L || !G || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !S) return 1;
+    if ((r != nullptr) != (y != nullptr)) return 1;
+    if (!ws && P.ws_doubles > 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (factor_impl<DD>(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, st)));
+}
+
+int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, const double* y, double* Sig,
+                       double* Sub, double* x, void* ws, void* stream) {
+    if (!plan || !L || !G || !Sig) return 1;
+    const Plan& P = plan->p;
+    if ((y != nullptr) != (x != nullptr)) return 1;
+    if (!ws && P.ws_doubles > 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st)));
+}
+
+}  // extern "C"

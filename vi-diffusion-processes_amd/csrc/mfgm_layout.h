@@ -1,0 +1,42 @@
+// Packed ("segment-interleaved") HBM layout and the multi-level partition plan.
+//
+// A chain of n nodes is cut into P = ceil(n/R) segments of R nodes; the LAST node of every segment is
+// a separator.  One GPU lane owns one (chain b, segment p): lane = b*P + p.  For a per-node quantity
+// with E doubles the element (lane, step s, e) lives at
+//
+//        ((s*E + e) * Lpad + lane)            Lpad = lanes rounded up to 64
+//
+// so that, for a fixed (s, e), the 64 lanes of a wavefront read 512 contiguous bytes: every load and
+// store of the sequential sweeps is fully coalesced along the segment axis while each lane still walks
+// its own piece of the time axis in order.  The separators of level l form the chain of level l+1
+// (n_{l+1} = P_l), which is packed the same way, until a level has a single segment per chain.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace mfgm {
+
+struct LevelDesc {
+    int n;      // nodes per chain at this level
+    int R;      // nodes per segment (last one is the separator)
+    int P;      // segments per chain
+    int L;      // lanes = B * P
+    int Lpad;   // lanes padded to a multiple of 64
+};
+
+constexpr int kMaxLevels = 8;
+
+struct Plan {
+    int B, T, d;
+    int nlevels;
+    LevelDesc lv[kMaxLevels];
+    // per-level workspace offsets (in doubles) into the plan-owned level workspace, levels >= 1
+    size_t off_Dhat[kMaxLevels], off_Rsub[kMaxLevels], off_S[kMaxLevels], off_rhat[kMaxLevels], off_rho[kMaxLevels];
+    size_t off_L[kMaxLevels], off_G[kMaxLevels], off_y[kMaxLevels], off_Sig[kMaxLevels], off_mu[kMaxLevels];
+    size_t off_part[kMaxLevels];   // per-lane partial sums (2 * Lpad doubles), all levels incl. 0
+    size_t ws_doubles;             // total workspace size in doubles
+};
+
+inline size_t packed_elems(const LevelDesc& lv, int E) { return (size_t)lv.R * E * lv.Lpad; }
+
+}  // namespace mfgm

@@ -1,0 +1,422 @@
+// The three sweep kernels of the partitioned block-tri-diagonal SPD solver (lane = one chain segment).
+//
+//   reduce   : eliminates the interior of every segment, emitting the separator (reduced) system
+//   forward  : natural-order block Cholesky  L_tt, L_{t+1,t}, y = L^{-1} r   (+ log|L|, |y|^2 partials)
+//   backward : Takahashi selected inverse   S_tt, S_{t+1,t}  and  x = L^{-T} y
+//
+// They replace, fused and block-specialised, what the reference gets from banded_matrices'
+// cholesky_band / solve_triang_mat / inverse_from_cholesky_band (block_tri_diag.py:330-331,350,440;
+// ssm_gaussian_transformations.py:443-444).  All arrays use the packed layout of mfgm_layout.h.
+#pragma once
+#include "mfgm_layout.h"
+#include "mfgm_math.h"
+
+namespace mfgm {
+
+// ---- packed-layout element access --------------------------------------------------------------
+template <int E>
+MFGM_DEV void ld_node(const double* __restrict__ base, int Lpad, int s, int lane, double (&out)[E]) {
+    const double* p = base + (size_t)s * E * Lpad;
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] = p[(size_t)e * Lpad + lane];
+}
+template <int E>
+MFGM_DEV void st_node(double* __restrict__ base, int Lpad, int s, int lane, const double (&v)[E]) {
+    double* p = base + (size_t)s * E * Lpad;
+#pragma unroll
+    for (int e = 0; e < E; ++e) p[(size_t)e * Lpad + lane] = v[e];
+}
+template <int E>
+MFGM_DEV void st_node_zero(double* __restrict__ base, int Lpad, int s, int lane) {
+    double* p = base + (size_t)s * E * Lpad;
+#pragma unroll
+    for (int e = 0; e < E; ++e) p[(size_t)e * Lpad + lane] = 0.0;
+}
+
+struct SweepArgs {
+    LevelDesc lv;          // this level
+    LevelDesc up;          // next (coarser) level, valid when the level has more than one segment
+    // inputs of this level
+    const double* Dg;      // tri-packed symmetric diagonal blocks
+    const double* Sg;      // full sub-diagonal blocks, S at node t couples t -> t+1
+    const double* rg;      // right-hand side (may be null when !HAS_RHS)
+    const double* Dcorr;   // level >= 1: subtract (spike Gram term of the segment to the right)
+    const double* rcorr;
+    double aD, aS, aR;     // scales applied on load (e.g. -2, -1, 1 turn natural parameters into a precision)
+    // factor outputs of this level
+    double* Lg;            // tri-packed L_tt
+    double* Gg;            // full L_{t+1,t} stored at node t
+    double* yg;            // L^{-1} r
+    double* part;          // [2*Lpad] per-lane partial log|L| and |y|^2 (may be null)
+    // selected-inverse outputs of this level
+    double* Sigg;          // tri-packed S_tt
+    double* Subg;          // full S_{t+1,t} at node t (may be null)
+    double* mug;           // L^{-T} y
+    // coarser level arrays
+    double* uDhat; double* uRsub; double* uS; double* urhat; double* urho;   // written by reduce
+    const double* uL; const double* uy;                                         // read by forward
+    const double* uSig; const double* umu;                                      // read by backward
+    int* info;             // set non-zero when a pivot block is not positive definite
+};
+
+// ---- reduce -------------------------------------------------------------------------------------
+template <int D, bool HAS_RHS, bool HAS_CORR>
+__global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, a.lv.n - p * R);
+    int bad = 0;
+
+    double F[ET], W[EF], h[D], Racc[ET], rho[D];
+    ld_node<ET>(a.Dg, Lp, 0, lane, F);
+#pragma unroll
+    for (int e = 0; e < ET; ++e) F[e] *= a.aD;
+    if (HAS_CORR) {
+        double c[ET];
+        ld_node<ET>(a.Dcorr, Lp, 0, lane, c);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) F[e] -= c[e];
+    }
+    if (p > 0) {
+        ld_node<EF>(a.Sg, Lp, R - 1, lane - 1, W);
+#pragma unroll
+        for (int e = 0; e < EF; ++e) W[e] *= a.aS;
+    } else {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) W[e] = 0.0;
+    }
+    if (HAS_RHS) {
+        ld_node<D>(a.rg, Lp, 0, lane, h);
+#pragma unroll
+        for (int e = 0; e < D; ++e) h[e] *= a.aR;
+        if (HAS_CORR) {
+            double c[D];
+            ld_node<D>(a.rcorr, Lp, 0, lane, c);
+#pragma unroll
+            for (int e = 0; e < D; ++e) h[e] -= c[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < D; ++e) h[e] = 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < ET; ++e) Racc[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < D; ++e) rho[e] = 0.0;
+
+    // Loads of a step are issued at its top and consumed in its second half (S after the spike solve,
+    // D and r at the very end), so their latency hides under the step's own arithmetic and no second
+    // register buffer is needed.  Scales / corrections are applied at the point of use, never at the load.
+    for (int s = 0; s < R - 1; ++s) {
+        if (s < len - 1) {
+            double G[EF], Dn[ET], rn[D], Dc[HAS_CORR ? ET : 1], rc[HAS_CORR ? D : 1];
+            ld_node<EF>(a.Sg, Lp, s, lane, G);
+            ld_node<ET>(a.Dg, Lp, s + 1, lane, Dn);
+            if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, Lp, s + 1, lane, reinterpret_cast<double(&)[ET]>(Dc));
+            if (HAS_RHS) {
+                ld_node<D>(a.rg, Lp, s + 1, lane, rn);
+                if constexpr (HAS_CORR) ld_node<D>(a.rcorr, Lp, s + 1, lane, reinterpret_cast<double(&)[D]>(rc));
+            }
+            // eliminate interior node s
+            double invd[D];
+            chol_inplace<D>(F, invd, bad);
+            trsm_left_lower<D>(F, invd, W);        // W := L^{-1} W   (spike towards the left separator)
+            syrk_t_acc<D>(W, Racc);                // R += W^T W
+            if (HAS_RHS) {
+                trsv_lower<D>(F, invd, h);         // y := L^{-1} h
+                double t[D];
+                gemv_t<D>(W, h, t);
+#pragma unroll
+                for (int e = 0; e < D; ++e) rho[e] += t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EF; ++e) G[e] *= a.aS;
+            trsm_right_lower_t<D>(F, invd, G);     // G := S L^{-T}
+            // Schur complement onto node s+1
+            syrk_set<D>(G, F);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) F[e] = __builtin_fma(a.aD, Dn[e], -F[e]) - (HAS_CORR ? Dc[e] : 0.0);
+#pragma unroll
+            for (int c = 0; c < D; ++c) {          // W := -G W, column by column in place
+                double col[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) col[k] = W[k * D + c];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], col[k], t);
+                    W[i * D + c] = -t;
+                }
+            }
+            if (HAS_RHS) {
+                double t[D];
+                gemv<D>(G, h, t);
+#pragma unroll
+                for (int e = 0; e < D; ++e) h[e] = __builtin_fma(a.aR, rn[e], -t[e]) - (HAS_CORR ? rc[e] : 0.0);
+            }
+        }
+    }
+    // separator of this segment is node q = p of the coarser level
+    const int uP = a.up.P, uR = a.up.R, uLp = a.up.Lpad;
+    {
+        const int q = p, ul = b * uP + q / uR, us = q % uR;
+        st_node<ET>(a.uDhat, uLp, us, ul, F);
+        st_node<D>(a.urhat, uLp, us, ul, h);
+        if (p == P - 1) {
+            st_node_zero<ET>(a.uRsub, uLp, us, ul);
+            st_node_zero<D>(a.urho, uLp, us, ul);
+            st_node_zero<EF>(a.uS, uLp, us, ul);
+        }
+    }
+    if (p > 0) {
+        const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
+        st_node<EF>(a.uS, uLp, us, ul, W);      // couples separator p-1 -> p
+        st_node<ET>(a.uRsub, uLp, us, ul, Racc);
+        st_node<D>(a.urho, uLp, us, ul, rho);
+    }
+    if (bad) atomicMax(a.info, 1);
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+template <int D, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
+__global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    int bad = 0;
+
+    double C[ET], c[D];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) C[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < D; ++e) c[e] = 0.0;
+
+    if (HAS_UP && p > 0) {
+        // natural-order Cholesky state at the separator to the left:
+        //   F_a = Ltil Ltil^T + R_p ,  h_a = Ltil ytil + rho_p
+        const int uP = a.up.P, uR = a.up.R, uLp = a.up.Lpad;
+        const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
+        double Lt[ET], Fa[ET], ha[D], invd[D];
+        ld_node<ET>(a.uL, uLp, us, ul, Lt);
+        ld_node<ET>(a.uRsub, uLp, us, ul, Fa);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double t = Fa[tix(i, j)];
+#pragma unroll
+                for (int k = 0; k <= j; ++k) t = __builtin_fma(Lt[tix(i, k)], Lt[tix(j, k)], t);
+                Fa[tix(i, j)] = t;
+            }
+        if (HAS_RHS) {
+            double yt[D];
+            ld_node<D>(a.uy, uLp, us, ul, yt);
+            ld_node<D>(a.urho, uLp, us, ul, ha);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double t = ha[i];
+#pragma unroll
+                for (int k = 0; k <= i; ++k) t = __builtin_fma(Lt[tix(i, k)], yt[k], t);
+                ha[i] = t;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < D; ++e) ha[e] = 0.0;
+        }
+        chol_inplace<D>(Fa, invd, bad);
+        trsv_lower<D>(Fa, invd, ha);
+        double Ga[EF];
+        ld_node<EF>(a.Sg, Lp, R - 1, lane - 1, Ga);
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Ga[e] *= a.aS;
+        trsm_right_lower_t<D>(Fa, invd, Ga);
+        syrk_set<D>(Ga, C);
+        gemv<D>(Ga, ha, c);
+    }
+    // keep the first step's loads below the boundary arithmetic (the two together overflow the register file)
+    __builtin_amdgcn_sched_barrier(0);
+
+    LogAcc la;
+    la.init();
+    double quad = 0.0;
+
+    // cross-iteration register prefetch: the raw blocks of step s+1 are in flight while step s is factored;
+    // scales / corrections are applied at the point of use so no wait is forced at the load.
+    double Fn[ET], Gn[EF], rn[D], Fc[HAS_CORR ? ET : 1], rc[HAS_CORR ? D : 1];
+    auto load_step = [&](int s) {
+        ld_node<ET>(a.Dg, Lp, s, lane, Fn);
+        if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, Lp, s, lane, reinterpret_cast<double(&)[ET]>(Fc));
+        if (p * R + s + 1 < n) {
+            ld_node<EF>(a.Sg, Lp, s, lane, Gn);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EF; ++e) Gn[e] = 0.0;
+        }
+        if (HAS_RHS) {
+            ld_node<D>(a.rg, Lp, s, lane, rn);
+            if constexpr (HAS_CORR) ld_node<D>(a.rcorr, Lp, s, lane, reinterpret_cast<double(&)[D]>(rc));
+        }
+    };
+    load_step(0);
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            double F[ET], G[EF], h[D];
+#pragma unroll
+            for (int e = 0; e < ET; ++e) F[e] = __builtin_fma(a.aD, Fn[e], -C[e]) - (HAS_CORR ? Fc[e] : 0.0);
+#pragma unroll
+            for (int e = 0; e < EF; ++e) G[e] = Gn[e] * a.aS;
+#pragma unroll
+            for (int e = 0; e < D; ++e)
+                h[e] = HAS_RHS ? (__builtin_fma(a.aR, rn[e], -c[e]) - (HAS_CORR ? rc[e] : 0.0)) : 0.0;
+            if (s + 1 < len) load_step(s + 1);
+            double invd[D];
+            chol_inplace<D>(F, invd, bad);
+            if (HAS_RHS) trsv_lower<D>(F, invd, h);
+            trsm_right_lower_t<D>(F, invd, G);
+            st_node<ET>(a.Lg, Lp, s, lane, F);
+            st_node<EF>(a.Gg, Lp, s, lane, G);
+            if (HAS_RHS) st_node<D>(a.yg, Lp, s, lane, h);
+            syrk_set<D>(G, C);
+            if (HAS_RHS) gemv<D>(G, h, c);
+#pragma unroll
+            for (int j = 0; j < D; ++j) la.mul(F[tix(j, j)]);
+            la.renorm();
+#pragma unroll
+            for (int j = 0; j < D; ++j) quad = __builtin_fma(h[j], h[j], quad);
+        }
+    }
+    if (a.part) {
+        a.part[lane] = la.value();
+        a.part[Lp + lane] = quad;
+    }
+    if (bad) atomicMax(a.info, 1);
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB>
+__global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    const int se = len - 1;
+
+    double Sn[ET], xn[D];
+    if (HAS_UP) {
+        const int uP = a.up.P, uR = a.up.R, uLp = a.up.Lpad;
+        const int q = p, ul = b * uP + q / uR, us = q % uR;
+        ld_node<ET>(a.uSig, uLp, us, ul, Sn);
+        if (HAS_RHS) ld_node<D>(a.umu, uLp, us, ul, xn);
+    } else {
+        double Lt[ET], invd[D], X[ET];
+        ld_node<ET>(a.Lg, Lp, se, lane, Lt);
+#pragma unroll
+        for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
+        tri_inverse<D>(Lt, invd, X);
+        tri_t_tri<D>(X, Sn);
+        if (HAS_RHS) {
+            ld_node<D>(a.yg, Lp, se, lane, xn);
+            trsv_lower_t<D>(Lt, invd, xn);
+        }
+    }
+    if (!HAS_RHS) {
+#pragma unroll
+        for (int e = 0; e < D; ++e) xn[e] = 0.0;
+    }
+    st_node<ET>(a.Sigg, Lp, se, lane, Sn);
+    if (HAS_RHS) st_node<D>(a.mug, Lp, se, lane, xn);
+    if (WANT_SUB && (p * R + se == n - 1)) st_node_zero<EF>(a.Subg, Lp, se, lane);
+
+    double Ln[ET], Gn[EF], yn[D];
+    if (len > 1) {
+        ld_node<ET>(a.Lg, Lp, se - 1, lane, Ln);
+        ld_node<EF>(a.Gg, Lp, se - 1, lane, Gn);
+        if (HAS_RHS) ld_node<D>(a.yg, Lp, se - 1, lane, yn);
+    }
+    for (int s = R - 2; s >= 0; --s) {
+        if (s < len - 1) {
+            double Lt[ET], G[EF], x[D];
+#pragma unroll
+            for (int e = 0; e < ET; ++e) Lt[e] = Ln[e];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) G[e] = Gn[e];
+#pragma unroll
+            for (int e = 0; e < D; ++e) x[e] = HAS_RHS ? yn[e] : 0.0;
+            if (s > 0) {
+                ld_node<ET>(a.Lg, Lp, s - 1, lane, Ln);
+                ld_node<EF>(a.Gg, Lp, s - 1, lane, Gn);
+                if (HAS_RHS) ld_node<D>(a.yg, Lp, s - 1, lane, yn);
+            }
+            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET];
+#pragma unroll
+            for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
+            tri_inverse<D>(Lt, invd, X);
+            gemm_full_tri<D>(G, X, H);            // H = L_{t+1,t} L_tt^{-1}
+            gemm_sym_full<D>(Sn, H, Ssub);        // S_{t+1,t+1} H
+#pragma unroll
+            for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
+            tri_t_tri<D>(X, Sig);                 // L^{-T} L^{-1}
+            gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);  // - S_{t+1,t}^T H
+            if (HAS_RHS) {
+                double t[D];
+                gemv_t<D>(G, xn, t);
+#pragma unroll
+                for (int e = 0; e < D; ++e) x[e] -= t[e];
+                trsv_lower_t<D>(Lt, invd, x);
+                st_node<D>(a.mug, Lp, s, lane, x);
+#pragma unroll
+                for (int e = 0; e < D; ++e) xn[e] = x[e];
+            }
+            st_node<ET>(a.Sigg, Lp, s, lane, Sig);
+            if (WANT_SUB) st_node<EF>(a.Subg, Lp, s, lane, Ssub);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) Sn[e] = Sig[e];
+        }
+    }
+    if (WANT_SUB && p > 0) {
+        // S_{t0, t0-1} for the separator on the left, whose own blocks belong to lane-1
+        double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF];
+        ld_node<ET>(a.Lg, Lp, R - 1, lane - 1, Lt);
+        ld_node<EF>(a.Gg, Lp, R - 1, lane - 1, G);
+#pragma unroll
+        for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
+        tri_inverse<D>(Lt, invd, X);
+        gemm_full_tri<D>(G, X, H);
+        gemm_sym_full<D>(Sn, H, Ssub);
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
+        st_node<EF>(a.Subg, Lp, R - 1, lane - 1, Ssub);
+    }
+}
+
+// ---- per-chain sum of the per-lane partials ---------------------------------------------------------
+// part: [2*Lpad]; out_logdet[b] = sum_p part[b*P+p]; out_quad[b] likewise.  One wave per chain.
+__global__ __launch_bounds__(64) void k_sum_partials(const double* part, int P, int Lpad, double* out_logdet,
+                                                    double* out_quad) {
+    const int b = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int p = threadIdx.x; p < P; p += 64) {
+        s0 += part[(size_t)b * P + p];
+        s1 += part[(size_t)Lpad + (size_t)b * P + p];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        if (out_logdet) out_logdet[b] = s0;
+        if (out_quad) out_quad[b] = s1;
+    }
+}
+
+}  // namespace mfgm

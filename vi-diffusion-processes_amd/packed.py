@@ -1,0 +1,108 @@
+"""
+Device-resident packed tensors and the partition plan (thin wrapper over the C ABI).
+
+PyTorch is used only as the owner of device memory and of the HIP stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FULL, SYM, TRI, VEC
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Plan:
+    """Partition plan for B chains of T nodes with d x d blocks (mfgm_plan_create)."""
+
+    def __init__(self, B, T, d, R0=0, Rup=0, device="cuda"):
+        self.lib = _lib.load()
+        self.B, self.T, self.d = int(B), int(T), int(d)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.mfgm_plan_create(self.B, self.T, self.d, int(R0), int(Rup), ctypes.byref(h)),
+                   f"mfgm_plan_create(B={B}, T={T}, d={d})")
+        self.h = h
+        desc = (ctypes.c_int * 6)()
+        self.lib.mfgm_plan_describe(self.h, desc)
+        self.nlevels, self.R, self.P, self.Lpad = desc[0], desc[1], desc[2], desc[3]
+        self.device = torch.device(device)
+        nbytes = self.lib.mfgm_plan_workspace_bytes(self.h)
+        self.ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=self.device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.mfgm_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- storage ------------------------------------------------------------------------------
+    def empty(self, kind):
+        n = self.lib.mfgm_packed_doubles(self.h, kind)
+        return torch.empty(n, dtype=torch.float64, device=self.device)
+
+    def zeros(self, kind):
+        n = self.lib.mfgm_packed_doubles(self.h, kind)
+        return torch.zeros(n, dtype=torch.float64, device=self.device)
+
+    def pack(self, kind, natural, out=None):
+        """natural: [B, n_nodes, ...] contiguous fp64 device tensor; n_nodes = T or T-1."""
+        natural = natural.contiguous()
+        assert natural.dtype == torch.float64 and natural.is_cuda
+        assert natural.shape[0] == self.B, (natural.shape, self.B)
+        n_nodes = natural.shape[1]
+        out = self.zeros(kind) if out is None else out
+        _lib.check(self.lib.mfgm_pack(self.h, kind, _ptr(natural), n_nodes, _ptr(out), _stream()), "mfgm_pack")
+        return out
+
+    def unpack(self, kind, packed, n_nodes=None):
+        n_nodes = self.T if n_nodes is None else n_nodes
+        shape = (self.B, n_nodes, self.d) if kind == VEC else (self.B, n_nodes, self.d, self.d)
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_unpack(self.h, kind, _ptr(packed), _ptr(out), n_nodes, _stream()), "mfgm_unpack")
+        return out
+
+    # -- sweeps -------------------------------------------------------------------------------
+    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False, out=None):
+        """Block Cholesky (+ forward substitution).  Returns dict(L, G, y, logdet, quad)."""
+        out = {} if out is None else out
+        L = out.get("L") if out.get("L") is not None else self.empty(TRI)
+        G = out.get("G") if out.get("G") is not None else self.empty(FULL)
+        y = None
+        if r is not None:
+            y = out.get("y") if out.get("y") is not None else self.empty(VEC)
+        logdet = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_logdet else None
+        quad = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_quad else None
+        _lib.check(self.lib.mfgm_packed_factor(self.h, _ptr(D), _ptr(S), _ptr(r), float(aD), float(aS), float(aR),
+                                               _ptr(L), _ptr(G), _ptr(y), _ptr(logdet), _ptr(quad), _ptr(self.ws),
+                                               _ptr(self.info), _stream()), "mfgm_packed_factor")
+        return dict(L=L, G=G, y=y, logdet=logdet, quad=quad)
+
+    def selinv(self, L, G, y=None, want_sub=True, out=None):
+        """Selected inverse (+ backward substitution).  Returns dict(Sig, Sub, x)."""
+        out = {} if out is None else out
+        Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
+        Sub = None
+        if want_sub:
+            Sub = out.get("Sub") if out.get("Sub") is not None else self.empty(FULL)
+        x = None
+        if y is not None:
+            x = out.get("x") if out.get("x") is not None else self.empty(VEC)
+        _lib.check(self.lib.mfgm_packed_selinv(self.h, _ptr(L), _ptr(G), _ptr(y), _ptr(Sig), _ptr(Sub), _ptr(x),
+                                               _ptr(self.ws), _stream()), "mfgm_packed_selinv")
+        return dict(Sig=Sig, Sub=Sub, x=x)
+
+    def check_info(self):
+        """Raise ArithmeticError if a pivot block was not positive definite (synchronises)."""
+        if int(self.info.item()) != 0:
+            self.info.zero_()
+            raise ArithmeticError("block-tri-diagonal matrix is not positive definite")
