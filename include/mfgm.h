@@ -75,6 +75,35 @@ int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, 
 int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, const double* y, double* Sig,
                        double* Sub, double* x, void* ws, void* stream);
 
+/* out = a*x + b*y + c*z over n doubles (y and z may be NULL): the element-wise site / natural-parameter
+ * arithmetic of the CVI updates (variational_cvi_sde.py:161-174, 279-317) on packed arrays. */
+int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, const double* y, double c,
+                 const double* z, void* stream);
+
+/* Sparse node lists (observation times on the grid): node_ids[i] = b*T + t (int64, device), values natural
+ * [n, d] / [n, d, d].  mode 0: gather packed -> values; 1: scatter values -> packed (overwrite);
+ * 2: packed += values.  Replaces tf.scatter_nd / tf.gather_nd at variational_cvi_sde.py:167-172, 303-304 and
+ * kalman_filter.py:577. */
+int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, const long long* node_ids, int n, double* values,
+                 int mode, void* stream);
+
+/* SSM parameters -> natural parameters (cD=-0.5, cS=1; ssm_gaussian_transformations.py:182-253 `ssm_to_naturals`)
+ * or precision blocks (cD=1, cS=-1; state_space_model.py:431-483 `_build_precision`), all packed:
+ *   A (FULL, transition t->t+1 at node t), off (VEC: mu0 then b_k), chol (TRI: chol P0 then chol Q_k)
+ *   -> lin (VEC, may be NULL together with off), diag (SYM), sub (FULL),
+ *      sumlogchol[B] = sum_t log|chol_t| (may be NULL) i.e. -1/2 log det of the precision
+ *      (state_space_model.py:343-373 `log_det_precision`). */
+int mfgm_packed_ssm_to_naturals(const mfgm_plan* plan, const double* A, const double* off, const double* chol, double cD,
+                                double cS, double* lin, double* diag, double* sub, double* sumlogchol, void* ws,
+                                void* stream);
+
+/* Trace and Mahalanobis terms of KL(q || p) (state_space_model.py:557-593): q given by marginal blocks
+ * Sig (SYM), Sub (FULL), mu (VEC); p by precision blocks aD*Pd (SYM), aS*Ps (FULL) and marginal means mup.
+ * trace[B], maha[B]. */
+int mfgm_packed_kl_terms(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* mu, const double* Pd,
+                         const double* Ps, double aD, double aS, const double* mup, double* trace, double* maha, void* ws,
+                         void* stream);
+
 const char* mfgm_version(void);
 
 #ifdef __cplusplus

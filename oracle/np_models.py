@@ -1,0 +1,96 @@
+"""
+Oracle (test infrastructure, see oracle/__init__.py): the site-based CVI models of
+markovflow/models/variational_cvi_sde.py (`CVISitesSSM`) and markovflow/models/variational_cvi.py
+(`CVIGaussianProcess`), single trajectory, NumPy, following the reference's own op sequence
+(every property rebuilt from the sites).
+
+Parity note: the reference has no test for CVISitesSSM / CVISitesSDE; the only pin is the conjugate case
+KA11 of SURVEY.md 8c (OU prior, Gaussian likelihood, lr = 1 => ELBO equals the Kalman log marginal
+likelihood), which tests/test_oracle_models.py checks against the reference's NumPy Kalman filter.
+"""
+import numpy as np
+
+from . import np_btd, np_kalman, np_transforms
+from .np_ssm import StateSpaceModel, chol_solve
+
+
+class MultivariateGaussianLik:
+    """markovflow/likelihoods/multivariate_gaussian.py:80-115."""
+
+    def __init__(self, chol_covariance):
+        self.chol = np.asarray(chol_covariance, dtype=np.float64)
+        self.d = self.chol.shape[-1]
+        self.inv_cov = chol_solve(self.chol, np.eye(self.d))
+
+    def variational_expectations(self, mu, cov, y):
+        z = np.linalg.solve(self.chol, (y - mu)[..., None])[..., 0]
+        logp = -0.5 * np.sum(z * z, -1) - np.sum(np.log(np.diag(self.chol))) - 0.5 * self.d * np.log(2 * np.pi)
+        return -0.5 * np.sum(self.inv_cov * cov, axis=(-1, -2)) + logp
+
+    def grads_expectation(self, mu, cov, y):
+        """d sum VE / d(mu, S) mapped to d / d(mu, S + mu mu^T) (variational_cvi.py:448-462)."""
+        dmu = (self.inv_cov @ (y - mu)[..., None])[..., 0]
+        dS = np.broadcast_to(-0.5 * self.inv_cov, cov.shape)
+        return dmu - 2.0 * (dS @ mu[..., None])[..., 0], dS
+
+
+class CVISitesSSM:
+    """variational_cvi_sde.py:49-366 with a linear prior SSM; KL by the exact Gauss-Markov formula."""
+
+    def __init__(self, prior_ssm: StateSpaceModel, time_grid, obs_index, observations, likelihood):
+        self.dist_p = prior_ssm
+        self.time_grid = np.asarray(time_grid)
+        self.obs_index = np.asarray(obs_index)
+        self.y = np.asarray(observations, dtype=np.float64)
+        self.lik = likelihood
+        T, d = self.time_grid.shape[0], self.y.shape[-1]
+        self.T, self.d = T, d
+        self.g1 = np.zeros((T, d))
+        self.g2d = -1e-10 * np.ones((T, d, d))
+        self.g2s = -1e-10 * np.ones((T - 1, d, d))
+        self.d1 = np.zeros((self.y.shape[0], d))
+        self.d2 = 1e-10 * np.broadcast_to(np.eye(d), (self.y.shape[0], d, d)).copy()
+        self.fx_mus = np.zeros((T, d))
+        self.fx_covs = np.broadcast_to(np.eye(d), (T, d, d)).copy()
+
+    def _scatter(self, vals, shape):
+        out = np.zeros(shape)
+        np.add.at(out, self.obs_index, vals)
+        return out
+
+    def full_sites(self):
+        p1, pd, ps = np_transforms.ssm_to_naturals(self.dist_p)
+        return (p1 + self.g1 + self._scatter(self.d1, self.g1.shape),
+                pd + self.g2d + self._scatter(self.d2, self.g2d.shape), ps + self.g2s)
+
+    @property
+    def dist_q(self):
+        return np_transforms.ssm_from_params(np_transforms.naturals_to_ssm_params(*self.full_sites()))
+
+    def update_data_sites(self, lr):
+        g1, g2 = self.lik.grads_expectation(self.fx_mus[self.obs_index], self.fx_covs[self.obs_index], self.y)
+        self.d1 = (1 - lr) * self.d1 + lr * g1
+        self.d2 = (1 - lr) * self.d2 + lr * g2
+        self.fx_mus, self.fx_covs = self.dist_q.marginals
+
+    def grad_kl_wrt_exp_param(self):
+        q = self.full_sites()
+        p = np_transforms.ssm_to_naturals(self.dist_p)
+        return tuple(a - b for a, b in zip(q, p))
+
+    def update_girsanov_sites(self, lr):
+        gk = self.grad_kl_wrt_exp_param()
+        self.g1 = self.g1 + lr * (self._scatter(self.d1, self.g1.shape) - gk[0])
+        self.g2d = self.g2d + lr * (self._scatter(self.d2, self.g2d.shape) - gk[1])
+        self.g2s = self.g2s - lr * gk[2]
+        self.fx_mus, self.fx_covs = self.dist_q.marginals
+
+    def variational_expectation(self):
+        mu, cov = self.dist_q.marginals
+        return np.sum(self.lik.variational_expectations(mu[self.obs_index], cov[self.obs_index], self.y))
+
+    def KL_q_p(self):
+        return self.dist_q.kl_divergence(self.dist_p)
+
+    def classic_elbo(self):
+        return self.variational_expectation() - self.KL_q_p()

@@ -1,0 +1,63 @@
+"""CPU tests of the oracle's model layer (CVISitesSSM with a linear prior)."""
+import numpy as np
+import pytest
+
+from oracle import np_kalman, np_models, np_ssm
+from tests.helpers import random_ssm_params
+
+
+def ou_euler_ssm(T, dt, decay, q, d=1):
+    """Euler discretisation LinearDrift.to_ssm of dx = -decay x dt + sqrt(q) dB (drift.py:102-108), P0 = q/(2 decay)."""
+    A = np.broadcast_to((1.0 - decay * dt) * np.eye(d), (T - 1, d, d)).copy()
+    b = np.zeros((T - 1, d))
+    cholQ = np.broadcast_to(np.sqrt(q * dt) * np.eye(d), (T - 1, d, d)).copy()
+    cholP0 = np.sqrt(q / (2 * decay)) * np.eye(d)
+    return np_ssm.StateSpaceModel(np.zeros(d), cholP0, A, b, cholQ)
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_conjugate_cvi_equals_kalman(rng, d):
+    """KA11: Gaussian likelihood, one data-site update with lr=1 -> ELBO == log marginal likelihood."""
+    T, dt = 80, 0.01
+    ssm = ou_euler_ssm(T, dt, decay=1.2, q=1.0, d=d)
+    idx = np.sort(rng.choice(T, size=9, replace=False))
+    y = rng.normal(size=(9, d))
+    chol_R = 0.3 * np.eye(d)
+    m = np_models.CVISitesSSM(ssm, np.arange(T) * dt, idx, y, np_models.MultivariateGaussianLik(chol_R))
+    m.update_data_sites(1.0)
+    Rinv = np.linalg.inv(chol_R @ chol_R.T)
+    np.testing.assert_allclose(m.d1, y @ Rinv, rtol=1e-12)
+    np.testing.assert_allclose(m.d2, np.broadcast_to(-0.5 * Rinv, m.d2.shape), rtol=1e-12)
+    # the log marginal likelihood from the sparse-site Kalman filter (d=1) / a dense Gaussian (any d)
+    prec_d, prec_s = ssm.precision()
+    from oracle import np_btd
+    K = np.linalg.inv(np_btd.to_dense(prec_d, prec_s))
+    sel = (idx[:, None] * d + np.arange(d)[None, :]).reshape(-1)
+    Kyy = K[np.ix_(sel, sel)] + np.kron(np.eye(len(idx)), chol_R @ chol_R.T)
+    yf = y.reshape(-1)
+    loglik = -0.5 * yf @ np.linalg.solve(Kyy, yf) - 0.5 * np.linalg.slogdet(Kyy)[1] - 0.5 * len(yf) * np.log(2 * np.pi)
+    np.testing.assert_allclose(m.classic_elbo(), loglik, rtol=1e-6, atol=1e-6)
+    if d == 1:
+        sites = np_kalman.GaussianSitesNat(m.d1, m.d2)
+        kf = np_kalman.KalmanFilterWithSparseSites(ssm, np.ones((T, 1, 1)), sites, T, idx, y)
+        np.testing.assert_allclose(kf.log_likelihood(), loglik, rtol=1e-8)
+    # a Girsanov update with lr=1 against the same linear prior drives the Girsanov sites to zero
+    m.update_girsanov_sites(1.0)
+    np.testing.assert_allclose(m.g1, 0.0, atol=1e-9)
+    np.testing.assert_allclose(m.g2d, 0.0, atol=1e-9)
+    np.testing.assert_allclose(m.classic_elbo(), loglik, rtol=1e-6, atol=1e-6)
+
+
+def test_elbo_increases_with_damped_updates(rng):
+    T, d = 40, 2
+    ssm = np_ssm.StateSpaceModel(*random_ssm_params(rng, (), T, d))
+    idx = np.arange(0, T, 5)
+    y = rng.normal(size=(len(idx), d))
+    m = np_models.CVISitesSSM(ssm, np.arange(T) * 0.1, idx, y, np_models.MultivariateGaussianLik(0.5 * np.eye(d)))
+    prev = -np.inf
+    for _ in range(4):
+        m.update_data_sites(0.5)
+        m.update_girsanov_sites(0.5)
+        e = m.classic_elbo()
+        assert e > prev - 1e-9
+        prev = e

@@ -11,6 +11,7 @@
 #include "mfgm_layout.h"
 #include "mfgm_pack.h"
 #include "mfgm_sweeps.h"
+#include "mfgm_local.h"
 
 using namespace mfgm;
 
@@ -276,6 +277,32 @@ int mfgm_unpack(const mfgm_plan* plan, int kind, const double* packed, double* n
     return repack(plan, kind, packed, natural, n_nodes, false, stream);
 }
 
+int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, const double* y, double c, const double* z,
+                 void* stream) {
+    if (!out || !x) return 1;
+    if (n == 0) return 0;
+    if (((uintptr_t)out | (uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15) return 1;   // 16-byte aligned flat arrays
+    const size_t n2 = n / 2 + 1;
+    int blocks = (int)std::min<size_t>((n2 + 255) / 256, 2048 * 4);
+    hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, out, a, x, b, y, c, z);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, const long long* node_ids, int n, double* values, int mode,
+                 void* stream) {
+    if (!plan || !packed || kind < 0 || kind > 3 || mode < 0 || mode > 2 || n < 0) return 1;
+    if (n == 0) return 0;
+    if (!node_ids || !values) return 1;
+    const Plan& P = plan->p;
+    const size_t total = (size_t)n * kind_enat(kind, P.d);
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.lv[0], P.T, P.d, kind, packed, node_ids,
+                       n, values, mode);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 #define MFGM_DISPATCH_D(d, CALL)             \
     switch (d) {                             \
         case 1: { constexpr int DD = 1; return CALL; } \
@@ -309,6 +336,58 @@ int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, 
     if (!ws && P.ws_doubles > 0) return 1;
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st)));
+}
+
+}  // extern "C"
+
+namespace {
+template <int D>
+int s2n_impl(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
+             double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    double* part = sumlogchol ? ws + P.off_part[0] : nullptr;
+    if (lin) hipLaunchKernelGGL((k_ssm_to_naturals<D, true>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, A, off, chol, cD, cS, lin, diag, sub, part);
+    else hipLaunchKernelGGL((k_ssm_to_naturals<D, false>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, A, off, chol, cD, cS, lin, diag, sub, part);
+    MFGM_CHECK_LAUNCH();
+    if (sumlogchol) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, sumlogchol, (double*)nullptr);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+template <int D>
+int kl_impl(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps, double aD,
+            double aS, const double* mup, double* trace, double* maha, double* ws, hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    double* part = ws + P.off_part[0];
+    hipLaunchKernelGGL((k_kl_terms<D>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, Sig, Sub, mu, Pd, Ps, aD, aS, mup, part);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, lv.Lpad, trace, maha);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int mfgm_packed_ssm_to_naturals(const mfgm_plan* plan, const double* A, const double* off, const double* chol, double cD,
+                                double cS, double* lin, double* diag, double* sub, double* sumlogchol, void* ws,
+                                void* stream) {
+    if (!plan || !chol || !diag || !sub || !ws) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !A) return 1;
+    if ((lin != nullptr) != (off != nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (s2n_impl<DD>(P, A, off, chol, cD, cS, lin, diag, sub, sumlogchol, (double*)ws, st)));
+}
+
+int mfgm_packed_kl_terms(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* mu, const double* Pd,
+                         const double* Ps, double aD, double aS, const double* mup, double* trace, double* maha, void* ws,
+                         void* stream) {
+    if (!plan || !Sig || !Sub || !mu || !Pd || !Ps || !mup || !trace || !maha || !ws) return 1;
+    const Plan& P = plan->p;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (kl_impl<DD>(P, Sig, Sub, mu, Pd, Ps, aD, aS, mup, trace, maha, (double*)ws, st)));
 }
 
 }  // extern "C"

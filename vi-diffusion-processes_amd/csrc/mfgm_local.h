@@ -1,0 +1,250 @@
+// Per-node ("local") kernels on the packed layout: everything on the path that is embarrassingly parallel in
+// time but needs the neighbouring node (t+1).  One lane walks its segment in order and carries the
+// neighbour in registers, so every tensor is still read exactly once, coalesced.
+#pragma once
+#include "mfgm_layout.h"
+#include "mfgm_math.h"
+#include "mfgm_sweeps.h"
+
+namespace mfgm {
+
+// node (lane, s+1) of the same chain: the next step of this segment, or step 0 of the next segment.
+// Caller guarantees the global node t+1 exists.
+template <int E>
+MFGM_DEV void ld_next(const double* __restrict__ base, int Lpad, int s, int len, int lane, double (&out)[E]) {
+    if (s + 1 < len) ld_node<E>(base, Lpad, s + 1, lane, out);
+    else ld_node<E>(base, Lpad, 0, lane + 1, out);
+}
+
+// ---- out = a*x + b*y + c*z on flat arrays (y, z optional) ------------------------------------------------
+__global__ __launch_bounds__(256) void k_lincomb(size_t n, double* __restrict__ out, double a, const double* __restrict__ x,
+                                                double b, const double* __restrict__ y, double c,
+                                                const double* __restrict__ z) {
+    const size_t n2 = n / 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 v = reinterpret_cast<const double2*>(x)[i];
+        v.x *= a; v.y *= a;
+        if (y) { double2 w = reinterpret_cast<const double2*>(y)[i]; v.x = __builtin_fma(b, w.x, v.x); v.y = __builtin_fma(b, w.y, v.y); }
+        if (z) { double2 w = reinterpret_cast<const double2*>(z)[i]; v.x = __builtin_fma(c, w.x, v.x); v.y = __builtin_fma(c, w.y, v.y); }
+        reinterpret_cast<double2*>(out)[i] = v;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double v = a * x[n - 1];
+        if (y) v += b * y[n - 1];
+        if (z) v += c * z[n - 1];
+        out[n - 1] = v;
+    }
+}
+
+// ---- gather / scatter of a sparse list of nodes (observation times) --------------------------------------
+// node_ids[i] = b*T + t.  values: natural [n, E_nat].  mode 0: packed -> values, 1: values -> packed (set),
+// 2: packed += values.  SYM scatters read the lower triangle of the natural block.
+__global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int kind, double* packed,
+                                                const long long* __restrict__ node_ids, int n, double* values, int mode) {
+    const int En = (kind == 0) ? d : d * d;
+    const size_t total = (size_t)n * En;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / En), ne = (int)(idx - (size_t)i * En);
+        const long long id = node_ids[i];
+        const int b = (int)(id / T), t = (int)(id - (long long)b * T);
+        const int p = t / lv.R, s = t - p * lv.R, lane = b * lv.P + p;
+        int Ep = En, e = ne;
+        bool skip = false, zero = false;
+        if (kind >= 2) {
+            Ep = d * (d + 1) / 2;
+            const int r = ne / d, c = ne - r * d;
+            if (mode == 0) {
+                if (kind == 3 && c > r) zero = true;
+                e = six(r, c);
+            } else {
+                if (c > r) skip = true;
+                e = tix(r, c > r ? r : c);
+            }
+        }
+        if (skip) continue;
+        double* pp = packed + ((size_t)s * Ep + e) * lv.Lpad + lane;
+        if (mode == 0) values[idx] = zero ? 0.0 : *pp;
+        else if (mode == 1) *pp = values[idx];
+        else *pp += values[idx];
+    }
+}
+
+// ---- SSM parameters -> natural parameters / precision blocks ---------------------------------------------
+// Per node t:  A (FULL, transition t -> t+1, unused at the last node), off (VEC: mu0 at node 0, b_{t-1} after),
+// chol (TRI: chol P0 at node 0, chol Q_{t-1} after).  Writes
+//     lin_t  = Qi_t off_t - A_t^T Qi_{t+1} off_{t+1}
+//     diag_t = cD * (Qi_t + A_t^T Qi_{t+1} A_t)        (cD = -1/2: naturals, cD = 1: precision)
+//     sub_t  = cS * Qi_{t+1} A_t                        (cS = +1: naturals,  cS = -1: precision)
+// restating ssm_to_naturals (ssm_gaussian_transformations.py:182-253) and _build_precision
+// (state_space_model.py:431-483) with the same operation order (L^{-1}A, then L^{-T}, then the Gram product).
+template <int D, bool WANT_LIN>
+__global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const double* __restrict__ Ag,
+                                                       const double* __restrict__ offg, const double* __restrict__ cholg,
+                                                       double cD, double cS, double* __restrict__ ling,
+                                                       double* __restrict__ diagg, double* __restrict__ subg,
+                                                       double* __restrict__ part_logdet) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const int P = lv.P, R = lv.R, Lp = lv.Lpad, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    // X = chol^{-1}; Qi = X^T X; z = Qi off
+    auto prep = [&](const double (&C)[ET], const double (&o)[D], double (&X)[ET], double (&z)[D]) {
+        double invd[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) invd[j] = rcp_nr(C[tix(j, j)]);
+        tri_inverse<D>(C, invd, X);
+        if (WANT_LIN) {
+#pragma unroll
+            for (int e = 0; e < D; ++e) z[e] = o[e];
+            trsv_lower<D>(C, invd, z);
+            trsv_lower_t<D>(C, invd, z);
+        }
+    };
+    double Xc[ET], zc[D];
+    LogAcc la;
+    la.init();
+    {
+        double C[ET], o[D];
+        ld_node<ET>(cholg, Lp, 0, lane, C);
+        if (WANT_LIN) ld_node<D>(offg, Lp, 0, lane, o);
+        prep(C, o, Xc, zc);
+#pragma unroll
+        for (int j = 0; j < D; ++j) la.mul(C[tix(j, j)]);
+        la.renorm();
+    }
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            const bool has_next = (p * R + s + 1 < n);
+            double Qi[ET], lin[D];
+            tri_t_tri<D>(Xc, Qi);
+#pragma unroll
+            for (int e = 0; e < D; ++e) lin[e] = WANT_LIN ? zc[e] : 0.0;
+            if (has_next) {
+                double C[ET], o[D], A[EF], Xn[ET], zn[D];
+                ld_next<ET>(cholg, Lp, s, len, lane, C);
+                if (WANT_LIN) ld_next<D>(offg, Lp, s, len, lane, o);
+                ld_node<EF>(Ag, Lp, s, lane, A);
+                prep(C, o, Xn, zn);
+                if (s + 1 < len) {   // the next node belongs to this lane: account its log-det here
+#pragma unroll
+                    for (int j = 0; j < D; ++j) la.mul(C[tix(j, j)]);
+                    la.renorm();
+                }
+                // M = Xn A  (lower-tri times full)
+                double M[EF];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= i; ++k) t = __builtin_fma(Xn[tix(i, k)], A[k * D + j], t);
+                        M[i * D + j] = t;
+                    }
+                // sub = Xn^T M
+                double Sb[EF];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = i; k < D; ++k) t = __builtin_fma(Xn[tix(k, i)], M[k * D + j], t);
+                        Sb[i * D + j] = t;
+                    }
+                syrk_t_acc<D>(M, Qi);   // Qi += M^T M = A^T Qi_{t+1} A
+                if (WANT_LIN) {
+                    double t[D];
+                    gemv_t<D>(A, zn, t);
+#pragma unroll
+                    for (int e = 0; e < D; ++e) lin[e] -= t[e];
+                }
+#pragma unroll
+                for (int e = 0; e < EF; ++e) Sb[e] *= cS;
+                st_node<EF>(subg, Lp, s, lane, Sb);
+#pragma unroll
+                for (int e = 0; e < ET; ++e) Xc[e] = Xn[e];
+#pragma unroll
+                for (int e = 0; e < D; ++e) zc[e] = zn[e];
+            } else {
+                st_node_zero<EF>(subg, Lp, s, lane);
+            }
+#pragma unroll
+            for (int e = 0; e < ET; ++e) Qi[e] *= cD;
+            st_node<ET>(diagg, Lp, s, lane, Qi);
+            if (WANT_LIN) st_node<D>(ling, Lp, s, lane, lin);
+        }
+    }
+    if (part_logdet) part_logdet[lane] = la.value();   // sum log diag(chol) over this lane's nodes
+}
+
+// ---- KL(q || p) local terms -------------------------------------------------------------------------------
+// q: marginal covariances Sig (SYM), Sub = Sigma_{t+1,t} (FULL), means mu (VEC);
+// p: precision blocks aD*Pd (SYM), aS*Ps (FULL, block (t+1,t)), means mup (VEC).
+// Per-lane partials:  part[lane]        = sum_t <P_tt, Sig_t> + 2 <P_{t+1,t}, Sub_t>      (trace term)
+//                     part[Lpad + lane] = sum_t dl_t^T P_tt dl_t + 2 dl_{t+1}^T P_{t+1,t} dl_t   (Mahalanobis term)
+// restating StateSpaceModel.kl_divergence (state_space_model.py:557-593).
+template <int D>
+__global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __restrict__ Sigg, const double* __restrict__ Subg,
+                                                const double* __restrict__ mug, const double* __restrict__ Pdg,
+                                                const double* __restrict__ Psg, double aD, double aS,
+                                                const double* __restrict__ mupg, double* __restrict__ part) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const int P = lv.P, R = lv.R, Lp = lv.Lpad, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    double tr = 0.0, mh = 0.0;
+    double dl[D];
+    {
+        double m[D], mp[D];
+        ld_node<D>(mug, Lp, 0, lane, m);
+        ld_node<D>(mupg, Lp, 0, lane, mp);
+#pragma unroll
+        for (int e = 0; e < D; ++e) dl[e] = mp[e] - m[e];
+    }
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            const bool has_next = (p * R + s + 1 < n);
+            double Sg[ET], Pd[ET];
+            ld_node<ET>(Sigg, Lp, s, lane, Sg);
+            ld_node<ET>(Pdg, Lp, s, lane, Pd);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const double w = (i == j) ? 1.0 : 2.0;
+                    tr = __builtin_fma(w * aD * Pd[tix(i, j)], Sg[tix(i, j)], tr);
+                    mh = __builtin_fma(w * aD * Pd[tix(i, j)] * dl[i], dl[j], mh);
+                }
+            if (has_next) {
+                double Sb[EF], Ps[EF], m[D], mp[D], dn[D];
+                ld_node<EF>(Subg, Lp, s, lane, Sb);
+                ld_node<EF>(Psg, Lp, s, lane, Ps);
+                ld_next<D>(mug, Lp, s, len, lane, m);
+                ld_next<D>(mupg, Lp, s, len, lane, mp);
+#pragma unroll
+                for (int e = 0; e < D; ++e) dn[e] = mp[e] - m[e];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        tr = __builtin_fma(2.0 * aS * Ps[i * D + j], Sb[i * D + j], tr);
+                        mh = __builtin_fma(2.0 * aS * Ps[i * D + j] * dn[i], dl[j], mh);
+                    }
+#pragma unroll
+                for (int e = 0; e < D; ++e) dl[e] = dn[e];
+            }
+        }
+    }
+    part[lane] = tr;
+    part[Lp + lane] = mh;
+}
+
+}  // namespace mfgm

@@ -1,0 +1,58 @@
+"""
+Host-side mirror of the Gaussian likelihoods on the path (markovflow/likelihoods/multivariate_gaussian.py:80-115;
+gpflow.likelihoods.Gaussian for the scalar CVI-GP case): variational expectations and their gradients in
+closed form (the reference differentiates them with a GradientTape, variational_cvi_sde.py:204-220).
+Observation counts are tiny next to the time grid (n_obs << T), so these run as small batched torch ops on
+the gathered observation nodes.
+"""
+import math
+
+import torch
+
+
+class MultivariateGaussian:
+    """p(y | f) = N(y; f, L L^T) (multivariate_gaussian.py:29-160)."""
+
+    def __init__(self, chol_covariance):
+        self.chol_covariance = chol_covariance
+        self.obs_dim = chol_covariance.shape[-1]
+
+    @property
+    def inv_covariance(self):
+        eye = torch.eye(self.obs_dim, dtype=self.chol_covariance.dtype, device=self.chol_covariance.device)
+        return torch.cholesky_solve(eye, self.chol_covariance)
+
+    def variational_expectations(self, f_means, f_covariances, observations):
+        """-1/2 tr(S^{-1} S_i) + log N(y_i; mu_i, S) (multivariate_gaussian.py:80-115); shape [..., n]."""
+        Sinv = self.inv_covariance
+        diff = observations - f_means
+        z = torch.linalg.solve_triangular(self.chol_covariance, diff[..., None], upper=False)[..., 0]
+        logdet = torch.log(torch.diagonal(self.chol_covariance)).sum()
+        logp = -0.5 * (z * z).sum(-1) - logdet - 0.5 * self.obs_dim * math.log(2 * math.pi)
+        return -0.5 * (Sinv * f_covariances).sum(dim=(-1, -2)) + logp
+
+    def ve_gradients_expectation(self, f_means, f_covariances, observations):
+        """
+        Gradient of sum_i VE_i with respect to the expectation parameters (mu, S + mu mu^T):
+        d/dmu = S^{-1}(y - mu), d/dS = -1/2 S^{-1}, then gradient_transformation_mean_var_to_expectation
+        (variational_cvi.py:448-462): g1 = d/dmu - 2 (d/dS) mu = S^{-1} y,  g2 = -1/2 S^{-1}.
+        """
+        Sinv = self.inv_covariance
+        g1 = (Sinv @ observations[..., None])[..., 0]
+        g2 = (-0.5 * Sinv).expand(f_covariances.shape).contiguous()
+        return g1, g2
+
+
+class Gaussian:
+    """Scalar Gaussian likelihood with variance `variance` (gpflow.likelihoods.Gaussian), obs_dim 1."""
+
+    def __init__(self, variance):
+        self.variance = float(variance)
+
+    def variational_expectations(self, f_means, f_vars, observations):
+        v = self.variance
+        return -0.5 * math.log(2 * math.pi) - 0.5 * math.log(v) - 0.5 * ((observations - f_means) ** 2 + f_vars) / v
+
+    def ve_gradients_expectation(self, f_means, f_vars, observations):
+        v = self.variance
+        return observations / v, torch.full_like(f_vars, -0.5 / v)

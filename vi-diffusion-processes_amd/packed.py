@@ -36,6 +36,7 @@ class Plan:
         nbytes = self.lib.mfgm_plan_workspace_bytes(self.h)
         self.ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=self.device)
         self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.epoch = 0   # bumped by every factorisation (the coarse-level factors in `ws` belong to the latest one)
 
     def __del__(self):
         try:
@@ -80,6 +81,7 @@ class Plan:
         y = None
         if r is not None:
             y = out.get("y") if out.get("y") is not None else self.empty(VEC)
+        self.epoch += 1
         logdet = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_logdet else None
         quad = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_quad else None
         _lib.check(self.lib.mfgm_packed_factor(self.h, _ptr(D), _ptr(S), _ptr(r), float(aD), float(aS), float(aR),
@@ -100,6 +102,63 @@ class Plan:
         _lib.check(self.lib.mfgm_packed_selinv(self.h, _ptr(L), _ptr(G), _ptr(y), _ptr(Sig), _ptr(Sub), _ptr(x),
                                                _ptr(self.ws), _stream()), "mfgm_packed_selinv")
         return dict(Sig=Sig, Sub=Sub, x=x)
+
+    # -- local kernels --------------------------------------------------------------------------
+    def lincomb(self, out, a, x, b=0.0, y=None, c=0.0, z=None):
+        """out = a*x + b*y + c*z on flat packed arrays (in place allowed)."""
+        n = x.numel()
+        assert out.numel() == n and (y is None or y.numel() == n) and (z is None or z.numel() == n)
+        _lib.check(self.lib.mfgm_lincomb(n, _ptr(out), float(a), _ptr(x), float(b), _ptr(y), float(c), _ptr(z), _stream()),
+                   "mfgm_lincomb")
+        return out
+
+    def gather_nodes(self, kind, packed, node_ids):
+        """node_ids: int64 device tensor of b*T + t.  Returns natural [n, d] or [n, d, d]."""
+        n = node_ids.numel()
+        shape = (n, self.d) if kind == VEC else (n, self.d, self.d)
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_node_io(self.h, kind, _ptr(packed), _ptr(node_ids), n, _ptr(out), 0, _stream()),
+                   "mfgm_node_io(gather)")
+        return out
+
+    def scatter_nodes(self, kind, packed, node_ids, values, accumulate=False):
+        values = values.contiguous()
+        n = node_ids.numel()
+        _lib.check(self.lib.mfgm_node_io(self.h, kind, _ptr(packed), _ptr(node_ids), n, _ptr(values),
+                                         2 if accumulate else 1, _stream()), "mfgm_node_io(scatter)")
+        return packed
+
+    def ssm_to_naturals(self, A, off, chol, precision=False, want_logdet=False, out=None):
+        """Packed SSM parameters -> naturals (or precision blocks).  Returns dict(lin, diag, sub, sumlogchol)."""
+        out = {} if out is None else out
+        lin = None
+        if off is not None:
+            lin = out.get("lin") if out.get("lin") is not None else self.empty(VEC)
+        diag = out.get("diag") if out.get("diag") is not None else self.empty(SYM)
+        sub = out.get("sub") if out.get("sub") is not None else self.empty(FULL)
+        slc = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_logdet else None
+        cD, cS = (1.0, -1.0) if precision else (-0.5, 1.0)
+        _lib.check(self.lib.mfgm_packed_ssm_to_naturals(self.h, _ptr(A), _ptr(off), _ptr(chol), cD, cS, _ptr(lin),
+                                                        _ptr(diag), _ptr(sub), _ptr(slc), _ptr(self.ws), _stream()),
+                   "mfgm_packed_ssm_to_naturals")
+        return dict(lin=lin, diag=diag, sub=sub, sumlogchol=slc)
+
+    def kl_terms(self, Sig, Sub, mu, Pd, Ps, mup, aD=1.0, aS=1.0):
+        """Trace and Mahalanobis terms of KL(q||p) per chain."""
+        tr = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        mh = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_packed_kl_terms(self.h, _ptr(Sig), _ptr(Sub), _ptr(mu), _ptr(Pd), _ptr(Ps), float(aD),
+                                                 float(aS), _ptr(mup), _ptr(tr), _ptr(mh), _ptr(self.ws), _stream()),
+                   "mfgm_packed_kl_terms")
+        return tr, mh
+
+    def node_ids(self, time_index):
+        """int64 device tensor b*T + t for every chain and every index in `time_index` ([n] or [B, n])."""
+        ti = torch.as_tensor(time_index, dtype=torch.int64, device=self.device)
+        if ti.dim() == 1:
+            ti = ti.unsqueeze(0).expand(self.B, -1)
+        base = torch.arange(self.B, dtype=torch.int64, device=self.device).unsqueeze(1) * self.T
+        return (base + ti).reshape(-1).contiguous()
 
     def check_info(self):
         """Raise ArithmeticError if a pivot block was not positive definite (synchronises)."""

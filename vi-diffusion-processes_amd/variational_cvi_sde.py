@@ -1,0 +1,208 @@
+"""
+Host-side mirror of markovflow/models/variational_cvi_sde.py: `CVISitesSSM` (site-based posterior over the
+state trajectory of a linear SSM prior) and `CVISitesSDE` (CVI-DP: non-linear SDE prior, linearised).
+
+Same method names as the reference (`full_sites`, `dist_q`, `update_data_sites`, `update_girsanov_sites`,
+`variational_expectation`, `KL_q_p`, `classic_elbo`, `set_linearized_prior`).  Differences, all additive:
+  * a leading batch of B independent trajectories is supported (the reference asserts batch_shape == []):
+    observations [B, n_obs, d]; every quantity is per trajectory and `classic_elbo()` returns the sum over B
+    (the reduction that becomes the RCCL all-reduce when trajectories are sharded over GPUs);
+  * all per-time-step state (prior naturals, Girsanov sites, posterior naturals, marginals) lives in the
+    packed device layout and is refreshed once per site update, not once per property access.
+"""
+import math
+
+import torch
+
+from ._lib import FULL, SYM, TRI, VEC
+from .packed import Plan
+from .state_space_model import StateSpaceModel
+
+
+def grid_indices(time_grid, obs_times):
+    """Indices of the observation times on the grid (variational_cvi_sde.py:108-110: exact equality)."""
+    tg = torch.as_tensor(time_grid, dtype=torch.float64).cpu()
+    ot = torch.as_tensor(obs_times, dtype=torch.float64).cpu()
+    idx = torch.searchsorted(tg, ot)
+    idx = idx.clamp(max=tg.numel() - 1)
+    if not torch.equal(tg[idx], ot):
+        raise ValueError("every observation time must be a point of the time grid")
+    return idx
+
+
+class PackedBTDNat:
+    """Natural parameters of a block-tri-diagonal Gaussian in packed form (BTDGaussian, gauss_markov.py:220-242)."""
+
+    def __init__(self, lin, diag, sub):
+        self.lin, self.diag, self.sub = lin, diag, sub
+
+
+class CVISitesSSM:
+    """variational_cvi_sde.py:49-366."""
+
+    def __init__(self, prior_ssm, time_grid, input_data, likelihood, prior_initial_state=None,
+                 initial_posterior_path=None, plan=None):
+        obs_times, observations = input_data
+        if observations.dim() == 2:
+            observations = observations[None]
+        self.likelihood = likelihood
+        self.time_grid = torch.as_tensor(time_grid, dtype=torch.float64)
+        self.dt = float(self.time_grid[1] - self.time_grid[0])
+        self._observations = observations.contiguous()
+        self.B, self.n_obs, self.state_dim = observations.shape
+        self.output_dim = self.state_dim
+        self.T = int(self.time_grid.numel())
+        self.device = observations.device
+        if plan is None:
+            plan = prior_ssm.plan if prior_ssm is not None else Plan(self.B, self.T, self.state_dim, device=self.device)
+        self.plan = plan
+        self.obs_sites_indices = grid_indices(self.time_grid, obs_times).to(self.device)
+        self.obs_node_ids = plan.node_ids(self.obs_sites_indices)
+        d, pl = self.state_dim, plan
+        # Girsanov sites: nat1 = 0, nat2 = -1e-10 * ones  (variational_cvi_sde.py:141-152)
+        self.girsanov_sites = PackedBTDNat(pl.zeros(VEC), pl.zeros(SYM).fill_(-1e-10), pl.zeros(FULL).fill_(-1e-10))
+        # data sites: nat1 = 0, nat2 = +1e-10 * I  (variational_cvi_sde.py:96-103)
+        n = self.B * self.n_obs
+        self.data_nat1 = torch.zeros((n, d), dtype=torch.float64, device=self.device)
+        self.data_nat2 = (1e-10 * torch.eye(d, dtype=torch.float64, device=self.device)).expand(n, d, d).contiguous()
+        self.prior_initial_state = prior_initial_state
+        # initial posterior path: zero mean, identity covariance (variational_cvi_sde.py:131-139)
+        if initial_posterior_path is None:
+            self.fx_mus_obs = torch.zeros((n, d), dtype=torch.float64, device=self.device)
+            self.fx_covs_obs = torch.eye(d, dtype=torch.float64, device=self.device).expand(n, d, d).contiguous()
+            self._path = None
+        else:
+            mu, cov = initial_posterior_path
+            self._path = (pl.pack(VEC, mu.reshape(self.B, self.T, d)), pl.pack(SYM, cov.reshape(self.B, self.T, d, d)))
+            self.fx_mus_obs = pl.gather_nodes(VEC, self._path[0], self.obs_node_ids)
+            self.fx_covs_obs = pl.gather_nodes(SYM, self._path[1], self.obs_node_ids)
+        self._theta_q = PackedBTDNat(pl.empty(VEC), pl.empty(SYM), pl.empty(FULL))
+        self._bufs = dict(f={}, s={})
+        self._q = None          # cached posterior refresh (factor + selected inverse) for the current sites
+        self.dist_p = None
+        if prior_ssm is not None:
+            self._set_prior(prior_ssm)
+
+    # -- prior ---------------------------------------------------------------------------------------
+    def _set_prior(self, ssm: StateSpaceModel):
+        """Cache the prior's natural parameters, marginal means and log-determinant (packed)."""
+        if ssm.plan is not self.plan:
+            ssm = StateSpaceModel(ssm.initial_mean, ssm.cholesky_initial_covariance, ssm.state_transitions,
+                                  ssm.state_offsets, ssm.cholesky_process_covariances, plan=self.plan)
+        self.dist_p = ssm
+        pk = ssm.packed
+        nat = self.plan.ssm_to_naturals(pk.A, pk.off, pk.chol, precision=False, want_logdet=True)
+        self._theta_p = PackedBTDNat(nat["lin"], nat["diag"], nat["sub"])
+        self._p_sumlogchol = nat["sumlogchol"]
+        # prior marginal means K theta_lin: one factor + solve of the prior itself
+        f = self.plan.factor(nat["diag"], nat["sub"], nat["lin"], aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
+        s = self.plan.selinv(f["L"], f["G"], f["y"], want_sub=False)
+        self._p_mu = s["x"]
+        self._q = None
+
+    # -- sites -> posterior --------------------------------------------------------------------------------
+    def full_sites(self):
+        """theta_q = theta_prior + girsanov sites + scattered data sites (variational_cvi_sde.py:161-174)."""
+        pl, tq, tp, g = self.plan, self._theta_q, self._theta_p, self.girsanov_sites
+        pl.lincomb(tq.lin, 1.0, tp.lin, 1.0, g.lin)
+        pl.lincomb(tq.diag, 1.0, tp.diag, 1.0, g.diag)
+        pl.lincomb(tq.sub, 1.0, tp.sub, 1.0, g.sub)
+        pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True)
+        pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True)
+        return tq
+
+    def _refresh(self):
+        """theta_q -> (L, log|L|, mu, Sigma_tt, Sigma_{t+1,t}) in one forward and one backward sweep."""
+        if self._q is None:
+            pl = self.plan
+            tq = self.full_sites()
+            f = pl.factor(tq.diag, tq.sub, tq.lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=self._bufs["f"])
+            s = pl.selinv(f["L"], f["G"], f["y"], want_sub=True, out=self._bufs["s"])
+            self._bufs["f"].update(L=f["L"], G=f["G"], y=f["y"])
+            self._bufs["s"].update(Sig=s["Sig"], Sub=s["Sub"], x=s["x"])
+            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=s["Sub"])
+        return self._q
+
+    @property
+    def dist_q_marginals_packed(self):
+        q = self._refresh()
+        return q["mu"], q["Sig"], q["Sub"]
+
+    @property
+    def dist_q(self) -> StateSpaceModel:
+        """The posterior as a StateSpaceModel (variational_cvi_sde.py:177-192), via naturals_to_ssm_params."""
+        from .ssm_gaussian_transformations import naturals_to_ssm_params_packed
+        tq = self.full_sites()
+        return naturals_to_ssm_params_packed(self.plan, tq.lin, tq.diag, tq.sub)
+
+    def _gather_obs(self):
+        q = self._refresh()
+        self.fx_mus_obs = self.plan.gather_nodes(VEC, q["mu"], self.obs_node_ids)
+        self.fx_covs_obs = self.plan.gather_nodes(SYM, q["Sig"], self.obs_node_ids)
+
+    @property
+    def fx_mus(self):
+        return self.plan.unpack(VEC, self._refresh()["mu"])
+
+    @property
+    def fx_covs(self):
+        return self.plan.unpack(SYM, self._refresh()["Sig"])
+
+    # -- updates -------------------------------------------------------------------------------------------
+    def _obs_flat(self):
+        return self._observations.reshape(self.B * self.n_obs, self.state_dim)
+
+    def update_data_sites(self, lr: float):
+        """theta_data <- (1-lr) theta_data + lr dVE/d(eta) at the current marginals (variational_cvi_sde.py:301-317)."""
+        g1, g2 = self.likelihood.ve_gradients_expectation(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
+        self.data_nat1 = (1 - lr) * self.data_nat1 + lr * g1
+        self.data_nat2 = (1 - lr) * self.data_nat2 + lr * g2
+        self._q = None
+        self._gather_obs()
+
+    def grad_kl_wrt_exp_param(self):
+        """
+        d KL[q || p] / d(eta) for a linear prior is theta_q - theta_p (natural-gradient identity; the reference's
+        SSM_KL_with_grads_wrt_exp_params, sde_utils.py:376-461, differentiates a quadrature of the same KL).
+        """
+        tq, tp = self.full_sites(), self._theta_p
+        pl = self.plan
+        return (pl.lincomb(pl.empty(VEC), 1.0, tq.lin, -1.0, tp.lin), pl.lincomb(pl.empty(SYM), 1.0, tq.diag, -1.0, tp.diag),
+                pl.lincomb(pl.empty(FULL), 1.0, tq.sub, -1.0, tp.sub))
+
+    def update_girsanov_sites(self, lr: float):
+        """g <- g + lr (scatter(data sites) - dKL/d eta) (variational_cvi_sde.py:279-299)."""
+        gl, gd, gs = self.grad_kl_wrt_exp_param()
+        pl, g = self.plan, self.girsanov_sites
+        pl.lincomb(g.lin, 1.0, g.lin, -lr, gl)
+        pl.lincomb(g.diag, 1.0, g.diag, -lr, gd)
+        pl.lincomb(g.sub, 1.0, g.sub, -lr, gs)
+        pl.scatter_nodes(VEC, g.lin, self.obs_node_ids, lr * self.data_nat1, accumulate=True)
+        pl.scatter_nodes(SYM, g.diag, self.obs_node_ids, lr * self.data_nat2, accumulate=True)
+        self._q = None
+        self._gather_obs()
+
+    # -- objective -----------------------------------------------------------------------------------------
+    def variational_expectation(self):
+        """sum_i E_q log p(y_i | x_i), per trajectory [B] (variational_cvi_sde.py:319-337)."""
+        self._refresh()
+        mu = self.plan.gather_nodes(VEC, self._q["mu"], self.obs_node_ids)
+        cov = self.plan.gather_nodes(SYM, self._q["Sig"], self.obs_node_ids)
+        ve = self.likelihood.variational_expectations(mu, cov, self._obs_flat())
+        return ve.reshape(self.B, self.n_obs).sum(-1)
+
+    def KL_q_p(self):
+        """KL[q || p] per trajectory [B]; exact Gauss-Markov KL against the linear prior (state_space_model.py:528-593)."""
+        q = self._refresh()
+        tp = self._theta_p
+        tr, mh = self.plan.kl_terms(q["Sig"], q["Sub"], q["mu"], tp.diag, tp.sub, self._p_mu, aD=-2.0, aS=-1.0)
+        dim = float(self.T * self.state_dim)
+        # log det P_p = -2 sumlogchol_p ; log det P_q = 2 log|L_q|
+        return 0.5 * (tr + mh - dim + 2.0 * self._p_sumlogchol + 2.0 * q["logdetL"])
+
+    def classic_elbo_per_trajectory(self):
+        return self.variational_expectation() - self.KL_q_p()
+
+    def classic_elbo(self):
+        """E_q[log p(Y|X)] - KL[q || p], summed over trajectories (variational_cvi_sde.py:339-352)."""
+        return self.classic_elbo_per_trajectory().sum()
