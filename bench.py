@@ -1,0 +1,212 @@
+"""
+bench.py -- ELBO steps/sec of the CVI site-update loop on the block-tri-diagonal Gauss-Markov path.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one iteration of the reference's inner training loop (docs/diffusion_processes/cvi_dp_trainer.py:72-75):
+    model.update_data_sites(lr); model.update_girsanov_sites(lr); model.classic_elbo()
+on B independent synthetic double-well trajectories per GPU (T states, state dim d; weak scaling: every rank owns
+its own B trajectories, the only collective is the RCCL all-reduce of the scalar ELBO sum).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : the dominant kernel (backward selected-inverse sweep) timed alone with HIP events on its stream
+  cpu_baseline : the plain-C port of the same step (oracle/csrc) on the host cores, bounded sample, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def synth_double_well(B, T, d, dt, obs_every, noise, seed):
+    """Euler-Maruyama double-well trajectories f(x) = 4x(1-x^2), q = I and noisy observations."""
+    rng = np.random.default_rng(seed)
+    x = np.where(rng.random((B, d)) < 0.5, -1.0, 1.0)
+    idx = np.arange(obs_every, T, obs_every)
+    ys = np.empty((B, len(idx), d))
+    sq = np.sqrt(dt)
+    k = 0
+    for t in range(1, T):
+        x = x + dt * 4.0 * x * (1.0 - x * x) + sq * rng.standard_normal((B, d))
+        if k < len(idx) and t == idx[k]:
+            ys[:, k] = x + noise * rng.standard_normal((B, d))
+            k += 1
+    return idx, ys
+
+
+def linearised_prior(B, T, d, dt, device):
+    """Euler SSM of the double-well linearised on the initial posterior path N(0, I):
+    A = 1 + dt*4*(1 - 3(m^2+S)) = 1 - 8 dt, b = 0, Q = dt I (sde_utils.py:119-179, drift.py:102-108), P0 = I."""
+    eye = torch.eye(d, dtype=torch.float64, device=device)
+    A = ((1.0 - 8.0 * dt) * eye).expand(B, T - 1, d, d).contiguous()
+    b = torch.zeros((B, T - 1, d), dtype=torch.float64, device=device)
+    cholQ = (np.sqrt(dt) * eye).expand(B, T - 1, d, d).contiguous()
+    return torch.zeros((B, d), dtype=torch.float64, device=device), eye.expand(B, d, d).contiguous(), A, b, cholQ
+
+
+def cpu_baseline(args, idx, ys, dt, noise):
+    """The plain-C port (oracle/csrc/btd_ref.c) of the same step on a bounded sample of trajectories."""
+    from oracle import c_ref
+    lib = c_ref.load()
+    threads = int(lib.ref_num_threads())
+    Bs = max(1, min(args.B, threads))
+    T, d = args.T, args.d
+    A = np.broadcast_to((1.0 - 8.0 * dt) * np.eye(d), (T - 1, d, d))
+    off = np.zeros((T, d))
+    chol = np.concatenate([np.eye(d)[None], np.broadcast_to(np.sqrt(dt) * np.eye(d), (T - 1, d, d))], axis=0)
+    lin, diag, sub = c_ref.ssm_to_naturals(A, off, chol)
+    rep = lambda a: np.broadcast_to(a, (Bs,) + a.shape).copy()
+    pslc = np.full(Bs, np.sum(np.log(np.einsum("tii->ti", chol))))
+    Rinv = np.eye(d) / noise ** 2
+    st = c_ref.CviStepState(rep(lin), rep(diag), rep(sub), np.zeros((Bs, T, d)), pslc, idx, ys[:Bs], Rinv,
+                            2 * d * np.log(noise))
+    st.step(args.lr, args.lr)  # warm-up (page-in)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        st.step(args.lr, args.lr)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 20:
+            break
+    per_step_sample = el / n
+    # throughput for the full per-GPU workload, linear in the number of trajectories
+    value = 1.0 / (per_step_sample * args.B / Bs)
+    return {"value": value, "unit": "ELBO steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of {Bs} of the {args.B} trajectories (T={T}, d={d}), OpenMP over trajectories; "
+                      f"{per_step_sample:.3f} s per sampled step, scaled linearly to {args.B} trajectories"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--B", type=int, default=64, help="trajectories per GPU")
+    ap.add_argument("--T", type=int, default=100000)
+    ap.add_argument("--d", type=int, default=6)
+    ap.add_argument("--lr", type=float, default=0.5)
+    ap.add_argument("--obs-every", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    import vidp_amd
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.state_space_model import StateSpaceModel
+    from vidp_amd.variational_cvi_sde import CVISitesSSM
+
+    B, T, d = args.B, args.T, args.d
+    dt, noise = 0.01, 0.1
+    idx, ys = synth_double_well(B, T, d, dt, args.obs_every, noise, seed=71892305 + 3 + rank)
+    plan = vidp_amd.Plan(B, T, d, device=device)
+    prior = StateSpaceModel(*linearised_prior(B, T, d, dt, device), plan=plan)
+    grid = np.arange(T) * dt
+    lik = MultivariateGaussian(noise * torch.eye(d, dtype=torch.float64, device=device))
+    model = CVISitesSSM(prior, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik, plan=plan)
+
+    elbos = []
+
+    def step():
+        model.update_data_sites(args.lr)
+        model.update_girsanov_sites(args.lr)
+        e = model.classic_elbo()
+        if dist is not None:
+            dist.all_reduce(e)
+        elbos.append(e)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    plan.check_info()
+    elbo_vals = [float(e.item()) for e in elbos]
+    assert all(np.isfinite(elbo_vals)), "non-finite ELBO"
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    out = {
+        "metric": "ELBO steps/sec (T=100k, d=6) at 1/2/4/8 GPU; HBM GB/s vs roofline",
+        "value": args.steps / elapsed, "unit": "ELBO steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"CVI site-update loop (update_data_sites + update_girsanov_sites + classic_elbo) on "
+                               f"double-well trajectories with the linearised prior, T={T}, d={d}, {B} trajectories per GPU, "
+                               f"observation every {args.obs_every} steps",
+                   "trajectories_per_gpu": B, "T": T, "d": d, "total_trajectories": B * world,
+                   "partition": {"levels": plan.nlevels, "segment_len": plan.R, "lanes": plan.Lpad}},
+        "elbo_last": elbo_vals[-1],
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: level-0 backward (selected inverse) sweep, timed alone ----------
+        lib = vidp_amd._lib.load()
+        from vidp_amd.packed import _ptr, _stream
+        f, s = model._bufs["f"], model._bufs["s"]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 20
+
+        def one():
+            rc = lib.mfgm_packed_selinv_level(plan.h, 0, _ptr(f["L"]), _ptr(f["G"]), _ptr(f["y"]), _ptr(s["Sig"]), _ptr(s["Sub"]),
+                                              _ptr(s["x"]), _ptr(plan.ws), _stream())
+            assert rc == 0
+        one()
+        torch.cuda.synchronize()
+        ev[0].record()   # torch's current stream is the stream the kernel is launched on (_stream())
+        for _ in range(reps):
+            one()
+        ev[1].record()
+        torch.cuda.synchronize()
+        k_ms = ev[0].elapsed_time(ev[1]) / reps
+        ET = d * (d + 1) // 2
+        bytes_per_node = 8 * 2 * (ET + d * d + d)        # read L, L_sub, y; write Sigma, Sigma_sub, mu (packed)
+        alg_bytes = bytes_per_node * B * T
+        ach = alg_bytes / (k_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": f"k_backward<{d},true,true,true> (level 0)", "achieved": ach,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise)
+            except OSError as e:  # library not built
+                out["cpu_baseline"] = {"value": None, "unit": "ELBO steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@
  *   - "natural" layout = the reference's row-major [B, T, d, d] / [B, T-1, d, d] / [B, T, d] tensors;
  *     "packed" layout = the segment-interleaved layout the sweeps run on (csrc/mfgm_layout.h):
  *     element (chain b, node t = p*R + s, e) of a per-node quantity with E doubles is at
- *     ((s*E + e)*Lpad + b*P + p).  Symmetric and lower-triangular blocks are stored as packed lower
+ *     (((lane/64)*R + s)*E + e)*64 + lane%64 with lane = b*P + p.  Symmetric and lower-triangular blocks are stored as packed lower
  *     triangles (E = d(d+1)/2) in the packed layout.
  */
 #ifndef MFGM_H
@@ -103,6 +103,15 @@ int mfgm_packed_ssm_to_naturals(const mfgm_plan* plan, const double* A, const do
 int mfgm_packed_kl_terms(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* mu, const double* Pd,
                          const double* Ps, double aD, double aS, const double* mup, double* trace, double* maha, void* ws,
                          void* stream);
+
+/* Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 =
+ * finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call with the
+ * same arguments; outputs are overwritten with identical values.  Used by bench.py to time the dominant kernel alone. */
+int mfgm_packed_factor_stage(const mfgm_plan* plan, int stage, int level, const double* D, const double* S, const double* r,
+                             double aD, double aS, double aR, double* L, double* G, double* y, void* ws, int* info,
+                             void* stream);
+int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, const double* G, const double* y, double* Sig,
+                             double* Sub, double* x, void* ws, void* stream);
 
 const char* mfgm_version(void);
 

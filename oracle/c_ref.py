@@ -1,0 +1,109 @@
+"""
+ctypes binding of oracle/csrc/libbtdref.so, the plain-C CPU port used as `cpu_baseline` (kind "port") and as
+an independent cross-check of the NumPy oracle.  Test infrastructure only (see oracle/__init__.py).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "csrc", "libbtdref.so")
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(LIB)
+        lib.ref_btd_cholesky.restype = ctypes.c_int
+        lib.ref_btd_cholesky.argtypes = [_dp, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int]
+        lib.ref_btd_solve.restype = None
+        lib.ref_btd_solve.argtypes = [_dp, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.ref_btd_logdet.restype = ctypes.c_double
+        lib.ref_btd_logdet.argtypes = [_dp, ctypes.c_int, ctypes.c_int]
+        lib.ref_btd_inverse_blocks.restype = None
+        lib.ref_btd_inverse_blocks.argtypes = [_dp, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int]
+        lib.ref_ssm_to_naturals.restype = None
+        lib.ref_ssm_to_naturals.argtypes = [_dp] * 6 + [ctypes.c_int, ctypes.c_int]
+        lib.ref_cvi_step_work_doubles.restype = ctypes.c_size_t
+        lib.ref_cvi_step_work_doubles.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.ref_cvi_step.restype = ctypes.c_double
+        lib.ref_cvi_step.argtypes = ([ctypes.c_int] * 4 + [_ip, _dp, _dp, ctypes.c_double] + [_dp] * 10
+                                     + [ctypes.c_double, ctypes.c_double, _dp, _dp])
+        lib.ref_num_threads.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def btd_cholesky(diag, sub):
+    lib = load()
+    diag, sub = c64(diag), c64(sub)
+    T, d = diag.shape[0], diag.shape[-1]
+    Ld, Ls = np.zeros_like(diag), np.zeros_like(sub)
+    bad = lib.ref_btd_cholesky(_p(diag), _p(sub), _p(Ld), _p(Ls), T, d)
+    if bad:
+        raise np.linalg.LinAlgError("not positive definite")
+    return Ld, Ls
+
+
+def btd_solve(Ld, Ls, rhs, transpose=False):
+    lib = load()
+    Ld, Ls, rhs = c64(Ld), c64(Ls), c64(rhs)
+    out = np.zeros_like(rhs)
+    lib.ref_btd_solve(_p(Ld), _p(Ls), _p(rhs), _p(out), Ld.shape[0], Ld.shape[-1], int(transpose))
+    return out
+
+
+def btd_inverse_blocks(Ld, Ls):
+    lib = load()
+    Ld, Ls = c64(Ld), c64(Ls)
+    Sd, Ss = np.zeros_like(Ld), np.zeros_like(Ls)
+    lib.ref_btd_inverse_blocks(_p(Ld), _p(Ls), _p(Sd), _p(Ss), Ld.shape[0], Ld.shape[-1])
+    return Sd, Ss
+
+
+def ssm_to_naturals(A, off, chol):
+    lib = load()
+    A, off, chol = c64(A), c64(off), c64(chol)
+    T, d = off.shape
+    lin, diag, sub = np.zeros((T, d)), np.zeros((T, d, d)), np.zeros((T - 1, d, d))
+    lib.ref_ssm_to_naturals(_p(A), _p(off), _p(chol), _p(lin), _p(diag), _p(sub), T, d)
+    return lin, diag, sub
+
+
+class CviStepState:
+    """Host arrays for ref_cvi_step (B chains)."""
+
+    def __init__(self, p1, pd, ps, pmu, pslc, idx, y, Rinv, logdetR):
+        self.p1, self.pd, self.ps, self.pmu, self.pslc = c64(p1), c64(pd), c64(ps), c64(pmu), c64(pslc)
+        self.B, self.T, self.d = self.p1.shape
+        self.idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.y, self.Rinv, self.logdetR = c64(y), c64(Rinv), float(logdetR)
+        self.n = self.idx.shape[0]
+        B, T, d, n = self.B, self.T, self.d, self.n
+        self.g1 = np.zeros((B, T, d))
+        self.g2d = -1e-10 * np.ones((B, T, d, d))
+        self.g2s = -1e-10 * np.ones((B, T - 1, d, d))
+        self.d1 = np.zeros((B, n, d))
+        self.d2 = 1e-10 * np.broadcast_to(np.eye(d), (B, n, d, d)).copy()
+        lib = load()
+        self.work = np.zeros(B * lib.ref_cvi_step_work_doubles(T, d))
+        self.elbo = np.zeros(B)
+
+    def step(self, lr_d, lr_g):
+        lib = load()
+        return lib.ref_cvi_step(self.B, self.T, self.d, self.n, self.idx.ctypes.data_as(_ip), _p(self.y), _p(self.Rinv),
+                                self.logdetR, _p(self.p1), _p(self.pd), _p(self.ps), _p(self.pmu), _p(self.pslc),
+                                _p(self.g1), _p(self.g2d), _p(self.g2s), _p(self.d1), _p(self.d2), lr_d, lr_g,
+                                _p(self.work), _p(self.elbo))

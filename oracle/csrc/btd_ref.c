@@ -1,0 +1,325 @@
+/*
+ * CPU restatement ("port") of the reference's block-tri-diagonal Gauss-Markov path in plain C.
+ *
+ * TEST INFRASTRUCTURE / CPU BASELINE ONLY (see oracle/__init__.py): used by tests/ to cross-check the NumPy
+ * oracle and by bench.py's `cpu_baseline` leg.  Never linked into or called from the product library.
+ *
+ * Natural row-major layout, one chain at a time: diag [T,d,d], sub [T-1,d,d], vec [T,d].
+ * Algorithms follow the reference's sequential banded route:
+ *   ref_btd_cholesky        SymmetricBlockTriDiagonal.cholesky   (markovflow/block_tri_diag.py:428-440 -> cholesky_band)
+ *   ref_btd_solve           LowerTriangularBlockTriDiagonal.solve (block_tri_diag.py:339-351 -> solve_triang_mat)
+ *   ref_btd_inverse_blocks  inverse_from_cholesky_band            (block_tri_diag.py:318-337; ssm_gaussian_transformations.py:443-458)
+ *   ref_ssm_to_naturals     ssm_to_naturals                       (ssm_gaussian_transformations.py:182-253)
+ *   ref_kl_terms            StateSpaceModel.kl_divergence         (state_space_model.py:557-593)
+ *   ref_cvi_step            one CVISitesSSM iteration: update_data_sites, update_girsanov_sites, classic_elbo
+ *                           (variational_cvi_sde.py:161-192, 279-352; docs/diffusion_processes/cvi_dp_trainer.py:72-75)
+ * banded-matrices (the native dependency that holds these loops in the reference) is not vendored in
+ * /root/reference; its published algorithms are restated here in block form.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define IDX(i, j, d) ((i) * (d) + (j))
+
+/* in-place lower Cholesky of a d x d SPD matrix (lower triangle read); returns 1 if not PD */
+static int chol_d(double* a, int d) {
+    for (int j = 0; j < d; ++j) {
+        double s = a[IDX(j, j, d)];
+        for (int k = 0; k < j; ++k) s -= a[IDX(j, k, d)] * a[IDX(j, k, d)];
+        if (!(s > 0.0)) return 1;
+        double l = sqrt(s);
+        a[IDX(j, j, d)] = l;
+        for (int i = j + 1; i < d; ++i) {
+            double t = a[IDX(i, j, d)];
+            for (int k = 0; k < j; ++k) t -= a[IDX(i, k, d)] * a[IDX(j, k, d)];
+            a[IDX(i, j, d)] = t / l;
+        }
+        for (int i = 0; i < j; ++i) a[IDX(i, j, d)] = 0.0;
+    }
+    return 0;
+}
+/* x := L^{-1} x (n right-hand sides stored as columns of the d x n row-major matrix x) */
+static void trsm_l(const double* L, double* x, int d, int n) {
+    for (int c = 0; c < n; ++c)
+        for (int i = 0; i < d; ++i) {
+            double t = x[i * n + c];
+            for (int k = 0; k < i; ++k) t -= L[IDX(i, k, d)] * x[k * n + c];
+            x[i * n + c] = t / L[IDX(i, i, d)];
+        }
+}
+/* x := L^{-T} x */
+static void trsm_lt(const double* L, double* x, int d, int n) {
+    for (int c = 0; c < n; ++c)
+        for (int i = d - 1; i >= 0; --i) {
+            double t = x[i * n + c];
+            for (int k = i + 1; k < d; ++k) t -= L[IDX(k, i, d)] * x[k * n + c];
+            x[i * n + c] = t / L[IDX(i, i, d)];
+        }
+}
+/* C (+)= op(A) op(B): plain triple loops; ta/tb transpose flags; beta in {0,1}; alpha scalar */
+static void gemm_d(double alpha, const double* A, int ta, const double* B, int tb, double beta, double* C, int d) {
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double t = 0.0;
+            for (int k = 0; k < d; ++k) t += (ta ? A[IDX(k, i, d)] : A[IDX(i, k, d)]) * (tb ? B[IDX(j, k, d)] : B[IDX(k, j, d)]);
+            C[IDX(i, j, d)] = alpha * t + (beta != 0.0 ? C[IDX(i, j, d)] : 0.0);
+        }
+}
+
+int ref_btd_cholesky(const double* diag, const double* sub, double* Ld, double* Ls, int T, int d) {
+    const int dd = d * d;
+    double* carry = (double*)calloc(dd, sizeof(double));
+    double* tmp = (double*)malloc(dd * sizeof(double));
+    int bad = 0;
+    for (int k = 0; k < T && !bad; ++k) {
+        double* L = Ld + (size_t)k * dd;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j <= i; ++j) L[IDX(i, j, d)] = diag[(size_t)k * dd + IDX(i, j, d)] - carry[IDX(i, j, d)];
+        bad = chol_d(L, d);
+        if (k < T - 1) {
+            /* L_{k+1,k} = S_k L^{-T}: solve L X^T = S^T */
+            const double* S = sub + (size_t)k * dd;
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) tmp[IDX(i, j, d)] = S[IDX(j, i, d)];
+            trsm_l(L, tmp, d, d);
+            double* G = Ls + (size_t)k * dd;
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) G[IDX(i, j, d)] = tmp[IDX(j, i, d)];
+            gemm_d(1.0, G, 0, G, 1, 0.0, carry, d);
+        }
+    }
+    free(carry);
+    free(tmp);
+    return bad;
+}
+
+void ref_btd_solve(const double* Ld, const double* Ls, const double* rhs, double* out, int T, int d, int transpose) {
+    const int dd = d * d;
+    if (!transpose) {
+        for (int k = 0; k < T; ++k) {
+            double* y = out + (size_t)k * d;
+            for (int i = 0; i < d; ++i) {
+                double t = rhs[(size_t)k * d + i];
+                if (k > 0)
+                    for (int j = 0; j < d; ++j) t -= Ls[(size_t)(k - 1) * dd + IDX(i, j, d)] * out[(size_t)(k - 1) * d + j];
+                y[i] = t;
+            }
+            trsm_l(Ld + (size_t)k * dd, y, d, 1);
+        }
+    } else {
+        for (int k = T - 1; k >= 0; --k) {
+            double* y = out + (size_t)k * d;
+            for (int i = 0; i < d; ++i) {
+                double t = rhs[(size_t)k * d + i];
+                if (k < T - 1)
+                    for (int j = 0; j < d; ++j) t -= Ls[(size_t)k * dd + IDX(j, i, d)] * out[(size_t)(k + 1) * d + j];
+                y[i] = t;
+            }
+            trsm_lt(Ld + (size_t)k * dd, y, d, 1);
+        }
+    }
+}
+
+double ref_btd_logdet(const double* Ld, int T, int d) {
+    double s = 0.0;
+    for (int k = 0; k < T; ++k)
+        for (int i = 0; i < d; ++i) s += log(Ld[(size_t)k * d * d + IDX(i, i, d)]);
+    return s;
+}
+
+void ref_btd_inverse_blocks(const double* Ld, const double* Ls, double* Sd, double* Ss, int T, int d) {
+    const int dd = d * d;
+    double* Linv = (double*)malloc(dd * sizeof(double));
+    double* H = (double*)malloc(dd * sizeof(double));
+    for (int k = T - 1; k >= 0; --k) {
+        const double* L = Ld + (size_t)k * dd;
+        memset(Linv, 0, dd * sizeof(double));
+        for (int i = 0; i < d; ++i) Linv[IDX(i, i, d)] = 1.0;
+        trsm_l(L, Linv, d, d);
+        double* S = Sd + (size_t)k * dd;
+        gemm_d(1.0, Linv, 1, Linv, 0, 0.0, S, d);
+        if (k < T - 1) {
+            gemm_d(1.0, Ls + (size_t)k * dd, 0, Linv, 0, 0.0, H, d);            /* H = L_{k+1,k} L_kk^{-1} */
+            double* Sb = Ss + (size_t)k * dd;
+            gemm_d(-1.0, Sd + (size_t)(k + 1) * dd, 0, H, 0, 0.0, Sb, d);       /* S_{k+1,k} = -S_{k+1,k+1} H */
+            gemm_d(-1.0, Sb, 1, H, 0, 1.0, S, d);                               /* S_kk -= S_{k+1,k}^T H */
+        }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < i; ++j) {
+                double v = 0.5 * (S[IDX(i, j, d)] + S[IDX(j, i, d)]);
+                S[IDX(i, j, d)] = S[IDX(j, i, d)] = v;
+            }
+    }
+    free(Linv);
+    free(H);
+}
+
+/* A [T-1,d,d], off [T,d] (mu0 then b), chol [T,d,d] (chol P0 then chol Q) -> naturals */
+void ref_ssm_to_naturals(const double* A, const double* off, const double* chol, double* lin, double* diag, double* sub,
+                         int T, int d) {
+    const int dd = d * d;
+    double* X = (double*)malloc(dd * sizeof(double));
+    double* M = (double*)malloc(dd * sizeof(double));
+    double* z = (double*)malloc((size_t)T * d * sizeof(double));
+    for (int k = 0; k < T; ++k) {
+        const double* C = chol + (size_t)k * dd;
+        memset(X, 0, dd * sizeof(double));
+        for (int i = 0; i < d; ++i) X[IDX(i, i, d)] = 1.0;
+        trsm_l(C, X, d, d);
+        gemm_d(-0.5, X, 1, X, 0, 0.0, diag + (size_t)k * dd, d);   /* -1/2 Q^{-1} */
+        double* zk = z + (size_t)k * d;
+        memcpy(zk, off + (size_t)k * d, d * sizeof(double));
+        trsm_l(C, zk, d, 1);
+        trsm_lt(C, zk, d, 1);
+        memcpy(lin + (size_t)k * d, zk, d * sizeof(double));
+        if (k > 0) {
+            const double* Ak = A + (size_t)(k - 1) * dd;
+            gemm_d(1.0, X, 0, Ak, 0, 0.0, M, d);                                  /* chol^{-1} A */
+            gemm_d(1.0, X, 1, M, 0, 0.0, sub + (size_t)(k - 1) * dd, d);          /* Q^{-1} A */
+            gemm_d(-0.5, M, 1, M, 0, 1.0, diag + (size_t)(k - 1) * dd, d);        /* -1/2 A^T Q^{-1} A */
+            for (int i = 0; i < d; ++i) {
+                double t = 0.0;
+                for (int j = 0; j < d; ++j) t += Ak[IDX(j, i, d)] * zk[j];
+                lin[(size_t)(k - 1) * d + i] -= t;
+            }
+        }
+    }
+    free(X);
+    free(M);
+    free(z);
+}
+
+/* trace and Mahalanobis terms of KL(q||p): q blocks (Sig, Sub, mu), p precision (Pd, Ps) and means mup */
+void ref_kl_terms(const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps, const double* mup,
+                  int T, int d, double* trace, double* maha) {
+    const int dd = d * d;
+    double tr = 0.0, mh = 0.0;
+    for (int k = 0; k < T; ++k) {
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double pij = Pd[(size_t)k * dd + IDX(i, j, d)];
+                tr += pij * Sig[(size_t)k * dd + IDX(i, j, d)];
+                mh += pij * (mup[(size_t)k * d + i] - mu[(size_t)k * d + i]) * (mup[(size_t)k * d + j] - mu[(size_t)k * d + j]);
+            }
+        if (k < T - 1)
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) {
+                    double pij = Ps[(size_t)k * dd + IDX(i, j, d)];
+                    tr += 2.0 * pij * Sub[(size_t)k * dd + IDX(i, j, d)];
+                    mh += 2.0 * pij * (mup[(size_t)(k + 1) * d + i] - mu[(size_t)(k + 1) * d + i]) * (mup[(size_t)k * d + j] - mu[(size_t)k * d + j]);
+                }
+    }
+    *trace = tr;
+    *maha = mh;
+}
+
+/*
+ * One CVISitesSSM iteration for B chains (OpenMP over chains), Gaussian likelihood with precision Rinv [d,d]:
+ *   update_data_sites(lr_d); update_girsanov_sites(lr_g); classic_elbo()
+ * State (updated in place): girsanov sites g1 [B,T,d], g2d [B,T,d,d], g2s [B,T-1,d,d]; data sites d1 [B,n,d], d2 [B,n,d,d].
+ * Prior naturals p1, pd, ps, prior means pmu, prior sum-log-chol pslc[B]; observations y [B,n,d] at grid indices idx[n].
+ * Returns the sum over chains of the ELBO; elbo_out[B] per chain.  work: caller-provided scratch of
+ * ref_cvi_step_work_doubles(T,d) doubles PER CHAIN.
+ */
+size_t ref_cvi_step_work_doubles(int T, int d) { return (size_t)T * (7 * d * d + 4 * d) + 16 * d * d; }
+
+double ref_cvi_step(int B, int T, int d, int n, const int* idx, const double* y, const double* Rinv, double logdetR,
+                    const double* p1, const double* pd, const double* ps, const double* pmu, const double* pslc,
+                    double* g1, double* g2d, double* g2s, double* d1, double* d2, double lr_d, double lr_g,
+                    double* work, double* elbo_out) {
+    const int dd = d * d;
+    const size_t W = ref_cvi_step_work_doubles(T, d);
+    double total = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+    for (int b = 0; b < B; ++b) {
+        double* w = work + (size_t)b * W;
+        double* q1 = w; w += (size_t)T * d;
+        double* qd = w; w += (size_t)T * dd;
+        double* qs = w; w += (size_t)T * dd;
+        double* Ld = w; w += (size_t)T * dd;
+        double* Ls = w; w += (size_t)T * dd;
+        double* Sd = w; w += (size_t)T * dd;
+        double* Ss = w; w += (size_t)T * dd;
+        double* yv = w; w += (size_t)T * d;
+        double* mu = w; w += (size_t)T * d;
+        double* Pd = w; w += (size_t)T * dd;   /* precision = -2 qd, -qs (scratch) */
+        double* tmpv = w; w += (size_t)T * d;
+        const double* P1 = p1 + (size_t)b * T * d; const double* PD = pd + (size_t)b * T * dd; const double* PS = ps + (size_t)b * (T - 1) * dd;
+        double* G1 = g1 + (size_t)b * T * d; double* G2D = g2d + (size_t)b * T * dd; double* G2S = g2s + (size_t)b * (T - 1) * dd;
+        double* D1 = d1 + (size_t)b * n * d; double* D2 = d2 + (size_t)b * n * dd;
+        const double* Y = y + (size_t)b * n * d;
+        double logdetL = 0.0;
+        /* ---- update_data_sites: Gaussian likelihood => target (Rinv y, -1/2 Rinv), then refresh ---- */
+        for (int i = 0; i < n; ++i) {
+            for (int r = 0; r < d; ++r) {
+                double t = 0.0;
+                for (int c = 0; c < d; ++c) t += Rinv[IDX(r, c, d)] * Y[(size_t)i * d + c];
+                D1[(size_t)i * d + r] = (1 - lr_d) * D1[(size_t)i * d + r] + lr_d * t;
+                for (int c = 0; c < d; ++c)
+                    D2[(size_t)i * dd + IDX(r, c, d)] = (1 - lr_d) * D2[(size_t)i * dd + IDX(r, c, d)] - 0.5 * lr_d * Rinv[IDX(r, c, d)];
+            }
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            /* full_sites: theta_q = theta_p + g + scatter(data) */
+            for (size_t i = 0; i < (size_t)T * d; ++i) q1[i] = P1[i] + G1[i];
+            for (size_t i = 0; i < (size_t)T * dd; ++i) qd[i] = PD[i] + G2D[i];
+            for (size_t i = 0; i < (size_t)(T - 1) * dd; ++i) qs[i] = PS[i] + G2S[i];
+            for (int i = 0; i < n; ++i) {
+                for (int r = 0; r < d; ++r) q1[(size_t)idx[i] * d + r] += D1[(size_t)i * d + r];
+                for (int r = 0; r < dd; ++r) qd[(size_t)idx[i] * dd + r] += D2[(size_t)i * dd + r];
+            }
+            if (pass == 0) {
+                /* update_girsanov_sites: g += lr (scatter(data) - (theta_q - theta_p)), then refresh with the new sites */
+                for (size_t i = 0; i < (size_t)T * d; ++i) G1[i] -= lr_g * (q1[i] - P1[i]);
+                for (size_t i = 0; i < (size_t)T * dd; ++i) G2D[i] -= lr_g * (qd[i] - PD[i]);
+                for (size_t i = 0; i < (size_t)(T - 1) * dd; ++i) G2S[i] -= lr_g * (qs[i] - PS[i]);
+                for (int i = 0; i < n; ++i) {
+                    for (int r = 0; r < d; ++r) G1[(size_t)idx[i] * d + r] += lr_g * D1[(size_t)i * d + r];
+                    for (int r = 0; r < dd; ++r) G2D[(size_t)idx[i] * dd + r] += lr_g * D2[(size_t)i * dd + r];
+                }
+                /* the reference refreshes the marginals after the data-site update as well: do the sweep */
+            }
+            for (size_t i = 0; i < (size_t)T * dd; ++i) Pd[i] = -2.0 * qd[i];
+            for (size_t i = 0; i < (size_t)(T - 1) * dd; ++i) qs[i] = -qs[i];
+            ref_btd_cholesky(Pd, qs, Ld, Ls, T, d);
+            ref_btd_solve(Ld, Ls, q1, yv, T, d, 0);
+            ref_btd_solve(Ld, Ls, yv, mu, T, d, 1);
+            ref_btd_inverse_blocks(Ld, Ls, Sd, Ss, T, d);
+            logdetL = ref_btd_logdet(Ld, T, d);
+        }
+        /* classic_elbo at the final q: VE at the observations - KL(q || p) */
+        double ve = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double* m = mu + (size_t)idx[i] * d;
+            const double* S = Sd + (size_t)idx[i] * dd;
+            double quad = 0.0, trc = 0.0;
+            for (int r = 0; r < d; ++r)
+                for (int c = 0; c < d; ++c) {
+                    quad += (Y[(size_t)i * d + r] - m[r]) * Rinv[IDX(r, c, d)] * (Y[(size_t)i * d + c] - m[c]);
+                    trc += Rinv[IDX(r, c, d)] * S[IDX(r, c, d)];
+                }
+            ve += -0.5 * trc - 0.5 * quad - 0.5 * logdetR - 0.5 * d * log(2.0 * M_PI);
+        }
+        for (size_t i = 0; i < (size_t)T * dd; ++i) Pd[i] = -2.0 * PD[i];
+        for (size_t i = 0; i < (size_t)(T - 1) * dd; ++i) qs[i] = -PS[i];
+        double tr, mh;
+        ref_kl_terms(Sd, Ss, mu, Pd, qs, pmu + (size_t)b * T * d, T, d, &tr, &mh);
+        double kl = 0.5 * (tr + mh - (double)T * d + 2.0 * pslc[b] + 2.0 * logdetL);
+        (void)tmpv;
+        elbo_out[b] = ve - kl;
+        total += ve - kl;
+    }
+    return total;
+}
+
+int ref_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,60 @@
+"""The plain-C CPU port (oracle/csrc) against the NumPy oracle: it is the cpu_baseline, so it must be right."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_ref, np_btd, np_models, np_ssm, np_transforms
+from tests.helpers import random_dominant_btd, random_ssm_params
+
+pytestmark = pytest.mark.skipif(not os.path.exists(c_ref.LIB), reason="oracle/csrc/libbtdref.so not built (run __graft_entry__.build())")
+
+
+@pytest.mark.parametrize("T,d", [(1, 1), (7, 1), (12, 3), (30, 6)])
+def test_c_btd(rng, T, d):
+    diag, sub = random_dominant_btd(rng, (), T, d)
+    sub = np.zeros((0, d, d)) if sub is None else sub
+    Ld, Ls = c_ref.btd_cholesky(diag, sub)
+    oLd, oLs = np_btd.cholesky(diag, sub if T > 1 else None)
+    np.testing.assert_allclose(Ld, oLd, rtol=1e-10, atol=1e-12)
+    r = rng.normal(size=(T, d))
+    if T > 1:
+        np.testing.assert_allclose(Ls, oLs, rtol=1e-10, atol=1e-12)
+    for tr in (False, True):
+        np.testing.assert_allclose(c_ref.btd_solve(Ld, Ls, r, tr), np_btd.solve(oLd, oLs, r, tr), rtol=1e-9, atol=1e-11)
+    Sd, Ss = c_ref.btd_inverse_blocks(Ld, Ls)
+    oSd, oSs = np_btd.inverse_blocks(oLd, oLs)
+    np.testing.assert_allclose(Sd, oSd, rtol=1e-9, atol=1e-11)
+    if T > 1:
+        np.testing.assert_allclose(Ss, oSs, rtol=1e-9, atol=1e-11)
+
+
+def test_c_ssm_to_naturals(rng):
+    ssm = np_ssm.StateSpaceModel(*random_ssm_params(rng, (), 11, 3))
+    got = c_ref.ssm_to_naturals(ssm.A, ssm.concatenated_state_offsets, ssm.concatenated_cholesky_process_covariance)
+    for a, b in zip(got, np_transforms.ssm_to_naturals(ssm)):
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
+def test_c_cvi_step(rng):
+    B, T, d, n = 3, 40, 2, 6
+    prm = random_ssm_params(rng, (B,), T, d)
+    idx = np.sort(rng.choice(T, size=n, replace=False))
+    y = rng.normal(size=(B, n, d))
+    cholR = 0.4 * np.eye(d)
+    Rinv = np.linalg.inv(cholR @ cholR.T)
+    ssms = [np_ssm.StateSpaceModel(*[p[b] for p in prm]) for b in range(B)]
+    nats = [np_transforms.ssm_to_naturals(s) for s in ssms]
+    st = c_ref.CviStepState(np.stack([n_[0] for n_ in nats]), np.stack([n_[1] for n_ in nats]), np.stack([n_[2] for n_ in nats]),
+                            np.stack([s.marginal_means for s in ssms]), np.array([-0.5 * s.log_det_precision() for s in ssms]),
+                            idx, y, Rinv, 2 * np.sum(np.log(np.diag(cholR))))
+    models = [np_models.CVISitesSSM(ssms[b], np.arange(T) * 0.1, idx, y[b], np_models.MultivariateGaussianLik(cholR)) for b in range(B)]
+    for lr_d, lr_g in ((1.0, 1.0), (0.5, 0.3)):
+        total = st.step(lr_d, lr_g)
+        ref = []
+        for m in models:
+            m.update_data_sites(lr_d)
+            m.update_girsanov_sites(lr_g)
+            ref.append(m.classic_elbo())
+        np.testing.assert_allclose(st.elbo, ref, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(total, np.sum(ref), rtol=1e-8)

@@ -18,11 +18,10 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     ET = d * (d + 1) // 2
     # diagonally dominant SPD system directly in packed form
-    D = plan.zeros(vidp_amd.SYM).view(plan.R, ET, plan.Lpad)
+    D = plan.zeros(vidp_amd.SYM).view(plan.Lpad // 64, plan.R, ET, 64)
     D.copy_(0.1 * torch.randn(D.shape, generator=g, device="cuda", dtype=torch.float64))
-    i = 0
     for r in range(d):
-        D[:, r * (r + 1) // 2 + r, :] = 4.0 + torch.rand((plan.R, plan.Lpad), generator=g, device="cuda", dtype=torch.float64)
+        D[:, :, r * (r + 1) // 2 + r, :] = 4.0 + torch.rand((plan.Lpad // 64, plan.R, 64), generator=g, device="cuda", dtype=torch.float64)
     S = 0.3 * torch.randn(plan.R * d * d * plan.Lpad, generator=g, device="cuda", dtype=torch.float64)
     r = torch.randn(plan.R * d * plan.Lpad, generator=g, device="cuda", dtype=torch.float64)
     D = D.view(-1)

@@ -33,6 +33,9 @@ EXPORTS = {
     "mfgm_node_io": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "mfgm_packed_ssm_to_naturals": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),
+    "mfgm_packed_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+                                 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 6),
+    "mfgm_packed_selinv_level": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8),
     "mfgm_packed_kl_terms": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
 }
 

@@ -118,7 +118,7 @@ void bind_up(const Plan& P, int l, double* ws, SweepArgs& a) {
 template <int D>
 int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info,
-                hipStream_t st) {
+                hipStream_t st, int only_stage = -1, int only_level = -1) {
     const bool has_rhs = (rg != nullptr);
     const int K = P.nlevels - 1;  // top level index (single segment per chain)
     auto make = [&](int l) {
@@ -137,16 +137,18 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
         return a;
     };
     for (int l = 0; l < K; ++l) {
+        if (only_stage >= 0 && !(only_stage == 0 && only_level == l)) continue;
         SweepArgs a = make(l);
         int rc = launch_reduce<D>(a, has_rhs, l > 0, st);
         if (rc) return rc;
     }
     for (int l = K; l >= 0; --l) {
+        if (only_stage >= 0 && !(only_stage == 1 && only_level == l)) continue;
         SweepArgs a = make(l);
         int rc = launch_forward<D>(a, has_rhs, l > 0, l < K, st);
         if (rc) return rc;
     }
-    if (logdet || quad) {
+    if (only_stage < 0 && (logdet || quad)) {
         hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad,
                            logdet, quad);
         MFGM_CHECK_LAUNCH();
@@ -156,10 +158,11 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
 
 template <int D>
 int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub,
-                double* x, double* ws, hipStream_t st) {
+                double* x, double* ws, hipStream_t st, int only_level = -1) {
     const bool has_rhs = (yg != nullptr);
     const int K = P.nlevels - 1;
     for (int l = K; l >= 0; --l) {
+        if (only_level >= 0 && only_level != l) continue;
         SweepArgs a;
         memset(&a, 0, sizeof(a));
         a.lv = P.lv[l];
@@ -388,6 +391,34 @@ int mfgm_packed_kl_terms(const mfgm_plan* plan, const double* Sig, const double*
     const Plan& P = plan->p;
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (kl_impl<DD>(P, Sig, Sub, mu, Pd, Ps, aD, aS, mup, trace, maha, (double*)ws, st)));
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 is
+// the finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call
+// with the same arguments; outputs are overwritten with identical values.
+int mfgm_packed_factor_stage(const mfgm_plan* plan, int stage, int level, const double* D, const double* S, const double* r,
+                             double aD, double aS, double aR, double* L, double* G, double* y, void* ws, int* info,
+                             void* stream) {
+    if (!plan || !D || !L || !G || !info || stage < 0 || stage > 1) return 1;
+    const Plan& P = plan->p;
+    if (level < 0 || level >= P.nlevels || (stage == 0 && level >= P.nlevels - 1)) return 1;
+    if ((r != nullptr) != (y != nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (factor_impl<DD>(P, D, S, r, aD, aS, aR, L, G, y, nullptr, nullptr, (double*)ws, info, st, stage, level)));
+}
+
+int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, const double* G, const double* y, double* Sig,
+                             double* Sub, double* x, void* ws, void* stream) {
+    if (!plan || !L || !G || !Sig) return 1;
+    const Plan& P = plan->p;
+    if (level < 0 || level >= P.nlevels) return 1;
+    if ((y != nullptr) != (x != nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st, level)));
 }
 
 }  // extern "C"

@@ -4,11 +4,12 @@
 // a separator.  One GPU lane owns one (chain b, segment p): lane = b*P + p.  For a per-node quantity
 // with E doubles the element (lane, step s, e) lives at
 //
-//        ((s*E + e) * Lpad + lane)            Lpad = lanes rounded up to 64
+//        (((lane/64)*R + s)*E + e)*64 + lane%64          (lanes padded to a multiple of 64: Lpad)
 //
-// so that, for a fixed (s, e), the 64 lanes of a wavefront read 512 contiguous bytes: every load and
-// store of the sequential sweeps is fully coalesced along the segment axis while each lane still walks
-// its own piece of the time axis in order.  The separators of level l form the chain of level l+1
+// i.e. [wave tile][step][element][64 lanes]: for a fixed (s, e) the 64 lanes of a wavefront read 512
+// contiguous bytes, a whole step of a wavefront is one contiguous run of E*512 bytes, and a wavefront streams
+// its R steps from one contiguous region -- every load and store of the sequential sweeps is fully
+// coalesced while each lane still walks its own piece of the time axis in order.  The separators of level l form the chain of level l+1
 // (n_{l+1} = P_l), which is packed the same way, until a level has a single segment per chain.
 #pragma once
 #include <cstddef>

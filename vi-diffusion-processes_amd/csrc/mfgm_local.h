@@ -11,15 +11,15 @@ namespace mfgm {
 // node (lane, s+1) of the same chain: the next step of this segment, or step 0 of the next segment.
 // Caller guarantees the global node t+1 exists.
 template <int E>
-MFGM_DEV void ld_next(const double* __restrict__ base, int Lpad, int s, int len, int lane, double (&out)[E]) {
-    if (s + 1 < len) ld_node<E>(base, Lpad, s + 1, lane, out);
-    else ld_node<E>(base, Lpad, 0, lane + 1, out);
+MFGM_DEV void ld_next(const double* __restrict__ base, int R, int s, int len, int lane, LaneRef me, double (&out)[E]) {
+    if (s + 1 < len) ld_node<E>(base, R, s + 1, me, out);
+    else ld_node<E>(base, R, 0, LaneRef::of(lane + 1), out);
 }
 
 // ---- out = a*x + b*y + c*z on flat arrays (y, z optional) ------------------------------------------------
-__global__ __launch_bounds__(256) void k_lincomb(size_t n, double* __restrict__ out, double a, const double* __restrict__ x,
-                                                double b, const double* __restrict__ y, double c,
-                                                const double* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_lincomb(size_t n, double* out, double a, const double* x,
+                                                double b, const double* y, double c,
+                                                const double* z) {
     const size_t n2 = n / 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int
             }
         }
         if (skip) continue;
-        double* pp = packed + ((size_t)s * Ep + e) * lv.Lpad + lane;
+        double* pp = packed + (((size_t)(lane >> 6) * lv.R + s) * Ep + e) * 64 + (lane & 63);
         if (mode == 0) values[idx] = zero ? 0.0 : *pp;
         else if (mode == 1) *pp = values[idx];
         else *pp += values[idx];
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const doub
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = lv.P, R = lv.R, Lp = lv.Lpad, n = lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const doub
     la.init();
     {
         double C[ET], o[D];
-        ld_node<ET>(cholg, Lp, 0, lane, C);
-        if (WANT_LIN) ld_node<D>(offg, Lp, 0, lane, o);
+        ld_node<ET>(cholg, R, 0, me, C);
+        if (WANT_LIN) ld_node<D>(offg, R, 0, me, o);
         prep(C, o, Xc, zc);
 #pragma unroll
         for (int j = 0; j < D; ++j) la.mul(C[tix(j, j)]);
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const doub
             for (int e = 0; e < D; ++e) lin[e] = WANT_LIN ? zc[e] : 0.0;
             if (has_next) {
                 double C[ET], o[D], A[EF], Xn[ET], zn[D];
-                ld_next<ET>(cholg, Lp, s, len, lane, C);
-                if (WANT_LIN) ld_next<D>(offg, Lp, s, len, lane, o);
-                ld_node<EF>(Ag, Lp, s, lane, A);
+                ld_next<ET>(cholg, R, s, len, lane, me, C);
+                if (WANT_LIN) ld_next<D>(offg, R, s, len, lane, me, o);
+                ld_node<EF>(Ag, R, s, me, A);
                 prep(C, o, Xn, zn);
                 if (s + 1 < len) {   // the next node belongs to this lane: account its log-det here
 #pragma unroll
@@ -165,18 +166,18 @@ __global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const doub
                 }
 #pragma unroll
                 for (int e = 0; e < EF; ++e) Sb[e] *= cS;
-                st_node<EF>(subg, Lp, s, lane, Sb);
+                st_node<EF>(subg, R, s, me, Sb);
 #pragma unroll
                 for (int e = 0; e < ET; ++e) Xc[e] = Xn[e];
 #pragma unroll
                 for (int e = 0; e < D; ++e) zc[e] = zn[e];
             } else {
-                st_node_zero<EF>(subg, Lp, s, lane);
+                st_node_zero<EF>(subg, R, s, me);
             }
 #pragma unroll
             for (int e = 0; e < ET; ++e) Qi[e] *= cD;
-            st_node<ET>(diagg, Lp, s, lane, Qi);
-            if (WANT_LIN) st_node<D>(ling, Lp, s, lane, lin);
+            st_node<ET>(diagg, R, s, me, Qi);
+            if (WANT_LIN) st_node<D>(ling, R, s, me, lin);
         }
     }
     if (part_logdet) part_logdet[lane] = la.value();   // sum log diag(chol) over this lane's nodes
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __r
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = lv.P, R = lv.R, Lp = lv.Lpad, n = lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -204,8 +206,8 @@ __global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __r
     double dl[D];
     {
         double m[D], mp[D];
-        ld_node<D>(mug, Lp, 0, lane, m);
-        ld_node<D>(mupg, Lp, 0, lane, mp);
+        ld_node<D>(mug, R, 0, me, m);
+        ld_node<D>(mupg, R, 0, me, mp);
 #pragma unroll
         for (int e = 0; e < D; ++e) dl[e] = mp[e] - m[e];
     }
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __r
         if (s < len) {
             const bool has_next = (p * R + s + 1 < n);
             double Sg[ET], Pd[ET];
-            ld_node<ET>(Sigg, Lp, s, lane, Sg);
-            ld_node<ET>(Pdg, Lp, s, lane, Pd);
+            ld_node<ET>(Sigg, R, s, me, Sg);
+            ld_node<ET>(Pdg, R, s, me, Pd);
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -225,10 +227,10 @@ __global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __r
                 }
             if (has_next) {
                 double Sb[EF], Ps[EF], m[D], mp[D], dn[D];
-                ld_node<EF>(Subg, Lp, s, lane, Sb);
-                ld_node<EF>(Psg, Lp, s, lane, Ps);
-                ld_next<D>(mug, Lp, s, len, lane, m);
-                ld_next<D>(mupg, Lp, s, len, lane, mp);
+                ld_node<EF>(Subg, R, s, me, Sb);
+                ld_node<EF>(Psg, R, s, me, Ps);
+                ld_next<D>(mug, R, s, len, lane, me, m);
+                ld_next<D>(mupg, R, s, len, lane, me, mp);
 #pragma unroll
                 for (int e = 0; e < D; ++e) dn[e] = mp[e] - m[e];
 #pragma unroll

@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void k_repack(const double* __restrict__ src, 
                     while (tix(i, 0) > e) --i;
                     ne = i * d + (e - tix(i, 0));
                 }
-                dst[((size_t)(s0 + sl) * Ep + e) * Lpad + lane0 + li] = tile[li * stride + sl * En + ne];
+                dst[(((size_t)blockIdx.x * R + (s0 + sl)) * Ep + e) * 64 + li] = tile[li * stride + sl * En + ne];
             }
         }
     } else {
         for (int idx = tid; idx < CH * Ep * 64; idx += 256) {
             const int li = idx & 63, se = idx >> 6, sl = se / Ep, e = se - sl * Ep;
             double v = 0.0;
-            if (s0 + sl < R && lane0 + li < Lpad) v = src[((size_t)(s0 + sl) * Ep + e) * Lpad + lane0 + li];
+            if (s0 + sl < R && lane0 + li < Lpad) v = src[(((size_t)blockIdx.x * R + (s0 + sl)) * Ep + e) * 64 + li];
             tile[li * stride + sl * Ep + e] = v;
         }
         __syncthreads();

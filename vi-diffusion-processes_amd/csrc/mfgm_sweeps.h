@@ -14,23 +14,31 @@
 namespace mfgm {
 
 // ---- packed-layout element access --------------------------------------------------------------
+// Element (lane, step s, e) of an array with E doubles per node and R steps per segment lives at
+//   (((lane/64)*R + s)*E + e)*64 + lane%64
+// For the wave's own lanes the tile (= blockIdx.x) is uniform, so the node pointer is scalar arithmetic and every
+// element is reached with an immediate offset e*512 from it (no per-element vector address math).
+struct LaneRef {
+    int tile, l;
+    MFGM_DEV static LaneRef of(int lane) { return LaneRef{lane >> 6, lane & 63}; }
+};
 template <int E>
-MFGM_DEV void ld_node(const double* __restrict__ base, int Lpad, int s, int lane, double (&out)[E]) {
-    const double* p = base + (size_t)s * E * Lpad;
+MFGM_DEV void ld_node(const double* __restrict__ base, int R, int s, LaneRef w, double (&out)[E]) {
+    const double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
 #pragma unroll
-    for (int e = 0; e < E; ++e) out[e] = p[(size_t)e * Lpad + lane];
+    for (int e = 0; e < E; ++e) out[e] = p[e * 64 + w.l];
 }
 template <int E>
-MFGM_DEV void st_node(double* __restrict__ base, int Lpad, int s, int lane, const double (&v)[E]) {
-    double* p = base + (size_t)s * E * Lpad;
+MFGM_DEV void st_node(double* __restrict__ base, int R, int s, LaneRef w, const double (&v)[E]) {
+    double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
 #pragma unroll
-    for (int e = 0; e < E; ++e) p[(size_t)e * Lpad + lane] = v[e];
+    for (int e = 0; e < E; ++e) p[e * 64 + w.l] = v[e];
 }
 template <int E>
-MFGM_DEV void st_node_zero(double* __restrict__ base, int Lpad, int s, int lane) {
-    double* p = base + (size_t)s * E * Lpad;
+MFGM_DEV void st_node_zero(double* __restrict__ base, int R, int s, LaneRef w) {
+    double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
 #pragma unroll
-    for (int e = 0; e < E; ++e) p[(size_t)e * Lpad + lane] = 0.0;
+    for (int e = 0; e < E; ++e) p[e * 64 + w.l] = 0.0;
 }
 
 struct SweepArgs {
@@ -65,23 +73,24 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, a.lv.n - p * R);
     int bad = 0;
 
     double F[ET], W[EF], h[D], Racc[ET], rho[D];
-    ld_node<ET>(a.Dg, Lp, 0, lane, F);
+    ld_node<ET>(a.Dg, R, 0, me, F);
 #pragma unroll
     for (int e = 0; e < ET; ++e) F[e] *= a.aD;
     if (HAS_CORR) {
         double c[ET];
-        ld_node<ET>(a.Dcorr, Lp, 0, lane, c);
+        ld_node<ET>(a.Dcorr, R, 0, me, c);
 #pragma unroll
         for (int e = 0; e < ET; ++e) F[e] -= c[e];
     }
     if (p > 0) {
-        ld_node<EF>(a.Sg, Lp, R - 1, lane - 1, W);
+        ld_node<EF>(a.Sg, R, R - 1, LaneRef::of(lane - 1), W);
 #pragma unroll
         for (int e = 0; e < EF; ++e) W[e] *= a.aS;
     } else {
@@ -89,12 +98,12 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
         for (int e = 0; e < EF; ++e) W[e] = 0.0;
     }
     if (HAS_RHS) {
-        ld_node<D>(a.rg, Lp, 0, lane, h);
+        ld_node<D>(a.rg, R, 0, me, h);
 #pragma unroll
         for (int e = 0; e < D; ++e) h[e] *= a.aR;
         if (HAS_CORR) {
             double c[D];
-            ld_node<D>(a.rcorr, Lp, 0, lane, c);
+            ld_node<D>(a.rcorr, R, 0, me, c);
 #pragma unroll
             for (int e = 0; e < D; ++e) h[e] -= c[e];
         }
@@ -113,12 +122,12 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
     for (int s = 0; s < R - 1; ++s) {
         if (s < len - 1) {
             double G[EF], Dn[ET], rn[D], Dc[HAS_CORR ? ET : 1], rc[HAS_CORR ? D : 1];
-            ld_node<EF>(a.Sg, Lp, s, lane, G);
-            ld_node<ET>(a.Dg, Lp, s + 1, lane, Dn);
-            if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, Lp, s + 1, lane, reinterpret_cast<double(&)[ET]>(Dc));
+            ld_node<EF>(a.Sg, R, s, me, G);
+            ld_node<ET>(a.Dg, R, s + 1, me, Dn);
+            if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, R, s + 1, me, reinterpret_cast<double(&)[ET]>(Dc));
             if (HAS_RHS) {
-                ld_node<D>(a.rg, Lp, s + 1, lane, rn);
-                if constexpr (HAS_CORR) ld_node<D>(a.rcorr, Lp, s + 1, lane, reinterpret_cast<double(&)[D]>(rc));
+                ld_node<D>(a.rg, R, s + 1, me, rn);
+                if constexpr (HAS_CORR) ld_node<D>(a.rcorr, R, s + 1, me, reinterpret_cast<double(&)[D]>(rc));
             }
             // eliminate interior node s
             double invd[D];
@@ -161,22 +170,22 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
         }
     }
     // separator of this segment is node q = p of the coarser level
-    const int uP = a.up.P, uR = a.up.R, uLp = a.up.Lpad;
+    const int uP = a.up.P, uR = a.up.R;
     {
         const int q = p, ul = b * uP + q / uR, us = q % uR;
-        st_node<ET>(a.uDhat, uLp, us, ul, F);
-        st_node<D>(a.urhat, uLp, us, ul, h);
+        st_node<ET>(a.uDhat, uR, us, LaneRef::of(ul), F);
+        st_node<D>(a.urhat, uR, us, LaneRef::of(ul), h);
         if (p == P - 1) {
-            st_node_zero<ET>(a.uRsub, uLp, us, ul);
-            st_node_zero<D>(a.urho, uLp, us, ul);
-            st_node_zero<EF>(a.uS, uLp, us, ul);
+            st_node_zero<ET>(a.uRsub, uR, us, LaneRef::of(ul));
+            st_node_zero<D>(a.urho, uR, us, LaneRef::of(ul));
+            st_node_zero<EF>(a.uS, uR, us, LaneRef::of(ul));
         }
     }
     if (p > 0) {
         const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
-        st_node<EF>(a.uS, uLp, us, ul, W);      // couples separator p-1 -> p
-        st_node<ET>(a.uRsub, uLp, us, ul, Racc);
-        st_node<D>(a.urho, uLp, us, ul, rho);
+        st_node<EF>(a.uS, uR, us, LaneRef::of(ul), W);      // couples separator p-1 -> p
+        st_node<ET>(a.uRsub, uR, us, LaneRef::of(ul), Racc);
+        st_node<D>(a.urho, uR, us, LaneRef::of(ul), rho);
     }
     if (bad) atomicMax(a.info, 1);
 }
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -201,11 +211,11 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
     if (HAS_UP && p > 0) {
         // natural-order Cholesky state at the separator to the left:
         //   F_a = Ltil Ltil^T + R_p ,  h_a = Ltil ytil + rho_p
-        const int uP = a.up.P, uR = a.up.R, uLp = a.up.Lpad;
+        const int uP = a.up.P, uR = a.up.R;
         const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
         double Lt[ET], Fa[ET], ha[D], invd[D];
-        ld_node<ET>(a.uL, uLp, us, ul, Lt);
-        ld_node<ET>(a.uRsub, uLp, us, ul, Fa);
+        ld_node<ET>(a.uL, uR, us, LaneRef::of(ul), Lt);
+        ld_node<ET>(a.uRsub, uR, us, LaneRef::of(ul), Fa);
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -217,8 +227,8 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
             }
         if (HAS_RHS) {
             double yt[D];
-            ld_node<D>(a.uy, uLp, us, ul, yt);
-            ld_node<D>(a.urho, uLp, us, ul, ha);
+            ld_node<D>(a.uy, uR, us, LaneRef::of(ul), yt);
+            ld_node<D>(a.urho, uR, us, LaneRef::of(ul), ha);
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 double t = ha[i];
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
         chol_inplace<D>(Fa, invd, bad);
         trsv_lower<D>(Fa, invd, ha);
         double Ga[EF];
-        ld_node<EF>(a.Sg, Lp, R - 1, lane - 1, Ga);
+        ld_node<EF>(a.Sg, R, R - 1, LaneRef::of(lane - 1), Ga);
 #pragma unroll
         for (int e = 0; e < EF; ++e) Ga[e] *= a.aS;
         trsm_right_lower_t<D>(Fa, invd, Ga);
@@ -251,17 +261,17 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
     // scales / corrections are applied at the point of use so no wait is forced at the load.
     double Fn[ET], Gn[EF], rn[D], Fc[HAS_CORR ? ET : 1], rc[HAS_CORR ? D : 1];
     auto load_step = [&](int s) {
-        ld_node<ET>(a.Dg, Lp, s, lane, Fn);
-        if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, Lp, s, lane, reinterpret_cast<double(&)[ET]>(Fc));
+        ld_node<ET>(a.Dg, R, s, me, Fn);
+        if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, R, s, me, reinterpret_cast<double(&)[ET]>(Fc));
         if (p * R + s + 1 < n) {
-            ld_node<EF>(a.Sg, Lp, s, lane, Gn);
+            ld_node<EF>(a.Sg, R, s, me, Gn);
         } else {
 #pragma unroll
             for (int e = 0; e < EF; ++e) Gn[e] = 0.0;
         }
         if (HAS_RHS) {
-            ld_node<D>(a.rg, Lp, s, lane, rn);
-            if constexpr (HAS_CORR) ld_node<D>(a.rcorr, Lp, s, lane, reinterpret_cast<double(&)[D]>(rc));
+            ld_node<D>(a.rg, R, s, me, rn);
+            if constexpr (HAS_CORR) ld_node<D>(a.rcorr, R, s, me, reinterpret_cast<double(&)[D]>(rc));
         }
     };
     load_step(0);
@@ -280,9 +290,9 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
             chol_inplace<D>(F, invd, bad);
             if (HAS_RHS) trsv_lower<D>(F, invd, h);
             trsm_right_lower_t<D>(F, invd, G);
-            st_node<ET>(a.Lg, Lp, s, lane, F);
-            st_node<EF>(a.Gg, Lp, s, lane, G);
-            if (HAS_RHS) st_node<D>(a.yg, Lp, s, lane, h);
+            st_node<ET>(a.Lg, R, s, me, F);
+            st_node<EF>(a.Gg, R, s, me, G);
+            if (HAS_RHS) st_node<D>(a.yg, R, s, me, h);
             syrk_set<D>(G, C);
             if (HAS_RHS) gemv<D>(G, h, c);
 #pragma unroll
@@ -305,6 +315,7 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -312,19 +323,19 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 
     double Sn[ET], xn[D];
     if (HAS_UP) {
-        const int uP = a.up.P, uR = a.up.R, uLp = a.up.Lpad;
+        const int uP = a.up.P, uR = a.up.R;
         const int q = p, ul = b * uP + q / uR, us = q % uR;
-        ld_node<ET>(a.uSig, uLp, us, ul, Sn);
-        if (HAS_RHS) ld_node<D>(a.umu, uLp, us, ul, xn);
+        ld_node<ET>(a.uSig, uR, us, LaneRef::of(ul), Sn);
+        if (HAS_RHS) ld_node<D>(a.umu, uR, us, LaneRef::of(ul), xn);
     } else {
         double Lt[ET], invd[D], X[ET];
-        ld_node<ET>(a.Lg, Lp, se, lane, Lt);
+        ld_node<ET>(a.Lg, R, se, me, Lt);
 #pragma unroll
         for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
         tri_inverse<D>(Lt, invd, X);
         tri_t_tri<D>(X, Sn);
         if (HAS_RHS) {
-            ld_node<D>(a.yg, Lp, se, lane, xn);
+            ld_node<D>(a.yg, R, se, me, xn);
             trsv_lower_t<D>(Lt, invd, xn);
         }
     }
@@ -332,15 +343,15 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 #pragma unroll
         for (int e = 0; e < D; ++e) xn[e] = 0.0;
     }
-    st_node<ET>(a.Sigg, Lp, se, lane, Sn);
-    if (HAS_RHS) st_node<D>(a.mug, Lp, se, lane, xn);
-    if (WANT_SUB && (p * R + se == n - 1)) st_node_zero<EF>(a.Subg, Lp, se, lane);
+    st_node<ET>(a.Sigg, R, se, me, Sn);
+    if (HAS_RHS) st_node<D>(a.mug, R, se, me, xn);
+    if (WANT_SUB && (p * R + se == n - 1)) st_node_zero<EF>(a.Subg, R, se, me);
 
     double Ln[ET], Gn[EF], yn[D];
     if (len > 1) {
-        ld_node<ET>(a.Lg, Lp, se - 1, lane, Ln);
-        ld_node<EF>(a.Gg, Lp, se - 1, lane, Gn);
-        if (HAS_RHS) ld_node<D>(a.yg, Lp, se - 1, lane, yn);
+        ld_node<ET>(a.Lg, R, se - 1, me, Ln);
+        ld_node<EF>(a.Gg, R, se - 1, me, Gn);
+        if (HAS_RHS) ld_node<D>(a.yg, R, se - 1, me, yn);
     }
     for (int s = R - 2; s >= 0; --s) {
         if (s < len - 1) {
@@ -352,9 +363,9 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 #pragma unroll
             for (int e = 0; e < D; ++e) x[e] = HAS_RHS ? yn[e] : 0.0;
             if (s > 0) {
-                ld_node<ET>(a.Lg, Lp, s - 1, lane, Ln);
-                ld_node<EF>(a.Gg, Lp, s - 1, lane, Gn);
-                if (HAS_RHS) ld_node<D>(a.yg, Lp, s - 1, lane, yn);
+                ld_node<ET>(a.Lg, R, s - 1, me, Ln);
+                ld_node<EF>(a.Gg, R, s - 1, me, Gn);
+                if (HAS_RHS) ld_node<D>(a.yg, R, s - 1, me, yn);
             }
             double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET];
 #pragma unroll
@@ -372,12 +383,12 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 #pragma unroll
                 for (int e = 0; e < D; ++e) x[e] -= t[e];
                 trsv_lower_t<D>(Lt, invd, x);
-                st_node<D>(a.mug, Lp, s, lane, x);
+                st_node<D>(a.mug, R, s, me, x);
 #pragma unroll
                 for (int e = 0; e < D; ++e) xn[e] = x[e];
             }
-            st_node<ET>(a.Sigg, Lp, s, lane, Sig);
-            if (WANT_SUB) st_node<EF>(a.Subg, Lp, s, lane, Ssub);
+            st_node<ET>(a.Sigg, R, s, me, Sig);
+            if (WANT_SUB) st_node<EF>(a.Subg, R, s, me, Ssub);
 #pragma unroll
             for (int e = 0; e < ET; ++e) Sn[e] = Sig[e];
         }
@@ -385,8 +396,8 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     if (WANT_SUB && p > 0) {
         // S_{t0, t0-1} for the separator on the left, whose own blocks belong to lane-1
         double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF];
-        ld_node<ET>(a.Lg, Lp, R - 1, lane - 1, Lt);
-        ld_node<EF>(a.Gg, Lp, R - 1, lane - 1, G);
+        ld_node<ET>(a.Lg, R, R - 1, LaneRef::of(lane - 1), Lt);
+        ld_node<EF>(a.Gg, R, R - 1, LaneRef::of(lane - 1), G);
 #pragma unroll
         for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
         tri_inverse<D>(Lt, invd, X);
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
         gemm_sym_full<D>(Sn, H, Ssub);
 #pragma unroll
         for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
-        st_node<EF>(a.Subg, Lp, R - 1, lane - 1, Ssub);
+        st_node<EF>(a.Subg, R, R - 1, LaneRef::of(lane - 1), Ssub);
     }
 }
 

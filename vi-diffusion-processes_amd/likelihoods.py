@@ -16,19 +16,17 @@ class MultivariateGaussian:
     def __init__(self, chol_covariance):
         self.chol_covariance = chol_covariance
         self.obs_dim = chol_covariance.shape[-1]
-
-    @property
-    def inv_covariance(self):
-        eye = torch.eye(self.obs_dim, dtype=self.chol_covariance.dtype, device=self.chol_covariance.device)
-        return torch.cholesky_solve(eye, self.chol_covariance)
+        eye = torch.eye(self.obs_dim, dtype=chol_covariance.dtype, device=chol_covariance.device)
+        # one d x d inverse, reused by every call (no per-observation triangular solves)
+        self.inv_covariance = torch.cholesky_solve(eye, chol_covariance)
+        self.log_det_chol = torch.log(torch.diagonal(chol_covariance)).sum()
 
     def variational_expectations(self, f_means, f_covariances, observations):
         """-1/2 tr(S^{-1} S_i) + log N(y_i; mu_i, S) (multivariate_gaussian.py:80-115); shape [..., n]."""
         Sinv = self.inv_covariance
         diff = observations - f_means
-        z = torch.linalg.solve_triangular(self.chol_covariance, diff[..., None], upper=False)[..., 0]
-        logdet = torch.log(torch.diagonal(self.chol_covariance)).sum()
-        logp = -0.5 * (z * z).sum(-1) - logdet - 0.5 * self.obs_dim * math.log(2 * math.pi)
+        quad = ((diff @ Sinv) * diff).sum(-1)
+        logp = -0.5 * quad - self.log_det_chol - 0.5 * self.obs_dim * math.log(2 * math.pi)
         return -0.5 * (Sinv * f_covariances).sum(dim=(-1, -2)) + logp
 
     def ve_gradients_expectation(self, f_means, f_covariances, observations):

@@ -99,17 +99,27 @@ class CVISitesSSM:
         s = self.plan.selinv(f["L"], f["G"], f["y"], want_sub=False)
         self._p_mu = s["x"]
         self._q = None
+        self._theta_q_valid = False
 
     # -- sites -> posterior --------------------------------------------------------------------------------
-    def full_sites(self):
-        """theta_q = theta_prior + girsanov sites + scattered data sites (variational_cvi_sde.py:161-174)."""
+    def _rebuild_theta_q(self):
+        """theta_q = theta_prior + girsanov sites + scattered data sites (variational_cvi_sde.py:161-174), from scratch."""
         pl, tq, tp, g = self.plan, self._theta_q, self._theta_p, self.girsanov_sites
         pl.lincomb(tq.lin, 1.0, tp.lin, 1.0, g.lin)
         pl.lincomb(tq.diag, 1.0, tp.diag, 1.0, g.diag)
         pl.lincomb(tq.sub, 1.0, tp.sub, 1.0, g.sub)
         pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True)
         pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True)
-        return tq
+        self._theta_q_valid = True
+
+    def full_sites(self):
+        """
+        The posterior natural parameters theta_q (variational_cvi_sde.py:161-174).  They are kept resident and
+        updated incrementally by the site updates instead of being re-summed on every access.
+        """
+        if not getattr(self, "_theta_q_valid", False):
+            self._rebuild_theta_q()
+        return self._theta_q
 
     def _refresh(self):
         """theta_q -> (L, log|L|, mu, Sigma_tt, Sigma_{t+1,t}) in one forward and one backward sweep."""
@@ -155,8 +165,12 @@ class CVISitesSSM:
     def update_data_sites(self, lr: float):
         """theta_data <- (1-lr) theta_data + lr dVE/d(eta) at the current marginals (variational_cvi_sde.py:301-317)."""
         g1, g2 = self.likelihood.ve_gradients_expectation(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
-        self.data_nat1 = (1 - lr) * self.data_nat1 + lr * g1
-        self.data_nat2 = (1 - lr) * self.data_nat2 + lr * g2
+        new1 = (1 - lr) * self.data_nat1 + lr * g1
+        new2 = (1 - lr) * self.data_nat2 + lr * g2
+        tq = self.full_sites()
+        self.plan.scatter_nodes(VEC, tq.lin, self.obs_node_ids, new1 - self.data_nat1, accumulate=True)
+        self.plan.scatter_nodes(SYM, tq.diag, self.obs_node_ids, new2 - self.data_nat2, accumulate=True)
+        self.data_nat1, self.data_nat2 = new1, new2
         self._q = None
         self._gather_obs()
 
@@ -171,14 +185,18 @@ class CVISitesSSM:
                 pl.lincomb(pl.empty(FULL), 1.0, tq.sub, -1.0, tp.sub))
 
     def update_girsanov_sites(self, lr: float):
-        """g <- g + lr (scatter(data sites) - dKL/d eta) (variational_cvi_sde.py:279-299)."""
-        gl, gd, gs = self.grad_kl_wrt_exp_param()
-        pl, g = self.plan, self.girsanov_sites
-        pl.lincomb(g.lin, 1.0, g.lin, -lr, gl)
-        pl.lincomb(g.diag, 1.0, g.diag, -lr, gd)
-        pl.lincomb(g.sub, 1.0, g.sub, -lr, gs)
-        pl.scatter_nodes(VEC, g.lin, self.obs_node_ids, lr * self.data_nat1, accumulate=True)
-        pl.scatter_nodes(SYM, g.diag, self.obs_node_ids, lr * self.data_nat2, accumulate=True)
+        """
+        g <- g + lr (scatter(data sites) - dKL/d eta) (variational_cvi_sde.py:279-299), with dKL/d eta = theta_q - theta_p.
+        Sites and posterior naturals are updated together: theta_q <- theta_q + (g_new - g).
+        """
+        pl, g, tq, tp = self.plan, self.girsanov_sites, self.full_sites(), self._theta_p
+        for gg, qq, pp in ((g.lin, tq.lin, tp.lin), (g.diag, tq.diag, tp.diag), (g.sub, tq.sub, tp.sub)):
+            pl.lincomb(gg, 1.0, gg, -lr, qq, lr, pp)          # g += lr (theta_p - theta_q)
+            pl.lincomb(qq, 1.0 - lr, qq, lr, pp)               # theta_q += lr (theta_p - theta_q)
+        for kind, gg, qq, val in ((VEC, g.lin, tq.lin, self.data_nat1), (SYM, g.diag, tq.diag, self.data_nat2)):
+            v = lr * val
+            pl.scatter_nodes(kind, gg, self.obs_node_ids, v, accumulate=True)
+            pl.scatter_nodes(kind, qq, self.obs_node_ids, v, accumulate=True)
         self._q = None
         self._gather_obs()
 
