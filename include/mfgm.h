@@ -104,6 +104,39 @@ int mfgm_packed_kl_terms(const mfgm_plan* plan, const double* Sig, const double*
                          const double* Ps, double aD, double aS, const double* mup, double* trace, double* maha, void* ws,
                          void* stream);
 
+/* Parameters of an SDE prior whose Euler map is a per-dimension cubic u_i(x) = x + dt f_i(x) = alpha_i x - beta_i x^3
+ * (OrnsteinUhlenbeckSDE: alpha = 1 - dt*decay, beta = 0; DoubleWellSDE: alpha = 1 + dt*scale*c, beta = dt*scale;
+ * markovflow/sde/sde.py:134-224) with diagonal diffusion q.  Symmetric matrices are packed lower triangles. */
+typedef struct mfgm_sde_params {
+    double alpha[8], beta[8];
+    double W[8];          /* 1 / (dt q_ii) */
+    double P0inv[36];     /* inverse of the prior initial covariance */
+    double mu0[8];        /* prior initial mean */
+    double logdetQp;      /* sum_i log(dt q_ii) */
+    double logdetP0;
+    double lr;            /* Girsanov-site learning rate (mode 2) */
+    double clip_lo, clip_hi; /* clipping of the linearised A, b; lo >= hi disables (variational_cvi_sde.py:417-430) */
+    double sq_dtq[8];     /* sqrt(dt q_ii) */
+    double cholP0[36];    /* Cholesky of the prior initial covariance */
+} mfgm_sde_params;
+
+/* KL[q || p_SDE] of the Gaussian chain q (marginal blocks mu, Sig, Sub packed) from the Euler-discretised SDE prior,
+ * in closed form (replaces the quadrature + GradientTape of SSM_KL_along_Gaussian_path / SDE_SSM_KL_with_grads_wrt_exp_params,
+ * sde_utils.py:262-359, 473-547):
+ *   mode 0: kl[B] only;
+ *   mode 1: also d KL / d(eta_lin, eta_diag, eta_sub) written to (o1 VEC, od SYM, os FULL);
+ *   mode 2: fused update_girsanov_sites (variational_cvi_sde.py:279-299): (o1,od,os) are the Girsanov sites and
+ *           (q1,qd,qs) the posterior naturals; both get  -= lr * dKL/d eta  (the sparse data-site term is added by the caller).
+ * kl may be NULL in modes 1/2. */
+int mfgm_packed_sde_kl(const mfgm_plan* plan, int mode, const mfgm_sde_params* prm, const double* mu, const double* Sig,
+                       const double* Sub, double* kl, double* o1, double* od, double* os, double* q1, double* qd, double* qs,
+                       void* ws, int* info, void* stream);
+
+/* Linearise the SDE on the posterior path (set_linearized_prior, variational_cvi_sde.py:408-432; linearize_sde,
+ * sde_utils.py:119-179; LinearDrift.to_ssm, drift.py:66-117): packed SSM parameters A (FULL), off (VEC), chol (TRI). */
+int mfgm_packed_linearize_cubic(const mfgm_plan* plan, const mfgm_sde_params* prm, const double* mu, const double* Sig,
+                                double* A, double* off, double* chol, void* stream);
+
 /* Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 =
  * finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call with the
  * same arguments; outputs are overwritten with identical values.  Used by bench.py to time the dominant kernel alone. */

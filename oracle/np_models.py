@@ -94,3 +94,61 @@ class CVISitesSSM:
 
     def classic_elbo(self):
         return self.variational_expectation() - self.KL_q_p()
+
+
+class CVISitesSDE(CVISitesSSM):
+    """
+    CVI-DP, variational_cvi_sde.py:368-518, single trajectory.  KL_q_p follows the reference's quadrature route
+    (SSM_KL_along_Gaussian_path, H = 20); grad_kl_wrt_exp_param uses the closed form of oracle/np_sde.py, which
+    tests/test_oracle_sde.py pins against finite differences of that same quadrature (the reference uses a GradientTape).
+    PARITY UNPINNED: the reference has no test for this class; the only anchor is the conjugate
+    OU case KA11.
+    """
+
+    def __init__(self, prior_sde, time_grid, obs_index, observations, likelihood, init_mu, init_cov, stabilize_ssm=True,
+                 clip=(-1.0, 1.0)):
+        from . import np_sde
+        self._np_sde = np_sde
+        self.sde = prior_sde
+        self.init_mu, self.init_cov = np.asarray(init_mu, dtype=np.float64), np.asarray(init_cov, dtype=np.float64)
+        self.stabilize_ssm, self.clip = stabilize_ssm, clip
+        self.dt = float(time_grid[1] - time_grid[0])
+        super().__init__(None, time_grid, obs_index, observations, likelihood)
+        self.set_linearized_prior()
+
+    def set_linearized_prior(self):
+        lin = self._np_sde.linearize_sde(self.sde, self.time_grid, self.fx_mus[1:], self.fx_covs[1:], self.init_mu, self.init_cov)
+        self.dist_p_linearized = lin
+        if self.stabilize_ssm:
+            self.dist_p = StateSpaceModel(lin.mu0, lin.cholP0, np.clip(lin.A, *self.clip), np.clip(lin.b, *self.clip), lin.cholQ)
+        else:
+            self.dist_p = lin
+
+    def relinearize(self):
+        """dist_p_last = dist_p; set_linearized_prior(); tranform_girsanov_sites (cvi_dp_trainer.py:127-134, sde_utils.py:550-568)."""
+        old = np_transforms.ssm_to_naturals(self.dist_p)
+        self.set_linearized_prior()
+        new = np_transforms.ssm_to_naturals(self.dist_p)
+        self.g1 = self.g1 + old[0] - new[0]
+        self.g2d = self.g2d + old[1] - new[1]
+        self.g2s = self.g2s + old[2] - new[2]
+
+    def KL_q_p(self):
+        q = self.dist_q
+        mu, cov = q.marginals
+        Qq = q.cholQ @ np.swapaxes(q.cholQ, -1, -2)
+        N, D = q.b.shape
+        Qp = np.broadcast_to(self.dt * self.sde.q, (N, D, D))
+        f_q = lambda x: (q.A[None] @ x[..., None])[..., 0] + q.b[None]
+        f_p = lambda x: x + self.dt * self.sde.drift(x)
+        kl = self._np_sde.ssm_kl_along_gaussian_path(f_q, f_p, Qq, Qp, mu, cov)
+        p0 = self.dist_p.cholP0 @ self.dist_p.cholP0.T
+        return kl + self._np_sde.gauss_kl(q.mu0, q.cholP0 @ q.cholP0.T, self.dist_p.mu0, p0)
+
+    def grad_kl_wrt_exp_param(self):
+        q = self.dist_q
+        mu, cov = q.marginals
+        alpha, beta = self.sde.cubic(self.dt)
+        _, grads = self._np_sde.sde_ssm_kl_closed_form(mu, cov, q.subsequent_covariances(cov), alpha, beta, np.diag(self.sde.q),
+                                                       self.dt, self.init_mu, self.init_cov)
+        return grads

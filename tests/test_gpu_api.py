@@ -148,3 +148,86 @@ def test_cvi_sites_ssm(amd, rng, d, B, T):
     assert_close(host(q.state_transitions)[0], oq.A)
     assert_close(host(q.cholesky_process_covariances)[0], oq.cholQ)
     assert_close(host(q.state_offsets)[0], oq.b)
+
+
+@pytest.mark.parametrize("d,kind", [(1, "dw"), (2, "dw"), (2, "ou"), (3, "dw")])
+def test_sde_kl_kernel(amd, rng, d, kind):
+    """Closed-form KL[q || p_SDE] and d KL / d eta (HIP) against the oracle's closed form, itself pinned to the reference's
+    quadrature formulation in tests/test_oracle_sde.py."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    B, T, dt = 3, 37, 0.05
+    qd = 0.5 + rng.random(d)
+    osde = np_sde.OrnsteinUhlenbeckSDE(0.8, np.diag(qd)) if kind == "ou" else np_sde.DoubleWellSDE(np.diag(qd))
+    gs = gsde.OrnsteinUhlenbeckSDE(0.8, torch.from_numpy(np.diag(qd))) if kind == "ou" else gsde.DoubleWellSDE(torch.from_numpy(np.diag(qd)))
+    prm = random_ssm_params(rng, (B,), T, d, scale_A=0.8)
+    init_mu, init_cov = 0.1 * rng.normal(size=d), 0.7 * np.eye(d) + 0.1 * np.ones((d, d))
+    plan = amd.Plan(B, T, d, R0=5, Rup=3)
+    mus, covs, subs = [], [], []
+    for b in range(B):
+        q = np_ssm.StateSpaceModel(*[p[b] for p in prm])
+        mu, cov = q.marginals
+        mus.append(mu); covs.append(cov); subs.append(q.subsequent_covariances(cov))
+    mu, cov, sub = np.stack(mus), np.stack(covs), np.stack(subs)
+    pm, pc, ps = plan.pack(amd.VEC, dev(mu)), plan.pack(amd.SYM, dev(cov)), plan.pack(amd.FULL, dev(sub))
+    cprm = gs.params(dt, init_mu, init_cov)
+    grads = (plan.empty(amd.VEC), plan.empty(amd.SYM), plan.empty(amd.FULL))
+    kl0 = host(plan.sde_kl(cprm, pm, pc, ps, mode=0))
+    kl1 = host(plan.sde_kl(cprm, pm, pc, ps, mode=1, grads=grads))
+    plan.check_info()
+    g1, gd, gsub = host(plan.unpack(amd.VEC, grads[0])), host(plan.unpack(amd.SYM, grads[1])), host(plan.unpack(amd.FULL, grads[2], T - 1))
+    al, be = osde.cubic(dt)
+    for b in range(B):
+        kl, (o1, od, os_) = np_sde.sde_ssm_kl_closed_form(mu[b], cov[b], sub[b], al, be, qd, dt, init_mu, init_cov)
+        np.testing.assert_allclose(kl0[b], kl, rtol=1e-9)
+        np.testing.assert_allclose(kl1[b], kl, rtol=1e-9)
+        assert_close(g1[b], o1)
+        assert_close(gd[b], od)
+        assert_close(gsub[b], os_)
+
+
+@pytest.mark.parametrize("d,kind,B,T", [(1, "ou", 1, 60), (1, "dw", 2, 50), (2, "dw", 2, 45)])
+def test_cvi_sites_sde(amd, rng, d, kind, B, T):
+    """CVISitesSDE (CVI-DP): linearised prior, data-site and Girsanov updates, ELBO, re-linearisation, per trajectory."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    dt = 0.02
+    qd = np.ones(d)
+    osde = np_sde.OrnsteinUhlenbeckSDE(1.2, np.diag(qd)) if kind == "ou" else np_sde.DoubleWellSDE(np.diag(qd))
+    gs = gsde.OrnsteinUhlenbeckSDE(1.2, torch.from_numpy(np.diag(qd))) if kind == "ou" else gsde.DoubleWellSDE(torch.from_numpy(np.diag(qd)))
+    grid = np.arange(T) * dt
+    idx = np.sort(rng.choice(np.arange(1, T), size=6, replace=False))
+    y = np.sign(rng.normal(size=(B, 6, d))) + 0.2 * rng.normal(size=(B, 6, d))
+    cholR = 0.3 * np.eye(d)
+    init = (np.zeros(d), 0.5 * np.eye(d))
+    plan = amd.Plan(B, T, d, R0=8, Rup=3)
+    g = CVISitesSDE(gs, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)), prior_initial_state=init, plan=plan)
+    os_ = [np_models.CVISitesSDE(osde, grid, idx, y[b], np_models.MultivariateGaussianLik(cholR), *init) for b in range(B)]
+    assert_close(host(g.dist_p.state_transitions)[0], os_[0].dist_p.A)
+    assert_close(host(g.dist_p.state_offsets)[0], os_[0].dist_p.b)
+    for outer in range(2):
+        for lr_d, lr_g in ((0.5, 0.2), (0.3, 0.1)):
+            g.update_data_sites(lr_d)
+            g.update_girsanov_sites(lr_g)
+            e = host(g.classic_elbo_per_trajectory())
+            for b, o in enumerate(os_):
+                o.update_data_sites(lr_d)
+                o.update_girsanov_sites(lr_g)
+                np.testing.assert_allclose(e[b], o.classic_elbo(), rtol=1e-6, atol=1e-6)
+        mu, cov = host(g.fx_mus), host(g.fx_covs)
+        for b, o in enumerate(os_):
+            assert_close(mu[b], o.fx_mus)
+            assert_close(cov[b], o.fx_covs)
+        # re-linearise on the current posterior and transform the Girsanov sites (posterior unchanged)
+        g.relinearize()
+        for o in os_:
+            o.relinearize()
+        e = host(g.classic_elbo_per_trajectory())
+        for b, o in enumerate(os_):
+            np.testing.assert_allclose(e[b], o.classic_elbo(), rtol=1e-6, atol=1e-6)
+        assert_close(host(g.dist_p.state_transitions)[B - 1], os_[B - 1].dist_p.A)
+        assert_close(host(g.dist_p.state_offsets)[B - 1], os_[B - 1].dist_p.b)

@@ -61,3 +61,41 @@ def test_elbo_increases_with_damped_updates(rng):
         e = m.classic_elbo()
         assert e > prev - 1e-9
         prev = e
+
+
+def test_cvi_dp_ou_conjugate(rng):
+    """KA11 for CVISitesSDE: OU prior + Gaussian likelihood; lr = 1 updates reach the exact posterior, so
+    classic_elbo equals the log marginal likelihood of the Euler-discretised SSM."""
+    from oracle import np_btd, np_sde
+    T, dt, decay, qv = 60, 0.01, 1.2, 1.0
+    sde = np_sde.OrnsteinUhlenbeckSDE(decay, qv * np.eye(1))
+    idx = np.sort(rng.choice(np.arange(1, T), size=8, replace=False))
+    y = rng.normal(size=(8, 1))
+    cholR = 0.1 * np.eye(1)
+    P0 = qv / (2 * decay) * np.eye(1)
+    m = np_models.CVISitesSDE(sde, np.arange(T) * dt, idx, y, np_models.MultivariateGaussianLik(cholR), np.zeros(1), P0)
+    np.testing.assert_allclose(m.dist_p.A, 1 - decay * dt, rtol=1e-12)
+    m.update_data_sites(1.0)
+    m.update_girsanov_sites(1.0)
+    ssm = ou_euler_ssm(T, dt, decay, qv)
+    pd, ps = ssm.precision()
+    K = np.linalg.inv(np_btd.to_dense(pd, ps))
+    Kyy = K[np.ix_(idx, idx)] + 0.01 * np.eye(8)
+    yf = y[:, 0]
+    loglik = -0.5 * yf @ np.linalg.solve(Kyy, yf) - 0.5 * np.linalg.slogdet(Kyy)[1] - 0.5 * 8 * np.log(2 * np.pi)
+    np.testing.assert_allclose(m.classic_elbo(), loglik, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(m.g1, 0.0, atol=1e-7)
+
+
+def test_cvi_dp_double_well_elbo_improves(rng):
+    from oracle import np_sde
+    T, dt, d = 40, 0.02, 1
+    sde = np_sde.DoubleWellSDE(np.eye(1))
+    idx = np.arange(4, T, 6)
+    y = np.sign(rng.normal(size=(len(idx), d))) + 0.1 * rng.normal(size=(len(idx), d))
+    m = np_models.CVISitesSDE(sde, np.arange(T) * dt, idx, y, np_models.MultivariateGaussianLik(0.3 * np.eye(d)), np.zeros(d), np.eye(d))
+    e0 = m.classic_elbo()
+    for _ in range(3):
+        m.update_data_sites(0.5)
+        m.update_girsanov_sites(0.3)
+    assert m.classic_elbo() > e0

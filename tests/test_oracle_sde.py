@@ -1,0 +1,64 @@
+"""
+CPU tests of the oracle's SDE layer: the reference's quadrature formulation (mvnquad) against the closed-form
+Gaussian moments that the HIP kernels use, and the hand-derived d KL / d eta against finite differences of the
+quadrature KL (the stand-in for the reference's GradientTape).  KA10 (OU linearisation) as in
+tests/unit/test_sde.py:66-103.
+"""
+import numpy as np
+import pytest
+
+from oracle import np_sde, np_ssm, np_transforms
+from tests.helpers import random_ssm_params
+
+
+def test_mvnquad_moments(rng):
+    m = rng.normal(size=(4, 2))
+    L = np.tril(rng.normal(size=(4, 2, 2))) * 0.3 + np.eye(2)
+    S = L @ np.swapaxes(L, -1, -2)
+    got = np_sde.mvnquad(lambda x: x[:, :1] * x[:, 1:], m, S, 5, 2, (1,))[:, 0]
+    np.testing.assert_allclose(got, S[:, 0, 1] + m[:, 0] * m[:, 1], rtol=1e-12)
+
+
+def test_ou_linearisation_analytic(rng):
+    """KA10: linearize_sde of an OU process is exact: A = 1 - decay dt, b = 0, Q = q dt (test_sde.py:66-103)."""
+    decay, q, dt, N = 0.7, 1.3, 0.01, 30
+    sde = np_sde.OrnsteinUhlenbeckSDE(decay, q * np.eye(1))
+    t = np.arange(N + 1) * dt
+    ssm = np_sde.linearize_sde(sde, t, rng.normal(size=(N, 1)), 0.5 + rng.random((N, 1, 1)), np.zeros(1), np.eye(1))
+    np.testing.assert_allclose(ssm.A, (1 - decay * dt) * np.ones((N, 1, 1)), atol=1e-12)
+    np.testing.assert_allclose(ssm.b, 0.0, atol=1e-12)
+    np.testing.assert_allclose(ssm.cholQ, np.sqrt(q * dt) * np.ones((N, 1, 1)), atol=1e-12)
+
+
+@pytest.mark.parametrize("d", [1, 2])
+@pytest.mark.parametrize("kind", ["ou", "dw"])
+def test_closed_form_kl_and_gradient(rng, d, kind):
+    T, dt = 5, 0.05
+    qd = 0.5 + rng.random(d)
+    sde = np_sde.OrnsteinUhlenbeckSDE(0.8, np.diag(qd)) if kind == "ou" else np_sde.DoubleWellSDE(np.diag(qd))
+    q = np_ssm.StateSpaceModel(*random_ssm_params(rng, (), T, d, scale_A=0.8))
+    eta = np_transforms.ssm_to_expectations(q)
+    init_mu, init_cov = 0.1 * rng.normal(size=d), np.eye(d) * 0.7
+    kl_quad = np_sde.sde_ssm_kl_from_expectations(*eta, sde, dt, init_mu, init_cov)
+    mu, Sig = q.marginals
+    Sub = q.subsequent_covariances(Sig)
+    alpha, beta = sde.cubic(dt)
+    kl_cf, grads = np_sde.sde_ssm_kl_closed_form(mu, Sig, Sub, alpha, beta, qd, dt, init_mu, init_cov)
+    np.testing.assert_allclose(kl_cf, kl_quad, rtol=1e-9)
+    fd = np_sde.sde_ssm_kl_grads_fd(*eta, sde, dt, init_mu, init_cov, eps=1e-5)
+    for a, b in zip(grads, fd):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * max(1.0, np.max(np.abs(b))))
+
+
+def test_linear_prior_gradient_is_natural_parameter_difference(rng):
+    """For an OU (linear) prior the gradient equals theta_q - theta_p of the Euler SSM (the identity KA11 relies on)."""
+    T, dt, d = 6, 0.02, 1
+    sde = np_sde.OrnsteinUhlenbeckSDE(1.2, np.eye(1))
+    q = np_ssm.StateSpaceModel(*random_ssm_params(rng, (), T, d, scale_A=0.8))
+    mu, Sig = q.marginals
+    init_mu, init_cov = np.zeros(1), np.eye(1) * 0.4
+    _, grads = np_sde.sde_ssm_kl_closed_form(mu, Sig, q.subsequent_covariances(Sig), *sde.cubic(dt), np.ones(1), dt, init_mu, init_cov)
+    p = np_ssm.StateSpaceModel(init_mu, np.linalg.cholesky(init_cov), np.full((T - 1, 1, 1), 1 - 1.2 * dt), np.zeros((T - 1, 1)),
+                               np.full((T - 1, 1, 1), np.sqrt(dt)))
+    for g, tq, tp in zip(grads, np_transforms.ssm_to_naturals(q), np_transforms.ssm_to_naturals(p)):
+        np.testing.assert_allclose(g, tq - tp, rtol=1e-8, atol=1e-8)

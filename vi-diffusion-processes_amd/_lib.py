@@ -36,8 +36,18 @@ EXPORTS = {
     "mfgm_packed_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
                                  + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 6),
     "mfgm_packed_selinv_level": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8),
+    "mfgm_packed_sde_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 14),
+    "mfgm_packed_linearize_cubic": (ctypes.c_int, [ctypes.c_void_p] * 8),
     "mfgm_packed_kl_terms": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
 }
+
+
+class SdeParams(ctypes.Structure):
+    """mfgm_sde_params (include/mfgm.h)."""
+    _fields_ = [("alpha", ctypes.c_double * 8), ("beta", ctypes.c_double * 8), ("W", ctypes.c_double * 8),
+                ("P0inv", ctypes.c_double * 36), ("mu0", ctypes.c_double * 8), ("logdetQp", ctypes.c_double),
+                ("logdetP0", ctypes.c_double), ("lr", ctypes.c_double), ("clip_lo", ctypes.c_double),
+                ("clip_hi", ctypes.c_double), ("sq_dtq", ctypes.c_double * 8), ("cholP0", ctypes.c_double * 36)]
 
 
 class MfgmError(RuntimeError):

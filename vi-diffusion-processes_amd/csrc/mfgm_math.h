@@ -247,6 +247,31 @@ MFGM_DEV void gemm_tn_sym_acc(const double (&A)[D * D], const double (&B)[D * D]
         }
 }
 
+
+// X := X L^{-1}   (each row x solves a L = x by backward substitution over the columns)
+template <int D>
+MFGM_DEV void trsm_right_lower(const double (&L)[MFGM_NTRI(D)], const double (&invd)[D], double (&X)[D * D]) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+#pragma unroll
+        for (int j = D - 1; j >= 0; --j) {
+            double t = X[r * D + j];
+#pragma unroll
+            for (int k = j + 1; k < D; ++k) t = __builtin_fma(-X[r * D + k], L[tix(k, j)], t);
+            X[r * D + j] = t * invd[j];
+        }
+    }
+}
+
+// log of a product of positive numbers (used for log-determinants of small Cholesky factors)
+template <int D>
+MFGM_DEV double log_diag_prod(const double (&L)[MFGM_NTRI(D)]) {
+    double p = 1.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) p *= L[tix(j, j)];
+    return log(p);
+}
+
 // Running log-determinant accumulator without a log per pivot: keeps a mantissa product and an
 // integer exponent sum; log taken once at the end.
 struct LogAcc {

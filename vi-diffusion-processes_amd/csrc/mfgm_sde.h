@@ -1,0 +1,326 @@
+// CVI-DP local kernels: Girsanov KL between the Gaussian posterior chain q and the Euler-discretised SDE prior,
+// its gradient with respect to the expectation parameters, the fused Girsanov-site update, and the linearisation
+// of the SDE along the posterior path.
+//
+// The reference obtains these from tensor-product Gauss-Hermite quadrature plus a GradientTape through
+// expectations_to_ssm_params (sde_utils.py:262-359, 473-547; sde.py:92-131).  For drifts that are per-dimension
+// cubics (Ornstein-Uhlenbeck, double-well: u(x) = x + dt f(x) = alpha x - beta x^3) with diagonal diffusion the
+// Gaussian expectations are polynomial moments, so both the KL and its gradient are evaluated in closed form,
+// per transition (m,S,C,m',S') = (mu_t, Sigma_t, Sigma_{t+1,t}, mu_{t+1}, Sigma_{t+1}):
+//   KL_t = 1/2 { tr(W [V - J C^T - C J^T + S']) + |ubar - m'|^2_W - d - logdet(S' - C S^{-1} C^T) + logdet Qp }
+// with ubar = E u, J = E u' (diagonal), V = Var u (its diagonal suffices for diagonal W = Qp^{-1}).
+#pragma once
+#include "mfgm_local.h"
+
+namespace mfgm {
+
+struct SdeParams {
+    double alpha[8], beta[8];   // u_i(x) = alpha_i x - beta_i x^3
+    double W[8];                // 1 / (dt q_ii)
+    double P0inv[36];           // inverse prior initial covariance, packed lower triangle
+    double mu0[8];              // prior initial mean
+    double logdetQp;            // sum_i log(dt q_ii)
+    double logdetP0;            // log det of the prior initial covariance
+    double lr;                  // Girsanov learning rate (MODE 2)
+    double clip_lo, clip_hi;    // clipping of the linearised A, b (linearise kernel); lo >= hi disables
+    double sq_dtq[8];           // sqrt(dt q_ii): Cholesky of the prior process noise
+    double cholP0[36];          // Cholesky of the prior initial covariance, packed lower triangle
+};
+
+template <int D>
+MFGM_DEV void cubic_moments(const SdeParams& pr, const double (&m)[D], const double (&S)[MFGM_NTRI(D)], double (&ubar)[D],
+                            double (&J)[D], double (&V)[D], double (&ub_v)[D], double (&J_m)[D], double (&J_v)[D],
+                            double (&V_m)[D], double (&V_v)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double al = pr.alpha[i], be = pr.beta[i], mi = m[i], v = S[tix(i, i)];
+        const double m2 = mi * mi, a = m2 + v;
+        ubar[i] = al * mi - be * mi * (m2 + 3.0 * v);
+        J[i] = al - 3.0 * be * a;
+        V[i] = al * al * v - 6.0 * al * be * v * a + be * be * v * (9.0 * m2 * m2 + 36.0 * m2 * v + 15.0 * v * v);
+        ub_v[i] = -3.0 * be * mi;
+        J_m[i] = -6.0 * be * mi;
+        J_v[i] = -3.0 * be;
+        V_m[i] = -12.0 * al * be * mi * v + be * be * mi * v * (36.0 * m2 + 72.0 * v);
+        V_v[i] = al * al - 6.0 * al * be * (m2 + 2.0 * v) + be * be * (9.0 * m2 * m2 + 72.0 * m2 * v + 45.0 * v * v);
+    }
+}
+
+// One transition: returns its KL value; when GRAD, also the gradient pieces
+//   own node:   Gm[D], GS (sym, only the part added by this transition), GC (full)
+//   next node:  om[D] = -W e - GC m   (already includes the -GC_t m_t term of d/d eta1_{t+1}),  oS = 1/2 (W - P)
+template <int D, bool GRAD>
+MFGM_DEV double sde_transition(const SdeParams& pr, const double (&m)[D], const double (&S)[MFGM_NTRI(D)],
+                               const double (&C)[D * D], const double (&mn)[D], const double (&Sn)[MFGM_NTRI(D)],
+                               double (&Gm)[D], double (&GS)[MFGM_NTRI(D)], double (&GC)[D * D], double (&om)[D],
+                               double (&oS)[MFGM_NTRI(D)], int& bad) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    double ubar[D], J[D], V[D], ub_v[D], J_m[D], J_v[D], V_m[D], V_v[D];
+    cubic_moments<D>(pr, m, S, ubar, J, V, ub_v, J_m, J_v, V_m, V_v);
+    // A = C S^{-1}
+    double Ls[ET], invs[D], A[EF];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) Ls[e] = S[e];
+    chol_inplace<D>(Ls, invs, bad);
+#pragma unroll
+    for (int e = 0; e < EF; ++e) A[e] = C[e];
+    trsm_right_lower_t<D>(Ls, invs, A);
+    trsm_right_lower<D>(Ls, invs, A);
+    // Qq = S' - A C^T
+    double Lq[ET], invq[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double t = Sn[tix(i, j)];
+#pragma unroll
+            for (int k = 0; k < D; ++k) t = __builtin_fma(-A[i * D + k], C[j * D + k], t);
+            Lq[tix(i, j)] = t;
+        }
+    chol_inplace<D>(Lq, invq, bad);
+    double val = -2.0 * log_diag_prod<D>(Lq) + pr.logdetQp - (double)D;
+    double We[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double e = ubar[i] - mn[i];
+        We[i] = pr.W[i] * e;
+        const double kb = pr.W[i] * C[i * D + i];
+        val += pr.W[i] * V[i] - 2.0 * J[i] * kb + pr.W[i] * Sn[tix(i, i)] + We[i] * e;
+    }
+    val *= 0.5;
+    if (GRAD) {
+        double X[ET], P[ET], PA[EF];
+        tri_inverse<D>(Lq, invq, X);
+        tri_t_tri<D>(X, P);                       // P = Qq^{-1}
+        gemm_sym_full<D>(P, A, PA);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) GS[e] = 0.0;
+        gemm_tn_sym_acc<D>(A, PA, -0.5, GS);      // -1/2 A^T P A
+#pragma unroll
+        for (int e = 0; e < EF; ++e) GC[e] = PA[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double kb = pr.W[i] * C[i * D + i];
+            GC[i * D + i] -= pr.W[i] * J[i];
+            GS[tix(i, i)] += 0.5 * pr.W[i] * V_v[i] - kb * J_v[i] + We[i] * ub_v[i];
+            Gm[i] = 0.5 * pr.W[i] * V_m[i] - kb * J_m[i] + We[i] * J[i];
+        }
+        double t[D];
+        gemv<D>(GC, m, t);
+#pragma unroll
+        for (int i = 0; i < D; ++i) om[i] = -We[i] - t[i];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) oS[e] = -0.5 * P[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) oS[tix(i, i)] += 0.5 * pr.W[i];
+    }
+    return val;
+}
+
+// MODE 0: KL value only (per-lane partials).  MODE 1: also write d KL / d eta to (o1, od, os).
+// MODE 2: fused Girsanov update  g <- g - lr dKL/deta,  theta_q <- theta_q - lr dKL/deta  (o* = g arrays, q* = theta_q)
+template <int D, int MODE>
+__global__ __launch_bounds__(64) void k_sde_kl(LevelDesc lv, SdeParams pr, const double* __restrict__ mug,
+                                              const double* __restrict__ Sigg, const double* __restrict__ Subg,
+                                              double* __restrict__ part, double* o1, double* od, double* os, double* q1,
+                                              double* qd, double* qs, int* info) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    constexpr bool GRAD = (MODE != 0);
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    int bad = 0;
+    double kl = 0.0;
+    double m[D], S[ET], cm[D], cS[ET];
+    ld_node<D>(mug, R, 0, me, m);
+    ld_node<ET>(Sigg, R, 0, me, S);
+    if (p == 0) {
+        // KL(q(x0) || p(x0)) and its gradient
+        double Ls[ET], invs[D], X[ET], Si[ET], dm[D];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) Ls[e] = S[e];
+        chol_inplace<D>(Ls, invs, bad);
+        double tr = 0.0, mh = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) dm[i] = m[i] - pr.mu0[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                t = __builtin_fma(pr.P0inv[six(i, j)], dm[j], t);
+                tr = __builtin_fma(pr.P0inv[six(i, j)], S[six(i, j)], tr);
+            }
+            cm[i] = t;
+            mh = __builtin_fma(t, dm[i], mh);
+        }
+        kl = 0.5 * (tr + mh - (double)D + pr.logdetP0 - 2.0 * log_diag_prod<D>(Ls));
+        if (GRAD) {
+            tri_inverse<D>(Ls, invs, X);
+            tri_t_tri<D>(X, Si);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) cS[e] = 0.5 * (pr.P0inv[e] - Si[e]);
+        }
+    } else if (GRAD) {
+        // contribution of the transition that enters this segment (its KL value is counted by the lane on the left)
+        double mp[D], Sp[ET], Cp[EF], Gm[D], GS[ET], GC[EF];
+        const LaneRef left = LaneRef::of(lane - 1);
+        ld_node<D>(mug, R, R - 1, left, mp);
+        ld_node<ET>(Sigg, R, R - 1, left, Sp);
+        ld_node<EF>(Subg, R, R - 1, left, Cp);
+        sde_transition<D, true>(pr, mp, Sp, Cp, m, S, Gm, GS, GC, cm, cS, bad);
+    }
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            const bool has_next = (p * R + s + 1 < n);
+            double g1[D], gd[ET], gs[EF];
+            double mn[D], Sn[ET];
+            if (has_next) {
+                double C[EF], Gm[D], GS[ET], om[D], oS[ET];
+                ld_node<EF>(Subg, R, s, me, C);
+                ld_next<D>(mug, R, s, len, lane, me, mn);
+                ld_next<ET>(Sigg, R, s, len, lane, me, Sn);
+                kl += sde_transition<D, GRAD>(pr, m, S, C, mn, Sn, Gm, GS, gs, om, oS, bad);
+                if (GRAD) {
+#pragma unroll
+                    for (int e = 0; e < ET; ++e) gd[e] = cS[e] + GS[e];
+                    double t1[D], t2[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int j = 0; j < D; ++j) t = __builtin_fma(gd[six(i, j)], m[j], t);
+                        t1[i] = t;
+                    }
+                    gemv_t<D>(gs, mn, t2);
+#pragma unroll
+                    for (int i = 0; i < D; ++i) g1[i] = cm[i] + Gm[i] - 2.0 * t1[i] - t2[i];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) cm[i] = om[i];
+#pragma unroll
+                    for (int e = 0; e < ET; ++e) cS[e] = oS[e];
+                }
+            } else if (GRAD) {
+#pragma unroll
+                for (int e = 0; e < ET; ++e) gd[e] = cS[e];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) t = __builtin_fma(gd[six(i, j)], m[j], t);
+                    g1[i] = cm[i] - 2.0 * t;
+                }
+#pragma unroll
+                for (int e = 0; e < EF; ++e) gs[e] = 0.0;
+            }
+            if (MODE == 1) {
+                st_node<D>(o1, R, s, me, g1);
+                st_node<ET>(od, R, s, me, gd);
+                st_node<EF>(os, R, s, me, gs);
+            } else if (MODE == 2) {
+                double a1[D], ad[ET], as_[EF];
+                ld_node<D>(o1, R, s, me, a1);
+#pragma unroll
+                for (int e = 0; e < D; ++e) a1[e] = __builtin_fma(-pr.lr, g1[e], a1[e]);
+                st_node<D>(o1, R, s, me, a1);
+                ld_node<D>(q1, R, s, me, a1);
+#pragma unroll
+                for (int e = 0; e < D; ++e) a1[e] = __builtin_fma(-pr.lr, g1[e], a1[e]);
+                st_node<D>(q1, R, s, me, a1);
+                ld_node<ET>(od, R, s, me, ad);
+#pragma unroll
+                for (int e = 0; e < ET; ++e) ad[e] = __builtin_fma(-pr.lr, gd[e], ad[e]);
+                st_node<ET>(od, R, s, me, ad);
+                ld_node<ET>(qd, R, s, me, ad);
+#pragma unroll
+                for (int e = 0; e < ET; ++e) ad[e] = __builtin_fma(-pr.lr, gd[e], ad[e]);
+                st_node<ET>(qd, R, s, me, ad);
+                if (has_next) {
+                    ld_node<EF>(os, R, s, me, as_);
+#pragma unroll
+                    for (int e = 0; e < EF; ++e) as_[e] = __builtin_fma(-pr.lr, gs[e], as_[e]);
+                    st_node<EF>(os, R, s, me, as_);
+                    ld_node<EF>(qs, R, s, me, as_);
+#pragma unroll
+                    for (int e = 0; e < EF; ++e) as_[e] = __builtin_fma(-pr.lr, gs[e], as_[e]);
+                    st_node<EF>(qs, R, s, me, as_);
+                }
+            }
+            if (has_next) {
+#pragma unroll
+                for (int e = 0; e < D; ++e) m[e] = mn[e];
+#pragma unroll
+                for (int e = 0; e < ET; ++e) S[e] = Sn[e];
+            }
+        }
+    }
+    if (part) part[lane] = kl;
+    if (bad) atomicMax(info, 1);
+}
+
+// Linearisation of the SDE along the posterior path (set_linearized_prior, variational_cvi_sde.py:408-432;
+// linearize_sde, sde_utils.py:119-179; LinearDrift.to_ssm, drift.py:66-117), written directly as packed SSM
+// parameters.  Transition t -> t+1 is linearised on the marginal of node t+1 (the reference passes fx_mus[1:]):
+//     A_t = diag(J(m_{t+1}, v_{t+1})),   b_t = ubar - J m   at node t+1,   Q_t = dt q,
+// both clipped to [clip_lo, clip_hi] when stabilising.  Node 0 carries the prior initial state.
+template <int D>
+__global__ __launch_bounds__(64) void k_linearize_cubic(LevelDesc lv, SdeParams pr, const double* __restrict__ mug,
+                                                       const double* __restrict__ Sigg,
+                                                       double* __restrict__ Ag, double* __restrict__ offg,
+                                                       double* __restrict__ cholg) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    const bool clip = pr.clip_lo < pr.clip_hi;
+    auto clipf = [&](double x) { return clip ? fmin(fmax(x, pr.clip_lo), pr.clip_hi) : x; };
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            const int t = p * R + s;
+            double m[D], S[ET], ubar[D], J[D], V[D], t0[D], t1[D], t2[D], t3[D], t4[D];
+            // offsets / chol of this node
+            double off[D], ch[ET];
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) off[i] = pr.mu0[i];
+#pragma unroll
+                for (int e = 0; e < ET; ++e) ch[e] = pr.cholP0[e];
+            } else {
+                ld_node<D>(mug, R, s, me, m);
+                ld_node<ET>(Sigg, R, s, me, S);
+                cubic_moments<D>(pr, m, S, ubar, J, V, t0, t1, t2, t3, t4);
+#pragma unroll
+                for (int i = 0; i < D; ++i) off[i] = clipf(ubar[i] - J[i] * m[i]);
+#pragma unroll
+                for (int e = 0; e < ET; ++e) ch[e] = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) ch[tix(i, i)] = pr.sq_dtq[i];
+            }
+            st_node<D>(offg, R, s, me, off);
+            st_node<ET>(cholg, R, s, me, ch);
+            double A[EF];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) A[e] = 0.0;
+            if (t + 1 < n) {
+                ld_next<D>(mug, R, s, len, lane, me, m);
+                ld_next<ET>(Sigg, R, s, len, lane, me, S);
+                cubic_moments<D>(pr, m, S, ubar, J, V, t0, t1, t2, t3, t4);
+#pragma unroll
+                for (int e = 0; e < EF; ++e) A[e] = clipf(0.0);
+#pragma unroll
+                for (int i = 0; i < D; ++i) A[i * D + i] = clipf(J[i]);
+            }
+            st_node<EF>(Ag, R, s, me, A);
+        }
+    }
+}
+
+}  // namespace mfgm

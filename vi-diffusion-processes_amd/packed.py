@@ -152,6 +152,25 @@ class Plan:
                    "mfgm_packed_kl_terms")
         return tr, mh
 
+    def sde_kl(self, prm, mu, Sig, Sub, mode=0, grads=None, theta_q=None, want_kl=True):
+        """Closed-form KL[q || p_SDE] (mode 0), + gradient wrt eta (mode 1, into `grads`), or fused Girsanov update (mode 2)."""
+        kl = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_kl else None
+        g = grads if grads is not None else (None, None, None)
+        q = theta_q if theta_q is not None else (None, None, None)
+        _lib.check(self.lib.mfgm_packed_sde_kl(self.h, int(mode), ctypes.byref(prm), _ptr(mu), _ptr(Sig), _ptr(Sub), _ptr(kl),
+                                               _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]),
+                                               _ptr(self.ws), _ptr(self.info), _stream()), "mfgm_packed_sde_kl")
+        return kl
+
+    def linearize_cubic(self, prm, mu, Sig, out=None):
+        """SDE linearised on the path (mu, Sig) as packed SSM parameters (A, off, chol)."""
+        A = out[0] if out else self.empty(FULL)
+        off = out[1] if out else self.empty(VEC)
+        chol = out[2] if out else self.empty(TRI)
+        _lib.check(self.lib.mfgm_packed_linearize_cubic(self.h, ctypes.byref(prm), _ptr(mu), _ptr(Sig), _ptr(A), _ptr(off),
+                                                        _ptr(chol), _stream()), "mfgm_packed_linearize_cubic")
+        return A, off, chol
+
     def node_ids(self, time_index):
         """int64 device tensor b*T + t for every chain and every index in `time_index` ([n] or [B, n])."""
         ti = torch.as_tensor(time_index, dtype=torch.int64, device=self.device)

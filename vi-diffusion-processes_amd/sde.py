@@ -1,0 +1,100 @@
+"""
+Host-side mirror of markovflow/sde/sde.py for the drifts on the path: `OrnsteinUhlenbeckSDE` (sde.py:134-176) and
+`DoubleWellSDE` (sde.py:179-224).  Both drifts act per dimension and their Euler map is a cubic
+u(x) = x + dt f(x) = alpha x - beta x^3, which is what the HIP kernels consume (closed-form Gaussian moments in
+place of the reference's 10^d / 20^d-point Gauss-Hermite grids).  The diffusion matrix q must be diagonal for d > 1.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class SDE:
+    """sde.py:24-131."""
+
+    def __init__(self, q):
+        q = torch.as_tensor(q, dtype=torch.float64)
+        if q.dim() == 0:
+            q = q.reshape(1, 1)
+        self.q = q
+        self.state_dim = q.shape[0]
+        qd = torch.diagonal(q)
+        if self.state_dim > 1 and not torch.equal(torch.diag(qd), q.cpu() if q.is_cuda else q):
+            raise ValueError("the HIP path needs a diagonal diffusion matrix q for state_dim > 1")
+        self.q_diag = [float(v) for v in qd]
+
+    def drift(self, x, t=None):
+        raise NotImplementedError
+
+    def gradient_drift(self, x, t=None):
+        raise NotImplementedError
+
+    def diffusion(self, x, t=None):
+        """l(x, t) = sqrt(q) (sde.py:165-176)."""
+        return torch.ones_like(x[..., None]) * torch.linalg.cholesky(self.q.to(x.device))
+
+    def cubic(self, dt):
+        """(alpha, beta) of the Euler map u(x) = x + dt f(x) = alpha x - beta x^3."""
+        raise NotImplementedError
+
+    def params(self, dt, init_mu, init_cov, lr=0.0, clip=None):
+        """Fill the C parameter block (mfgm_sde_params)."""
+        d = self.state_dim
+        al, be = self.cubic(dt)
+        prm = _lib.SdeParams()
+        P0 = np.asarray(init_cov, dtype=np.float64).reshape(d, d)
+        P0inv = np.linalg.inv(P0)
+        cP0 = np.linalg.cholesky(P0)
+        for i in range(d):
+            prm.alpha[i], prm.beta[i] = al, be
+            prm.W[i] = 1.0 / (dt * self.q_diag[i])
+            prm.sq_dtq[i] = math.sqrt(dt * self.q_diag[i])
+            prm.mu0[i] = float(np.asarray(init_mu).reshape(-1)[i])
+            for j in range(i + 1):
+                prm.P0inv[i * (i + 1) // 2 + j] = P0inv[i, j]
+                prm.cholP0[i * (i + 1) // 2 + j] = cP0[i, j]
+        prm.logdetQp = sum(math.log(dt * v) for v in self.q_diag)
+        prm.logdetP0 = float(np.linalg.slogdet(P0)[1])
+        prm.lr = float(lr)
+        if clip is None:
+            prm.clip_lo, prm.clip_hi = 1.0, 0.0
+        else:
+            prm.clip_lo, prm.clip_hi = float(clip[0]), float(clip[1])
+        return prm
+
+
+class OrnsteinUhlenbeckSDE(SDE):
+    """dx = -decay x dt + dB, spectral density q (sde.py:134-176)."""
+
+    def __init__(self, decay=1.0, q=None):
+        super().__init__(torch.ones((1, 1), dtype=torch.float64) if q is None else q)
+        self.decay = float(decay)
+
+    def drift(self, x, t=None):
+        return -self.decay * x
+
+    def gradient_drift(self, x, t=None):
+        return -self.decay * torch.ones_like(x)
+
+    def cubic(self, dt):
+        return 1.0 - dt * self.decay, 0.0
+
+
+class DoubleWellSDE(SDE):
+    """dx = scale x (c - x^2) dt + dB (sde.py:179-224)."""
+
+    def __init__(self, q=None, scale=4.0, c=1.0):
+        super().__init__(torch.ones((1, 1), dtype=torch.float64) if q is None else q)
+        self.scale, self.c = float(scale), float(c)
+
+    def drift(self, x, t=None):
+        return self.scale * x * (self.c - x * x)
+
+    def gradient_drift(self, x, t=None):
+        return self.scale * (self.c - 3.0 * x * x)
+
+    def cubic(self, dt):
+        return 1.0 + dt * self.scale * self.c, dt * self.scale

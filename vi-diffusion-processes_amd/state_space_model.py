@@ -55,6 +55,17 @@ class StateSpaceModel:
         self._prec = None
         self._post = None
 
+    def __getattr__(self, name):
+        # natural-layout parameter tensors of a model created from packed arrays are unpacked on first use
+        if name in ("_A", "_b", "_cholQ", "_mu0", "_cholP0") and self.__dict__.get("_lazy_natural"):
+            pl, pk = self.plan, self._packed
+            off = pl.unpack(VEC, pk.off)
+            chol = pl.unpack(TRI, pk.chol)
+            self.__dict__.update(_A=pl.unpack(FULL, pk.A, self.T - 1), _b=off[:, 1:].contiguous(), _mu0=off[:, 0].contiguous(),
+                                 _cholQ=chol[:, 1:].contiguous(), _cholP0=chol[:, 0].contiguous(), _lazy_natural=False)
+            return self.__dict__[name]
+        raise AttributeError(name)
+
     # -- reference-named accessors -----------------------------------------------------------
     @property
     def state_dim(self):

@@ -224,3 +224,121 @@ class CVISitesSSM:
     def classic_elbo(self):
         """E_q[log p(Y|X)] - KL[q || p], summed over trajectories (variational_cvi_sde.py:339-352)."""
         return self.classic_elbo_per_trajectory().sum()
+
+
+class CVISitesSDE(CVISitesSSM):
+    """
+    CVI-DP (variational_cvi_sde.py:368-518): non-linear SDE prior, linearised along the current posterior path;
+    KL[q || p_SDE] and its gradient with respect to the expectation parameters in closed form (HIP kernel k_sde_kl).
+    `prior_initial_state` is a (mean [d], covariance [d, d]) pair; default N(0, q) as in the reference (:437-444).
+    """
+
+    def __init__(self, prior_sde, time_grid, input_data, likelihood, prior_initial_state=None, initial_posterior_path=None,
+                 stabilize_ssm=True, clip_state_transitions=(-1.0, 1.0), plan=None):
+        self.prior_sde = prior_sde
+        d = input_data[1].shape[-1]
+        if prior_initial_state is None:
+            q = prior_sde.q.cpu().numpy()
+            prior_initial_state = (torch.zeros(d, dtype=torch.float64).numpy(), q * (torch.ones((d, d), dtype=torch.float64).numpy()))
+        self.stabilize_ssm = stabilize_ssm
+        self.clip_state_transitions = clip_state_transitions
+        super().__init__(None, time_grid, input_data, likelihood, prior_initial_state=prior_initial_state,
+                         initial_posterior_path=initial_posterior_path, plan=plan)
+        self._sde_prm = prior_sde.params(self.dt, prior_initial_state[0], prior_initial_state[1])
+        self.dist_p_linearized = None
+        self.set_linearized_prior()
+
+    def _path_packed(self):
+        """Current posterior path (mu, Sigma) in packed form: the initial path before the first refresh."""
+        if self._q is not None:
+            return self._q["mu"], self._q["Sig"]
+        if self._path is not None:
+            return self._path
+        pl, d = self.plan, self.state_dim
+        mu = pl.zeros(VEC)
+        eye = torch.eye(d, dtype=torch.float64, device=self.device).expand(self.B, self.T, d, d).contiguous()
+        self._path = (mu, pl.pack(SYM, eye))
+        return self._path
+
+    def set_linearized_prior(self):
+        """Linearise the SDE on the current posterior (variational_cvi_sde.py:408-432) and install it as dist_p."""
+        pl = self.plan
+        mu, Sig = self._path_packed()
+        prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1], clip=None)
+        A, off, chol = pl.linearize_cubic(prm, mu, Sig)
+        self.dist_p_linearized = _ssm_from_packed(pl, A, off, chol)
+        if self.stabilize_ssm:
+            prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1],
+                                        clip=self.clip_state_transitions)
+            A, off, chol = pl.linearize_cubic(prm, mu, Sig)
+            self._set_prior(_ssm_from_packed(pl, A, off, chol))
+        else:
+            self._set_prior(self.dist_p_linearized)
+
+    def relinearize(self):
+        """
+        Re-linearise on the current posterior and move the Girsanov sites to the new prior so that the posterior is
+        unchanged: the trainer's sequence `dist_p_last = dist_p; set_linearized_prior(); tranform_girsanov_sites(...)`
+        (docs/diffusion_processes/cvi_dp_trainer.py:127-134, sde_utils.py:550-568).
+        """
+        old = self._theta_p
+        q_valid = self._q
+        self.set_linearized_prior()
+        tranform_girsanov_sites(self.plan, self.girsanov_sites, old, self._theta_p)
+        # theta_q = theta_p + g + data is invariant under the transformation: the cached posterior stays valid
+        self._theta_q_valid = True
+        self._q = q_valid
+
+    def KL_q_p(self):
+        """KL between the posterior chain and the SDE prior, per trajectory [B] (variational_cvi_sde.py:446-486)."""
+        q = self._refresh()
+        return self.plan.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=0)
+
+    def grad_kl_wrt_exp_param(self):
+        """(KL [B], (d/d eta_lin, d/d eta_diag, d/d eta_sub) packed) (variational_cvi_sde.py:488-493)."""
+        q = self._refresh()
+        pl = self.plan
+        grads = (pl.empty(VEC), pl.empty(SYM), pl.empty(FULL))
+        kl = pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=1, grads=grads)
+        return kl, grads
+
+    def update_girsanov_sites(self, lr: float):
+        """Fused: g <- g + lr (scatter(data) - dKL/d eta), theta_q moves by the same increment (variational_cvi_sde.py:279-299)."""
+        q = self._refresh()
+        pl, g, tq = self.plan, self.girsanov_sites, self.full_sites()
+        self._sde_prm.lr = float(lr)
+        pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=2, grads=(g.lin, g.diag, g.sub),
+                  theta_q=(tq.lin, tq.diag, tq.sub), want_kl=False)
+        for kind, gg, qq, val in ((VEC, g.lin, tq.lin, self.data_nat1), (SYM, g.diag, tq.diag, self.data_nat2)):
+            v = lr * val
+            pl.scatter_nodes(kind, gg, self.obs_node_ids, v, accumulate=True)
+            pl.scatter_nodes(kind, qq, self.obs_node_ids, v, accumulate=True)
+        self._q = None
+        self._gather_obs()
+
+
+def tranform_girsanov_sites(plan, girsanov_sites, current_prior_nat, new_prior_nat):
+    """
+    g <- g + theta(current prior) - theta(new prior), in place (sde_utils.py:550-568; the reference's spelling).
+    All arguments are packed natural parameters (PackedBTDNat).
+    """
+    for g, a, b in ((girsanov_sites.lin, current_prior_nat.lin, new_prior_nat.lin),
+                    (girsanov_sites.diag, current_prior_nat.diag, new_prior_nat.diag),
+                    (girsanov_sites.sub, current_prior_nat.sub, new_prior_nat.sub)):
+        plan.lincomb(g, 1.0, g, 1.0, a, -1.0, b)
+    return girsanov_sites
+
+
+def _ssm_from_packed(plan, A, off, chol):
+    """StateSpaceModel whose packed parameter arrays are given (natural tensors are produced lazily on demand)."""
+    T, d = plan.T, plan.d
+    ssm = StateSpaceModel.__new__(StateSpaceModel)
+    ssm.batch_shape = (plan.B,)
+    ssm.B, ssm.T, ssm.d = plan.B, T, d
+    ssm.plan = plan
+    from .state_space_model import PackedSSM
+    ssm._packed = PackedSSM(plan, A, off, chol)
+    ssm._prec = None
+    ssm._post = None
+    ssm._lazy_natural = True
+    return ssm
