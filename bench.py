@@ -43,46 +43,42 @@ def synth_double_well(B, T, d, dt, obs_every, noise, seed):
     return idx, ys
 
 
-def linearised_prior(B, T, d, dt, device):
-    """Euler SSM of the double-well linearised on the initial posterior path N(0, I):
-    A = 1 + dt*4*(1 - 3(m^2+S)) = 1 - 8 dt, b = 0, Q = dt I (sde_utils.py:119-179, drift.py:102-108), P0 = I."""
-    eye = torch.eye(d, dtype=torch.float64, device=device)
-    A = ((1.0 - 8.0 * dt) * eye).expand(B, T - 1, d, d).contiguous()
-    b = torch.zeros((B, T - 1, d), dtype=torch.float64, device=device)
-    cholQ = (np.sqrt(dt) * eye).expand(B, T - 1, d, d).contiguous()
-    return torch.zeros((B, d), dtype=torch.float64, device=device), eye.expand(B, d, d).contiguous(), A, b, cholQ
-
-
-def cpu_baseline(args, idx, ys, dt, noise):
-    """The plain-C port (oracle/csrc/btd_ref.c) of the same step on a bounded sample of trajectories."""
+def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
+    """The plain-C port (oracle/csrc/btd_ref.c) of the same CVI-DP step on a bounded sample of trajectories."""
     from oracle import c_ref
     lib = c_ref.load()
     threads = int(lib.ref_num_threads())
     Bs = max(1, min(args.B, threads))
     T, d = args.T, args.d
-    A = np.broadcast_to((1.0 - 8.0 * dt) * np.eye(d), (T - 1, d, d))
+    alpha, beta = 1.0 + dt * 4.0, dt * 4.0
+    Jlin = alpha - 3.0 * beta                       # linearisation on N(0, I): A = J, b = 0
+    A = np.broadcast_to(Jlin * np.eye(d), (T - 1, d, d))
     off = np.zeros((T, d))
     chol = np.concatenate([np.eye(d)[None], np.broadcast_to(np.sqrt(dt) * np.eye(d), (T - 1, d, d))], axis=0)
     lin, diag, sub = c_ref.ssm_to_naturals(A, off, chol)
     rep = lambda a: np.broadcast_to(a, (Bs,) + a.shape).copy()
-    pslc = np.full(Bs, np.sum(np.log(np.einsum("tii->ti", chol))))
     Rinv = np.eye(d) / noise ** 2
-    st = c_ref.CviStepState(rep(lin), rep(diag), rep(sub), np.zeros((Bs, T, d)), pslc, idx, ys[:Bs], Rinv,
-                            2 * d * np.log(noise))
-    st.step(args.lr, args.lr)  # warm-up (page-in)
+    st = c_ref.CviDpStepState(rep(lin), rep(diag), rep(sub), idx, ys[:Bs], Rinv, 2 * d * np.log(noise), alpha, beta,
+                              np.ones(d), dt, np.zeros(d), np.eye(d))
+    st.step(args.lr_data, args.lr_girsanov)         # first step doubles as warm-up and as a parity probe
+    first = st.elbo.copy()
     n, t0 = 0, time.perf_counter()
     while True:
-        st.step(args.lr, args.lr)
+        st.step(args.lr_data, args.lr_girsanov)
         n += 1
         el = time.perf_counter() - t0
         if el > 10.0 or n >= 20:
             break
     per_step_sample = el / n
-    # throughput for the full per-GPU workload, linear in the number of trajectories
     value = 1.0 / (per_step_sample * args.B / Bs)
-    return {"value": value, "unit": "ELBO steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steps of {Bs} of the {args.B} trajectories (T={T}, d={d}), OpenMP over trajectories; "
-                      f"{per_step_sample:.3f} s per sampled step, scaled linearly to {args.B} trajectories"}
+    out = {"value": value, "unit": "ELBO steps/s", "cores": threads, "kind": "port",
+           "sample": f"{n} steps of {Bs} of the {args.B} trajectories (T={T}, d={d}), OpenMP over trajectories; "
+                     f"{per_step_sample:.3f} s per sampled step, scaled linearly to {args.B} trajectories; "
+                     f"closed-form cubic-drift moments as on the GPU (the reference's 20^d-point quadrature is infeasible at d={d})"}
+    if gpu_first_elbo is not None:
+        ref = first[:Bs]
+        out["first_step_elbo_max_rel_diff_vs_gpu"] = float(np.max(np.abs(gpu_first_elbo[:Bs] - ref) / np.abs(ref)))
+    return out
 
 
 def main():
@@ -93,7 +89,8 @@ def main():
     ap.add_argument("--B", type=int, default=64, help="trajectories per GPU")
     ap.add_argument("--T", type=int, default=100000)
     ap.add_argument("--d", type=int, default=6)
-    ap.add_argument("--lr", type=float, default=0.5)
+    ap.add_argument("--lr-data", type=float, default=0.5)
+    ap.add_argument("--lr-girsanov", type=float, default=0.1)
     ap.add_argument("--obs-every", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -112,24 +109,28 @@ def main():
 
     import vidp_amd
     from vidp_amd.likelihoods import MultivariateGaussian
-    from vidp_amd.state_space_model import StateSpaceModel
-    from vidp_amd.variational_cvi_sde import CVISitesSSM
+    from vidp_amd.sde import DoubleWellSDE
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
 
     B, T, d = args.B, args.T, args.d
     dt, noise = 0.01, 0.1
     idx, ys = synth_double_well(B, T, d, dt, args.obs_every, noise, seed=71892305 + 3 + rank)
     plan = vidp_amd.Plan(B, T, d, device=device)
-    prior = StateSpaceModel(*linearised_prior(B, T, d, dt, device), plan=plan)
     grid = np.arange(T) * dt
     lik = MultivariateGaussian(noise * torch.eye(d, dtype=torch.float64, device=device))
-    model = CVISitesSSM(prior, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik, plan=plan)
+    sde = DoubleWellSDE(q=torch.eye(d, dtype=torch.float64))
+    model = CVISitesSDE(sde, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik,
+                        prior_initial_state=(np.zeros(d), np.eye(d)), plan=plan)
 
-    elbos = []
+    elbos, first_elbo = [], []
 
     def step():
-        model.update_data_sites(args.lr)
-        model.update_girsanov_sites(args.lr)
-        e = model.classic_elbo()
+        model.update_data_sites(args.lr_data)
+        model.update_girsanov_sites(args.lr_girsanov)
+        e_traj = model.classic_elbo_per_trajectory()
+        if not first_elbo:
+            first_elbo.append(e_traj.clone())
+        e = e_traj.sum()
         if dist is not None:
             dist.all_reduce(e)
         elbos.append(e)
@@ -162,8 +163,8 @@ def main():
         "value": args.steps / elapsed, "unit": "ELBO steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"CVI site-update loop (update_data_sites + update_girsanov_sites + classic_elbo) on "
-                               f"double-well trajectories with the linearised prior, T={T}, d={d}, {B} trajectories per GPU, "
+        "config": {"workload": f"CVI-DP site-update loop (CVISitesSDE: update_data_sites + update_girsanov_sites + classic_elbo) "
+                               f"on double-well SDE trajectories, T={T}, d={d}, {B} trajectories per GPU, "
                                f"observation every {args.obs_every} steps",
                    "trajectories_per_gpu": B, "T": T, "d": d, "total_trajectories": B * world,
                    "partition": {"levels": plan.nlevels, "segment_len": plan.R, "lanes": plan.Lpad}},
@@ -199,7 +200,7 @@ def main():
                            "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise)
+                out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise, first_elbo[0].cpu().numpy())
             except OSError as e:  # library not built
                 out["cpu_baseline"] = {"value": None, "unit": "ELBO steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
         print(json.dumps(out))

@@ -33,6 +33,13 @@ def load():
         lib.ref_cvi_step.restype = ctypes.c_double
         lib.ref_cvi_step.argtypes = ([ctypes.c_int] * 4 + [_ip, _dp, _dp, ctypes.c_double] + [_dp] * 10
                                      + [ctypes.c_double, ctypes.c_double, _dp, _dp])
+        lib.ref_sde_kl.restype = ctypes.c_double
+        lib.ref_sde_kl.argtypes = [_dp] * 6 + [ctypes.c_double, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]
+        lib.ref_cvi_dp_step_work_doubles.restype = ctypes.c_size_t
+        lib.ref_cvi_dp_step_work_doubles.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.ref_cvi_dp_step.restype = ctypes.c_double
+        lib.ref_cvi_dp_step.argtypes = ([ctypes.c_int] * 4 + [_ip, _dp, _dp, ctypes.c_double] + [_dp] * 6 + [ctypes.c_double]
+                                        + [_dp] * 7 + [ctypes.c_double, ctypes.c_double, _dp, _dp])
         lib.ref_num_threads.restype = ctypes.c_int
         _lib = lib
     return _lib
@@ -107,3 +114,34 @@ class CviStepState:
                                 self.logdetR, _p(self.p1), _p(self.pd), _p(self.ps), _p(self.pmu), _p(self.pslc),
                                 _p(self.g1), _p(self.g2d), _p(self.g2s), _p(self.d1), _p(self.d2), lr_d, lr_g,
                                 _p(self.work), _p(self.elbo))
+
+
+def sde_kl(mu, Sig, Sub, alpha, beta, qdiag, dt, init_mu, init_cov, want_grads=True):
+    lib = load()
+    mu, Sig, Sub = c64(mu), c64(Sig), c64(Sub)
+    T, d = mu.shape
+    al, be, qd = c64(np.broadcast_to(alpha, (d,))), c64(np.broadcast_to(beta, (d,))), c64(qdiag)
+    g1, gd, gs = np.zeros((T, d)), np.zeros((T, d, d)), np.zeros((T - 1, d, d))
+    kl = lib.ref_sde_kl(_p(mu), _p(Sig), _p(Sub), _p(al), _p(be), _p(qd), float(dt), _p(c64(init_mu)), _p(c64(init_cov)), T, d,
+                        int(want_grads), _p(g1), _p(gd), _p(gs))
+    return (kl, (g1, gd, gs)) if want_grads else kl
+
+
+class CviDpStepState(CviStepState):
+    """Host arrays for ref_cvi_dp_step (B chains, fixed linearised prior naturals)."""
+
+    def __init__(self, p1, pd, ps, idx, y, Rinv, logdetR, alpha, beta, qdiag, dt, init_mu, init_cov):
+        B, T, d = np.asarray(p1).shape
+        super().__init__(p1, pd, ps, np.zeros((B, T, d)), np.zeros(B), idx, y, Rinv, logdetR)
+        self.alpha, self.beta = c64(np.broadcast_to(alpha, (d,))), c64(np.broadcast_to(beta, (d,)))
+        self.qdiag, self.dt = c64(qdiag), float(dt)
+        self.init_mu, self.init_cov = c64(init_mu), c64(init_cov)
+        lib = load()
+        self.work = np.zeros(B * lib.ref_cvi_dp_step_work_doubles(T, d))
+
+    def step(self, lr_d, lr_g):
+        lib = load()
+        return lib.ref_cvi_dp_step(self.B, self.T, self.d, self.n, self.idx.ctypes.data_as(_ip), _p(self.y), _p(self.Rinv),
+                                   self.logdetR, _p(self.p1), _p(self.pd), _p(self.ps), _p(self.alpha), _p(self.beta),
+                                   _p(self.qdiag), self.dt, _p(self.init_mu), _p(self.init_cov), _p(self.g1), _p(self.g2d),
+                                   _p(self.g2s), _p(self.d1), _p(self.d2), lr_d, lr_g, _p(self.work), _p(self.elbo))

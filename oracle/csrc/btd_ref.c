@@ -316,6 +316,207 @@ double ref_cvi_step(int B, int T, int d, int n, const int* idx, const double* y,
     return total;
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CVI-DP (CVISitesSDE) with a per-dimension cubic Euler map u(x) = alpha x - beta x^3 and diagonal diffusion:
+ * closed-form Girsanov KL and its gradient with respect to the expectation parameters, restating
+ * oracle/np_sde.py::sde_ssm_kl_closed_form (itself pinned to the reference's quadrature formulation,
+ * sde_utils.py:262-359, 473-547, by tests/test_oracle_sde.py).
+ * mu [T,d], Sig [T,d,d], Sub [T-1,d,d]; outputs g1 [T,d], gd [T,d,d], gs [T-1,d,d] when want_grads.
+ * ------------------------------------------------------------------------------------------------------------ */
+static void inv_spd(const double* S, double* out, double* logdet, int d, double* tmp) {
+    memcpy(tmp, S, (size_t)d * d * sizeof(double));
+    chol_d(tmp, d);
+    double ld = 0.0;
+    for (int i = 0; i < d; ++i) ld += log(tmp[IDX(i, i, d)]);
+    *logdet = 2.0 * ld;
+    memset(out, 0, (size_t)d * d * sizeof(double));
+    for (int i = 0; i < d; ++i) out[IDX(i, i, d)] = 1.0;
+    trsm_l(tmp, out, d, d);
+    trsm_lt(tmp, out, d, d);
+}
+
+double ref_sde_kl(const double* mu, const double* Sig, const double* Sub, const double* alpha, const double* beta,
+                  const double* qdiag, double dt, const double* init_mu, const double* init_cov, int T, int d, int want_grads,
+                  double* g1, double* gd, double* gs) {
+    const int dd = d * d;
+    double* buf = (double*)calloc((size_t)12 * dd + 16 * d, sizeof(double));
+    double *P0inv = buf, *tmp = buf + dd, *Sinv = buf + 2 * dd, *A = buf + 3 * dd, *Qq = buf + 4 * dd, *P = buf + 5 * dd,
+           *PA = buf + 6 * dd, *AtPA = buf + 7 * dd, *S0inv = buf + 8 * dd;
+    double *W = buf + 12 * dd, *ubar = W + d, *J = ubar + d, *V = J + d, *ub_v = V + d, *J_m = ub_v + d, *J_v = J_m + d,
+           *V_m = J_v + d, *V_v = V_m + d, *We = V_v + d, *kv = We + d;
+    double logdetQp = 0.0, ld;
+    for (int i = 0; i < d; ++i) { W[i] = 1.0 / (dt * qdiag[i]); logdetQp += log(dt * qdiag[i]); }
+    double* Gm = NULL;
+    if (want_grads) {
+        Gm = (double*)calloc((size_t)T * d, sizeof(double));
+        memset(gd, 0, (size_t)T * dd * sizeof(double));
+        memset(gs, 0, (size_t)(T - 1) * dd * sizeof(double));
+    }
+    double ldP0;
+    inv_spd(init_cov, P0inv, &ldP0, d, tmp);
+    inv_spd(Sig, S0inv, &ld, d, tmp);
+    double kl = 0.0, tr = 0.0, mh = 0.0;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            tr += P0inv[IDX(i, j, d)] * Sig[IDX(i, j, d)];
+            mh += (mu[i] - init_mu[i]) * P0inv[IDX(i, j, d)] * (mu[j] - init_mu[j]);
+        }
+    kl = 0.5 * (tr + mh - d + ldP0 - ld);
+    if (want_grads) {
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                Gm[i] += P0inv[IDX(i, j, d)] * (mu[j] - init_mu[j]);
+                gd[IDX(i, j, d)] += 0.5 * (P0inv[IDX(i, j, d)] - S0inv[IDX(i, j, d)]);
+            }
+    }
+    for (int t = 0; t < T - 1; ++t) {
+        const double *m = mu + (size_t)t * d, *S = Sig + (size_t)t * dd, *C = Sub + (size_t)t * dd, *mn = mu + (size_t)(t + 1) * d,
+                     *Sn = Sig + (size_t)(t + 1) * dd;
+        for (int i = 0; i < d; ++i) {
+            const double al = alpha[i], be = beta[i], mi = m[i], v = S[IDX(i, i, d)], m2 = mi * mi, a = m2 + v;
+            ubar[i] = al * mi - be * mi * (m2 + 3 * v);
+            J[i] = al - 3 * be * a;
+            V[i] = al * al * v - 6 * al * be * v * a + be * be * v * (9 * m2 * m2 + 36 * m2 * v + 15 * v * v);
+            ub_v[i] = -3 * be * mi; J_m[i] = -6 * be * mi; J_v[i] = -3 * be;
+            V_m[i] = -12 * al * be * mi * v + be * be * mi * v * (36 * m2 + 72 * v);
+            V_v[i] = al * al - 6 * al * be * (m2 + 2 * v) + be * be * (9 * m2 * m2 + 72 * m2 * v + 45 * v * v);
+        }
+        inv_spd(S, Sinv, &ld, d, tmp);
+        gemm_d(1.0, C, 0, Sinv, 0, 0.0, A, d);                 /* A = C S^{-1} */
+        gemm_d(-1.0, A, 0, C, 1, 0.0, Qq, d);                  /* -A C^T */
+        for (int i = 0; i < dd; ++i) Qq[i] += Sn[i];
+        double ldQ;
+        inv_spd(Qq, P, &ldQ, d, tmp);
+        double val = -ldQ + logdetQp - d;
+        for (int i = 0; i < d; ++i) {
+            double e = ubar[i] - mn[i];
+            We[i] = W[i] * e;
+            kv[i] = W[i] * C[IDX(i, i, d)];
+            val += W[i] * V[i] - 2.0 * J[i] * kv[i] + W[i] * Sn[IDX(i, i, d)] + We[i] * e;
+        }
+        kl += 0.5 * val;
+        if (want_grads) {
+            gemm_d(1.0, P, 0, A, 0, 0.0, PA, d);
+            gemm_d(1.0, A, 1, PA, 0, 0.0, AtPA, d);
+            double* GC = gs + (size_t)t * dd;
+            for (int i = 0; i < dd; ++i) GC[i] = PA[i];
+            for (int i = 0; i < d; ++i) GC[IDX(i, i, d)] -= W[i] * J[i];
+            double* GS = gd + (size_t)t * dd;
+            double* GSn = gd + (size_t)(t + 1) * dd;
+            for (int i = 0; i < dd; ++i) { GS[i] += -0.5 * AtPA[i]; GSn[i] += -0.5 * P[i]; }
+            for (int i = 0; i < d; ++i) {
+                GS[IDX(i, i, d)] += 0.5 * W[i] * V_v[i] - kv[i] * J_v[i] + We[i] * ub_v[i];
+                GSn[IDX(i, i, d)] += 0.5 * W[i];
+                Gm[(size_t)t * d + i] += 0.5 * W[i] * V_m[i] - kv[i] * J_m[i] + We[i] * J[i];
+                Gm[(size_t)(t + 1) * d + i] += -We[i];
+            }
+        }
+    }
+    if (want_grads) {
+        for (int t = 0; t < T; ++t)
+            for (int i = 0; i < d; ++i) {
+                double v = Gm[(size_t)t * d + i];
+                for (int j = 0; j < d; ++j) v -= 2.0 * gd[(size_t)t * dd + IDX(i, j, d)] * mu[(size_t)t * d + j];
+                if (t < T - 1)
+                    for (int j = 0; j < d; ++j) v -= gs[(size_t)t * dd + IDX(j, i, d)] * mu[(size_t)(t + 1) * d + j];
+                if (t > 0)
+                    for (int j = 0; j < d; ++j) v -= gs[(size_t)(t - 1) * dd + IDX(i, j, d)] * mu[(size_t)(t - 1) * d + j];
+                g1[(size_t)t * d + i] = v;
+            }
+        free(Gm);
+    }
+    free(buf);
+    return kl;
+}
+
+/*
+ * One CVISitesSDE (CVI-DP) iteration for B chains under a fixed linearised prior (naturals p1, pd, ps):
+ *   update_data_sites(lr_d); update_girsanov_sites(lr_g); classic_elbo()      (cvi_dp_trainer.py:72-75)
+ * Gaussian likelihood with precision Rinv.  State updated in place as in ref_cvi_step.
+ */
+size_t ref_cvi_dp_step_work_doubles(int T, int d) { return (size_t)T * (10 * d * d + 6 * d) + 16 * d * d; }
+
+double ref_cvi_dp_step(int B, int T, int d, int n, const int* idx, const double* y, const double* Rinv, double logdetR,
+                       const double* p1, const double* pd, const double* ps, const double* alpha, const double* beta,
+                       const double* qdiag, double dt, const double* init_mu, const double* init_cov, double* g1, double* g2d,
+                       double* g2s, double* d1, double* d2, double lr_d, double lr_g, double* work, double* elbo_out) {
+    const int dd = d * d;
+    const size_t W = ref_cvi_dp_step_work_doubles(T, d);
+    double total = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+    for (int b = 0; b < B; ++b) {
+        double* w = work + (size_t)b * W;
+        double* q1 = w; w += (size_t)T * d;
+        double* qd = w; w += (size_t)T * dd;
+        double* qs = w; w += (size_t)T * dd;
+        double* Ld = w; w += (size_t)T * dd;
+        double* Ls = w; w += (size_t)T * dd;
+        double* Sd = w; w += (size_t)T * dd;
+        double* Ss = w; w += (size_t)T * dd;
+        double* yv = w; w += (size_t)T * d;
+        double* mu = w; w += (size_t)T * d;
+        double* Pd = w; w += (size_t)T * dd;
+        double* k1 = w; w += (size_t)T * d;
+        double* kd = w; w += (size_t)T * dd;
+        double* ks = w; w += (size_t)T * dd;
+        const double* P1 = p1 + (size_t)b * T * d; const double* PD = pd + (size_t)b * T * dd; const double* PS = ps + (size_t)b * (T - 1) * dd;
+        double* G1 = g1 + (size_t)b * T * d; double* G2D = g2d + (size_t)b * T * dd; double* G2S = g2s + (size_t)b * (T - 1) * dd;
+        double* D1 = d1 + (size_t)b * n * d; double* D2 = d2 + (size_t)b * n * dd;
+        const double* Y = y + (size_t)b * n * d;
+        for (int i = 0; i < n; ++i)
+            for (int r = 0; r < d; ++r) {
+                double t = 0.0;
+                for (int c = 0; c < d; ++c) t += Rinv[IDX(r, c, d)] * Y[(size_t)i * d + c];
+                D1[(size_t)i * d + r] = (1 - lr_d) * D1[(size_t)i * d + r] + lr_d * t;
+                for (int c = 0; c < d; ++c)
+                    D2[(size_t)i * dd + IDX(r, c, d)] = (1 - lr_d) * D2[(size_t)i * dd + IDX(r, c, d)] - 0.5 * lr_d * Rinv[IDX(r, c, d)];
+            }
+        for (int pass = 0; pass < 2; ++pass) {
+            for (size_t i = 0; i < (size_t)T * d; ++i) q1[i] = P1[i] + G1[i];
+            for (size_t i = 0; i < (size_t)T * dd; ++i) qd[i] = PD[i] + G2D[i];
+            for (size_t i = 0; i < (size_t)(T - 1) * dd; ++i) qs[i] = PS[i] + G2S[i];
+            for (int i = 0; i < n; ++i) {
+                for (int r = 0; r < d; ++r) q1[(size_t)idx[i] * d + r] += D1[(size_t)i * d + r];
+                for (int r = 0; r < dd; ++r) qd[(size_t)idx[i] * dd + r] += D2[(size_t)i * dd + r];
+            }
+            for (size_t i = 0; i < (size_t)T * dd; ++i) Pd[i] = -2.0 * qd[i];
+            for (size_t i = 0; i < (size_t)(T - 1) * dd; ++i) qs[i] = -qs[i];
+            ref_btd_cholesky(Pd, qs, Ld, Ls, T, d);
+            ref_btd_solve(Ld, Ls, q1, yv, T, d, 0);
+            ref_btd_solve(Ld, Ls, yv, mu, T, d, 1);
+            ref_btd_inverse_blocks(Ld, Ls, Sd, Ss, T, d);
+            if (pass == 0) {
+                /* update_girsanov_sites at the refreshed posterior */
+                ref_sde_kl(mu, Sd, Ss, alpha, beta, qdiag, dt, init_mu, init_cov, T, d, 1, k1, kd, ks);
+                for (size_t i = 0; i < (size_t)T * d; ++i) G1[i] -= lr_g * k1[i];
+                for (size_t i = 0; i < (size_t)T * dd; ++i) G2D[i] -= lr_g * kd[i];
+                for (size_t i = 0; i < (size_t)(T - 1) * dd; ++i) G2S[i] -= lr_g * ks[i];
+                for (int i = 0; i < n; ++i) {
+                    for (int r = 0; r < d; ++r) G1[(size_t)idx[i] * d + r] += lr_g * D1[(size_t)i * d + r];
+                    for (int r = 0; r < dd; ++r) G2D[(size_t)idx[i] * dd + r] += lr_g * D2[(size_t)i * dd + r];
+                }
+            }
+        }
+        double ve = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double* m = mu + (size_t)idx[i] * d;
+            const double* S = Sd + (size_t)idx[i] * dd;
+            double quad = 0.0, trc = 0.0;
+            for (int r = 0; r < d; ++r)
+                for (int c = 0; c < d; ++c) {
+                    quad += (Y[(size_t)i * d + r] - m[r]) * Rinv[IDX(r, c, d)] * (Y[(size_t)i * d + c] - m[c]);
+                    trc += Rinv[IDX(r, c, d)] * S[IDX(r, c, d)];
+                }
+            ve += -0.5 * trc - 0.5 * quad - 0.5 * logdetR - 0.5 * d * log(2.0 * M_PI);
+        }
+        double kl = ref_sde_kl(mu, Sd, Ss, alpha, beta, qdiag, dt, init_mu, init_cov, T, d, 0, NULL, NULL, NULL);
+        elbo_out[b] = ve - kl;
+        total += ve - kl;
+    }
+    return total;
+}
+
 int ref_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

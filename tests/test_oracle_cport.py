@@ -58,3 +58,43 @@ def test_c_cvi_step(rng):
             ref.append(m.classic_elbo())
         np.testing.assert_allclose(st.elbo, ref, rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(total, np.sum(ref), rtol=1e-8)
+
+
+def test_c_sde_kl(rng):
+    from oracle import np_sde
+    T, d, dt = 9, 2, 0.05
+    q = np_ssm.StateSpaceModel(*random_ssm_params(rng, (), T, d, scale_A=0.8))
+    mu, cov = q.marginals
+    sub = q.subsequent_covariances(cov)
+    qd = 0.5 + rng.random(d)
+    init_mu, init_cov = 0.1 * rng.normal(size=d), 0.7 * np.eye(d) + 0.1
+    kl, grads = c_ref.sde_kl(mu, cov, sub, 1.2, 0.2, qd, dt, init_mu, init_cov)
+    okl, ograds = np_sde.sde_ssm_kl_closed_form(mu, cov, sub, 1.2, 0.2, qd, dt, init_mu, init_cov)
+    np.testing.assert_allclose(kl, okl, rtol=1e-12)
+    for a, b in zip(grads, ograds):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10)
+
+
+def test_c_cvi_dp_step(rng):
+    from oracle import np_sde
+    B, T, d, n, dt = 2, 40, 2, 5, 0.02
+    sde = np_sde.DoubleWellSDE(np.eye(d))
+    grid = np.arange(T) * dt
+    idx = np.sort(rng.choice(np.arange(1, T), size=n, replace=False))
+    y = np.sign(rng.normal(size=(B, n, d))) + 0.2 * rng.normal(size=(B, n, d))
+    cholR = 0.3 * np.eye(d)
+    init = (np.zeros(d), 0.5 * np.eye(d))
+    models = [np_models.CVISitesSDE(sde, grid, idx, y[b], np_models.MultivariateGaussianLik(cholR), *init) for b in range(B)]
+    nats = [np_transforms.ssm_to_naturals(m.dist_p) for m in models]
+    al, be = sde.cubic(dt)
+    st = c_ref.CviDpStepState(np.stack([n_[0] for n_ in nats]), np.stack([n_[1] for n_ in nats]), np.stack([n_[2] for n_ in nats]),
+                              idx, y, np.linalg.inv(cholR @ cholR.T), 2 * np.sum(np.log(np.diag(cholR))), al, be, np.ones(d), dt, *init)
+    for lr_d, lr_g in ((0.5, 0.2), (0.3, 0.1)):
+        total = st.step(lr_d, lr_g)
+        ref = []
+        for m in models:
+            m.update_data_sites(lr_d)
+            m.update_girsanov_sites(lr_g)
+            ref.append(m.classic_elbo())
+        np.testing.assert_allclose(st.elbo, ref, rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(total, np.sum(ref), rtol=1e-7)
