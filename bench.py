@@ -95,19 +95,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import vidp_amd
+    from vidp_amd import distributed as vdist
+    rank, world = vdist.init_from_env(backend="nccl")      # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
 
-    import vidp_amd
     from vidp_amd.likelihoods import MultivariateGaussian
     from vidp_amd.sde import DoubleWellSDE
     from vidp_amd.variational_cvi_sde import CVISitesSDE
@@ -130,9 +127,7 @@ def main():
         e_traj = model.classic_elbo_per_trajectory()
         if not first_elbo:
             first_elbo.append(e_traj.clone())
-        e = e_traj.sum()
-        if dist is not None:
-            dist.all_reduce(e)
+        e = vdist.allreduce_sum_(e_traj.sum())           # the only collective: scalar ELBO sum over ranks
         elbos.append(e)
 
     def fence():
@@ -149,10 +144,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = float(vdist.allreduce_max_(torch.tensor([elapsed], dtype=torch.float64, device=device)).item())
     plan.check_info()
     elbo_vals = [float(e.item()) for e in elbos]
     assert all(np.isfinite(elbo_vals)), "non-finite ELBO"

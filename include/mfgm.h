@@ -40,7 +40,7 @@ typedef struct mfgm_plan mfgm_plan;
 #define MFGM_TRI 3  /* [d, d] lower-triangular: upper triangle written as zero       */
 
 /* Partition plan for B chains of T nodes with d x d blocks.  R0 = nodes per lane segment at the finest
- * level (0 = choose so that about 64 Ki lanes exist), Rup = segment length of the coarser levels (0 = 32).
+ * level (0 = choose so that about 64 Ki lanes exist), Rup = segment length of the coarser levels (0 = 8).
  * Supported d: 1..8. */
 int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out);
 void mfgm_plan_destroy(mfgm_plan* plan);
@@ -82,10 +82,10 @@ int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, con
 
 /* Sparse node lists (observation times on the grid): node_ids[i] = b*T + t (int64, device), values natural
  * [n, d] / [n, d, d].  mode 0: gather packed -> values; 1: scatter values -> packed (overwrite);
- * 2: packed += values.  Replaces tf.scatter_nd / tf.gather_nd at variational_cvi_sde.py:167-172, 303-304 and
- * kalman_filter.py:577. */
-int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, const long long* node_ids, int n, double* values,
-                 int mode, void* stream);
+ * 2: packed += scale*values, and packed2 += scale*values when packed2 != NULL.  Replaces tf.scatter_nd / tf.gather_nd at
+ * variational_cvi_sde.py:167-172, 303-304 and kalman_filter.py:577. */
+int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed2, const long long* node_ids, int n,
+                 double* values, int mode, double scale, void* stream);
 
 /* SSM parameters -> natural parameters (cD=-0.5, cS=1; ssm_gaussian_transformations.py:182-253 `ssm_to_naturals`)
  * or precision blocks (cD=1, cS=-1; state_space_model.py:431-483 `_build_precision`), all packed:

@@ -30,8 +30,8 @@ EXPORTS = {
     "mfgm_packed_selinv": (ctypes.c_int, [ctypes.c_void_p] * 9),
     "mfgm_lincomb": (ctypes.c_int, [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
-    "mfgm_node_io": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "mfgm_node_io": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "mfgm_packed_ssm_to_naturals": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),
     "mfgm_packed_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
                                  + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 6),

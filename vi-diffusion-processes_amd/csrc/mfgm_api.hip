@@ -192,7 +192,7 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
     Plan& P = h->p;
     memset(&P, 0, sizeof(P));
     P.B = B; P.T = T; P.d = d;
-    if (Rup <= 1) Rup = 32;
+    if (Rup <= 1) Rup = 8;   // measured best on MI355X for the coarse levels (tools/sweep_partition.sh)
     if (const char* e = getenv("MFGM_RUP")) { int v = atoi(e); if (v > 1) Rup = v; }
     if (R0 <= 0) {
         if (const char* e = getenv("MFGM_R0")) R0 = atoi(e);
@@ -293,16 +293,17 @@ int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, con
     return 0;
 }
 
-int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, const long long* node_ids, int n, double* values, int mode,
-                 void* stream) {
+int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed2, const long long* node_ids, int n,
+                 double* values, int mode, double scale, void* stream) {
     if (!plan || !packed || kind < 0 || kind > 3 || mode < 0 || mode > 2 || n < 0) return 1;
     if (n == 0) return 0;
     if (!node_ids || !values) return 1;
     const Plan& P = plan->p;
     const size_t total = (size_t)n * kind_enat(kind, P.d);
+    if (total >= (1ull << 32)) return 1;
     int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.lv[0], P.T, P.d, kind, packed, node_ids,
-                       n, values, mode);
+    hipLaunchKernelGGL(k_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.lv[0], P.T, P.d, kind, packed, packed2,
+                       node_ids, n, values, mode, scale);
     MFGM_CHECK_LAUNCH();
     return 0;
 }

@@ -39,21 +39,22 @@ __global__ __launch_bounds__(256) void k_lincomb(size_t n, double* out, double a
 
 // ---- gather / scatter of a sparse list of nodes (observation times) --------------------------------------
 // node_ids[i] = b*T + t.  values: natural [n, E_nat].  mode 0: packed -> values, 1: values -> packed (set),
-// 2: packed += values.  SYM scatters read the lower triangle of the natural block.
-__global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int kind, double* packed,
-                                                const long long* __restrict__ node_ids, int n, double* values, int mode) {
-    const int En = (kind == 0) ? d : d * d;
-    const size_t total = (size_t)n * En;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(idx / En), ne = (int)(idx - (size_t)i * En);
+// 2: packed += scale*values (and packed2 += scale*values when given).  SYM scatters read the lower triangle.
+__global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int kind, double* packed, double* packed2,
+                                                const long long* __restrict__ node_ids, int n, double* values, int mode,
+                                                double scale) {
+    const unsigned En = (kind == 0) ? d : d * d;
+    const unsigned total = (unsigned)n * En;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned i = idx / En, ne = idx - i * En;
         const long long id = node_ids[i];
-        const int b = (int)(id / T), t = (int)(id - (long long)b * T);
-        const int p = t / lv.R, s = t - p * lv.R, lane = b * lv.P + p;
-        int Ep = En, e = ne;
+        const unsigned b = (unsigned)(id / T), t = (unsigned)(id - (long long)b * T);
+        const unsigned p = t / lv.R, s = t - p * lv.R, lane = b * lv.P + p;
+        unsigned Ep = En, e = ne;
         bool skip = false, zero = false;
         if (kind >= 2) {
             Ep = d * (d + 1) / 2;
-            const int r = ne / d, c = ne - r * d;
+            const unsigned r = ne / d, c = ne - r * d;
             if (mode == 0) {
                 if (kind == 3 && c > r) zero = true;
                 e = six(r, c);
@@ -63,10 +64,14 @@ __global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int
             }
         }
         if (skip) continue;
-        double* pp = packed + (((size_t)(lane >> 6) * lv.R + s) * Ep + e) * 64 + (lane & 63);
-        if (mode == 0) values[idx] = zero ? 0.0 : *pp;
-        else if (mode == 1) *pp = values[idx];
-        else *pp += values[idx];
+        const size_t off = (((size_t)(lane >> 6) * lv.R + s) * Ep + e) * 64 + (lane & 63);
+        if (mode == 0) values[idx] = zero ? 0.0 : packed[off];
+        else if (mode == 1) packed[off] = values[idx];
+        else {
+            const double v = scale * values[idx];
+            packed[off] += v;
+            if (packed2) packed2[off] += v;
+        }
     }
 }
 

@@ -117,15 +117,18 @@ class Plan:
         n = node_ids.numel()
         shape = (n, self.d) if kind == VEC else (n, self.d, self.d)
         out = torch.empty(shape, dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.mfgm_node_io(self.h, kind, _ptr(packed), _ptr(node_ids), n, _ptr(out), 0, _stream()),
+        _lib.check(self.lib.mfgm_node_io(self.h, kind, _ptr(packed), None, _ptr(node_ids), n, _ptr(out), 0, 1.0, _stream()),
                    "mfgm_node_io(gather)")
         return out
 
-    def scatter_nodes(self, kind, packed, node_ids, values, accumulate=False):
+    def scatter_nodes(self, kind, packed, node_ids, values, accumulate=False, scale=1.0, packed2=None):
+        """packed (+= | =) scale * values at the listed nodes; with `packed2` the same increment goes to a second array."""
         values = values.contiguous()
         n = node_ids.numel()
-        _lib.check(self.lib.mfgm_node_io(self.h, kind, _ptr(packed), _ptr(node_ids), n, _ptr(values),
-                                         2 if accumulate else 1, _stream()), "mfgm_node_io(scatter)")
+        if not accumulate:
+            assert scale == 1.0 and packed2 is None
+        _lib.check(self.lib.mfgm_node_io(self.h, kind, _ptr(packed), _ptr(packed2), _ptr(node_ids), n, _ptr(values),
+                                         2 if accumulate else 1, float(scale), _stream()), "mfgm_node_io(scatter)")
         return packed
 
     def ssm_to_naturals(self, A, off, chol, precision=False, want_logdet=False, out=None):

@@ -149,6 +149,7 @@ class CVISitesSSM:
         q = self._refresh()
         self.fx_mus_obs = self.plan.gather_nodes(VEC, q["mu"], self.obs_node_ids)
         self.fx_covs_obs = self.plan.gather_nodes(SYM, q["Sig"], self.obs_node_ids)
+        self._obs_fresh = True
 
     @property
     def fx_mus(self):
@@ -194,19 +195,16 @@ class CVISitesSSM:
             pl.lincomb(gg, 1.0, gg, -lr, qq, lr, pp)          # g += lr (theta_p - theta_q)
             pl.lincomb(qq, 1.0 - lr, qq, lr, pp)               # theta_q += lr (theta_p - theta_q)
         for kind, gg, qq, val in ((VEC, g.lin, tq.lin, self.data_nat1), (SYM, g.diag, tq.diag, self.data_nat2)):
-            v = lr * val
-            pl.scatter_nodes(kind, gg, self.obs_node_ids, v, accumulate=True)
-            pl.scatter_nodes(kind, qq, self.obs_node_ids, v, accumulate=True)
+            pl.scatter_nodes(kind, gg, self.obs_node_ids, val, accumulate=True, scale=lr, packed2=qq)
         self._q = None
         self._gather_obs()
 
     # -- objective -----------------------------------------------------------------------------------------
     def variational_expectation(self):
         """sum_i E_q log p(y_i | x_i), per trajectory [B] (variational_cvi_sde.py:319-337)."""
-        self._refresh()
-        mu = self.plan.gather_nodes(VEC, self._q["mu"], self.obs_node_ids)
-        cov = self.plan.gather_nodes(SYM, self._q["Sig"], self.obs_node_ids)
-        ve = self.likelihood.variational_expectations(mu, cov, self._obs_flat())
+        if self._q is None or not getattr(self, "_obs_fresh", False):
+            self._gather_obs()
+        ve = self.likelihood.variational_expectations(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
         return ve.reshape(self.B, self.n_obs).sum(-1)
 
     def KL_q_p(self):
@@ -310,9 +308,7 @@ class CVISitesSDE(CVISitesSSM):
         pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=2, grads=(g.lin, g.diag, g.sub),
                   theta_q=(tq.lin, tq.diag, tq.sub), want_kl=False)
         for kind, gg, qq, val in ((VEC, g.lin, tq.lin, self.data_nat1), (SYM, g.diag, tq.diag, self.data_nat2)):
-            v = lr * val
-            pl.scatter_nodes(kind, gg, self.obs_node_ids, v, accumulate=True)
-            pl.scatter_nodes(kind, qq, self.obs_node_ids, v, accumulate=True)
+            pl.scatter_nodes(kind, gg, self.obs_node_ids, val, accumulate=True, scale=lr, packed2=qq)
         self._q = None
         self._gather_obs()
 
