@@ -137,6 +137,26 @@ int mfgm_packed_sde_kl(const mfgm_plan* plan, int mode, const mfgm_sde_params* p
 int mfgm_packed_linearize_cubic(const mfgm_plan* plan, const mfgm_sde_params* prm, const double* mu, const double* Sig,
                                 double* A, double* off, double* chol, void* stream);
 
+/* A sum of up to 8 stationary SDE-kernel components (state dims add up to d <= 8): order 1 = Matern-1/2 or
+ * Ornstein-Uhlenbeck (lam = 1/lengthscale or decay; var = variance or diffusion/(2 decay)), order 2 = Matern-3/2
+ * (lam = sqrt(3)/l), order 3 = Matern-5/2 (lam = sqrt(5)/l).  kernels/matern.py:27-520, kernels/sde_kernel.py:540-687. */
+typedef struct mfgm_kernel_spec {
+    int ncomp;
+    int order[8];
+    int offset[8];
+    double lam[8];
+    double var[8];
+    double mean[8];
+    double jitter;
+} mfgm_kernel_spec;
+
+/* Kernel -> packed SSM parameters on a time grid: A_k = expm(F dt_k), Q_k = Pinf - A_k Pinf A_k^T + jitter (Cholesky
+ * factored, zero matrices kept zero), b_k = (I - A_k) m  (SDEKernel.state_space_model, kernels/sde_kernel.py:153-171;
+ * StationaryKernel.transition_statistics :421-446; state_space_model_from_covariances, state_space_model.py:613-664).
+ * time_deltas: natural [B, T-1] device array.  Outputs packed A (FULL), off (VEC), chol (TRI). */
+int mfgm_packed_stationary_ssm(const mfgm_plan* plan, const mfgm_kernel_spec* spec, const double* time_deltas, double* A,
+                               double* off, double* chol, int* info, void* stream);
+
 /* Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 =
  * finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call with the
  * same arguments; outputs are overwritten with identical values.  Used by bench.py to time the dominant kernel alone. */

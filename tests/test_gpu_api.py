@@ -231,3 +231,87 @@ def test_cvi_sites_sde(amd, rng, d, kind, B, T):
             np.testing.assert_allclose(e[b], o.classic_elbo(), rtol=1e-6, atol=1e-6)
         assert_close(host(g.dist_p.state_transitions)[B - 1], os_[B - 1].dist_p.A)
         assert_close(host(g.dist_p.state_offsets)[B - 1], os_[B - 1].dist_p.b)
+
+
+@pytest.mark.parametrize("name", ["m12", "ou", "m32", "m52", "sum"])
+def test_kernels_state_space_model(amd, rng, name, batch_shape):
+    """Kernel -> SSM against the oracle kernels (pinned to the reference's expm test objects, KA6)."""
+    from oracle import np_kernels
+    from vidp_amd import kernels as K
+    mk = {"m12": (lambda m: m.Matern12(0.7, 1.3)), "ou": (lambda m: m.OrnsteinUhlenbeck(1.4, 0.9)),
+          "m32": (lambda m: m.Matern32(2.1, 0.4)), "m52": (lambda m: m.Matern52(0.6, 1.7)),
+          "sum": (lambda m: m.Sum([m.Matern52(0.5, 1.0), m.Matern32(1.5, 0.3), m.Matern12(0.8, 2.0)], jitter=1e-9))}[name]
+    gk, ok = mk(K), mk(np_kernels)
+    t = np.cumsum(rng.exponential(0.2, size=batch_shape + (23,)), axis=-1)
+    g, o = gk.state_space_model(dev(t)), ok.state_space_model(t)
+    assert_close(host(g.state_transitions), o.A)
+    assert_close(host(g.state_offsets), o.b)
+    # Q = Pinf - A Pinf A^T cancels ~7 digits at small time steps: compare Q itself tightly, its Cholesky factor loosely
+    gc = host(g.cholesky_process_covariances)
+    assert_close(gc @ np.swapaxes(gc, -1, -2), o.cholQ @ np.swapaxes(o.cholQ, -1, -2), rtol=1e-6)
+    assert_close(gc, o.cholQ, rtol=1e-4, scale_atol=1e-6)
+    assert_close(host(g.cholesky_initial_covariance), o.cholP0)
+    assert_close(host(g.initial_mean), o.mu0)
+    np.testing.assert_allclose(gk.steady_state_covariance.numpy(), ok.steady_state_covariance(), rtol=1e-12)
+    np.testing.assert_allclose(gk.feedback_matrix.numpy(), ok.feedback_matrix(), rtol=1e-12)
+    H = host(gk.generate_emission_model(dev(t)).emission_matrix)
+    np.testing.assert_allclose(H, ok.emission_matrix(t))
+
+
+def _gpu_ssm_from_golden(g, bs, T):
+    from vidp_amd.state_space_model import StateSpaceModel
+    d = g["A"].shape[-1]
+    bc = lambda a, shp: dev(np.broadcast_to(a, shp).copy())
+    return StateSpaceModel(bc(g["mu0"], bs + (d,)), bc(g["cholP0"], bs + (d, d)), bc(g["A"], bs + (T - 1, d, d)),
+                           bc(g["b"], bs + (T - 1, d)), bc(g["cholQ"], bs + (T - 1, d, d)))
+
+
+@pytest.mark.parametrize("tag,bs", [("b0", ()), ("b3", (3,)), ("b21", (2, 1))])
+def test_kalman_filter_golden(amd, tag, bs):
+    """KA2: the reference's tests/integration/test_kalman_filter.py against ITS NumPy filter + RTS smoother (golden vectors)."""
+    from tests.conftest import golden
+    from vidp_amd.emission_model import EmissionModel
+    from vidp_amd.kalman_filter import KalmanFilter
+    g = golden(f"kalman_filter_{tag}.npz")
+    T = g["y"].shape[-2]
+    ssm = _gpu_ssm_from_golden(g, bs, T)
+    H = dev(np.broadcast_to(g["H"], bs + (T,) + g["H"].shape).copy())
+    kf = KalmanFilter(ssm, EmissionModel(H), dev(g["y"]), dev(np.linalg.cholesky(g["R"])))
+    np.testing.assert_allclose(float(kf.log_likelihood()), g["log_lik_total"], rtol=1e-7)
+    post = kf.posterior_state_space_model()
+    assert_close(host(post.marginal_means), g["smooth_means"])
+    assert_close(host(post.marginal_covariances), np.broadcast_to(g["smooth_covs"], bs + g["smooth_covs"].shape))
+
+
+def test_kalman_filter_sites_golden(amd):
+    """KA3: per-step Gaussian sites (tests/integration/test_kalman_filter_with_sites.py fixture)."""
+    from tests.conftest import golden
+    from vidp_amd.emission_model import EmissionModel
+    from vidp_amd.kalman_filter import GaussianSitesNat, KalmanFilterWithSites
+    g = golden("kalman_filter_sites.npz")
+    T = g["site_means"].shape[0]
+    ssm = _gpu_ssm_from_golden(g, (), T)
+    H = dev(np.broadcast_to(g["H"], (T,) + g["H"].shape).copy())
+    sites = GaussianSitesNat(dev(g["site_means"] / g["site_covs"][..., 0]), dev(-0.5 / g["site_covs"]))
+    kf = KalmanFilterWithSites(ssm, EmissionModel(H), sites)
+    np.testing.assert_allclose(float(kf.log_likelihood()), g["log_lik_total"], rtol=1e-7)
+    post = kf.posterior_state_space_model()
+    assert_close(host(post.marginal_means), g["smooth_means"])
+    assert_close(host(post.marginal_covariances), g["smooth_covs"])
+
+
+def test_kalman_filter_sparse_sites(amd, rng):
+    """Sparse-site filter == oracle (kalman_filter.py:504-639; reference test_kalman_filter_with_sparse_sites.py)."""
+    from oracle import np_kalman, np_kernels
+    from vidp_amd import kernels as K
+    from vidp_amd.kalman_filter import GaussianSitesNat, KalmanFilterWithSparseSites
+    T = 40
+    t = np.linspace(0.0, 4.0, T)
+    idx = np.sort(rng.choice(T, size=9, replace=False))
+    y = rng.normal(size=(9, 1))
+    nat1, nat2 = y / 0.3, -0.5 / 0.3 * np.ones((9, 1, 1))
+    ok, gk = np_kernels.Matern32(0.9, 1.2), K.Matern32(0.9, 1.2)
+    okf = np_kalman.KalmanFilterWithSparseSites(ok.state_space_model(t), ok.emission_matrix(t), np_kalman.GaussianSitesNat(nat1, nat2), T, idx, y)
+    gkf = KalmanFilterWithSparseSites(gk.state_space_model(dev(t)), gk.generate_emission_model(dev(t)),
+                                      GaussianSitesNat(dev(nat1), dev(nat2)), T, dev(idx), dev(y))
+    np.testing.assert_allclose(float(gkf.log_likelihood()), okf.log_likelihood(), rtol=1e-8)

@@ -38,6 +38,7 @@ EXPORTS = {
     "mfgm_packed_selinv_level": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8),
     "mfgm_packed_sde_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 14),
     "mfgm_packed_linearize_cubic": (ctypes.c_int, [ctypes.c_void_p] * 8),
+    "mfgm_packed_stationary_ssm": (ctypes.c_int, [ctypes.c_void_p] * 8),
     "mfgm_packed_kl_terms": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
 }
 
@@ -48,6 +49,12 @@ class SdeParams(ctypes.Structure):
                 ("P0inv", ctypes.c_double * 36), ("mu0", ctypes.c_double * 8), ("logdetQp", ctypes.c_double),
                 ("logdetP0", ctypes.c_double), ("lr", ctypes.c_double), ("clip_lo", ctypes.c_double),
                 ("clip_hi", ctypes.c_double), ("sq_dtq", ctypes.c_double * 8), ("cholP0", ctypes.c_double * 36)]
+
+
+class KernelSpec(ctypes.Structure):
+    """mfgm_kernel_spec (include/mfgm.h)."""
+    _fields_ = [("ncomp", ctypes.c_int), ("order", ctypes.c_int * 8), ("offset", ctypes.c_int * 8), ("lam", ctypes.c_double * 8),
+                ("var", ctypes.c_double * 8), ("mean", ctypes.c_double * 8), ("jitter", ctypes.c_double)]
 
 
 class MfgmError(RuntimeError):

@@ -481,3 +481,34 @@ int mfgm_packed_linearize_cubic(const mfgm_plan* plan, const mfgm_sde_params* pr
 }
 
 }  // extern "C"
+
+static_assert(sizeof(mfgm_kernel_spec) == sizeof(mfgm::KernelSpec), "public and internal kernel spec structs must match");
+
+namespace {
+template <int D>
+int stationary_impl(const Plan& P, const KernelSpec& ks, const double* dts, double* A, double* off, double* chol, int* info,
+                    hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    hipLaunchKernelGGL((k_stationary_ssm<D>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, ks, dts, A, off, chol, info);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" int mfgm_packed_stationary_ssm(const mfgm_plan* plan, const mfgm_kernel_spec* spec, const double* time_deltas,
+                                          double* A, double* off, double* chol, int* info, void* stream) {
+    if (!plan || !spec || !A || !off || !chol || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !time_deltas) return 1;
+    KernelSpec ks;
+    memcpy(&ks, spec, sizeof(ks));
+    if (ks.ncomp < 1 || ks.ncomp > 8) return 1;
+    int dim = 0;
+    for (int c = 0; c < ks.ncomp; ++c) {
+        if (ks.order[c] < 1 || ks.order[c] > 3 || ks.offset[c] != dim) return 1;
+        dim += ks.order[c];
+    }
+    if (dim != P.d) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (stationary_impl<DD>(P, ks, time_deltas, A, off, chol, info, st)));
+}

@@ -255,3 +255,159 @@ __global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __r
 }
 
 }  // namespace mfgm
+
+namespace mfgm {
+
+// ---- stationary SDE kernels -> packed SSM parameters ---------------------------------------------------------
+// A sum of up to 8 stationary components (Matern-1/2, -3/2, -5/2, Ornstein-Uhlenbeck), block-diagonal state.
+// Per transition (time step dt):  A = exp(-lam dt) (I + N dt + N^2 dt^2 / 2),  N = F + lam I nilpotent,
+//   Q = Pinf - A Pinf A^T + jitter I,  b = (I - A) m,  chol(Q) ("cholesky_or_zero": exactly-zero Q stays zero)
+// restating StationaryKernel.transition_statistics / state_offsets (kernels/sde_kernel.py:421-475),
+// Matern12/32/52.state_transitions + steady_state_covariance (kernels/matern.py:66-86, 299-324, 434-501),
+// Sum / ConcatKernel block-diagonal stacking (sde_kernel.py:592-656) and state_space_model_from_covariances
+// (state_space_model.py:613-664).  Node 0 carries (initial mean, chol(Pinf + jitter)).
+struct KernelSpec {
+    int ncomp;
+    int order[8];        // state dimension of the component: 1, 2 or 3
+    int offset[8];       // first state index of the component
+    double lam[8];       // decay rate lambda
+    double var[8];       // variance sigma^2 (Pinf scale)
+    double mean[8];      // state mean m (total dim <= 8)
+    double jitter;
+};
+
+template <int D>
+MFGM_DEV void stationary_pinf(const KernelSpec& ks, double (&Pinf)[D * D]) {
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) Pinf[e] = 0.0;
+    for (int c = 0; c < ks.ncomp; ++c) {
+        const int o = ks.offset[c];
+        const double l = ks.lam[c], v = ks.var[c];
+        if (ks.order[c] == 1) {
+            Pinf[o * D + o] = v;
+        } else if (ks.order[c] == 2) {
+            Pinf[o * D + o] = v;
+            Pinf[(o + 1) * D + o + 1] = v * l * l;
+        } else {
+            const double l23 = l * l / 3.0;
+            Pinf[o * D + o] = v;
+            Pinf[o * D + o + 2] = -v * l23;
+            Pinf[(o + 2) * D + o] = -v * l23;
+            Pinf[(o + 1) * D + o + 1] = v * l23;
+            Pinf[(o + 2) * D + o + 2] = v * l * l * l * l;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_stationary_ssm(LevelDesc lv, KernelSpec ks, const double* __restrict__ dts /* natural [B, n-1] */,
+                                                      double* __restrict__ Ag, double* __restrict__ offg,
+                                                      double* __restrict__ cholg, int* info) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    int bad = 0;
+    double Pinf[EF];
+    stationary_pinf<D>(ks, Pinf);
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            const int t = p * R + s;
+            // --- this node's incoming process noise / offset: transition t-1 -> t (or the initial state) ---
+            double A[EF];
+            auto build_A = [&](double dt) {
+#pragma unroll
+                for (int e = 0; e < EF; ++e) A[e] = 0.0;
+                for (int c = 0; c < ks.ncomp; ++c) {
+                    const int o = ks.offset[c];
+                    const double l = ks.lam[c], ex = exp(-l * dt);
+                    if (ks.order[c] == 1) {
+                        A[o * D + o] = ex;
+                    } else if (ks.order[c] == 2) {
+                        // N = [[l, 1], [-l^2, -l]]
+                        A[o * D + o] = ex * (1.0 + l * dt);
+                        A[o * D + o + 1] = ex * dt;
+                        A[(o + 1) * D + o] = ex * (-l * l * dt);
+                        A[(o + 1) * D + o + 1] = ex * (1.0 - l * dt);
+                    } else {
+                        // N = [[l,1,0],[0,l,1],[-l^3,-3l^2,-2l]],  N^2 = [[l^2,2l,1],[-l^3,-2l^2,-l],[l^4,2l^3,l^2]]
+                        const double l2 = l * l, l3 = l2 * l, l4 = l2 * l2, h = 0.5 * dt * dt;
+                        A[o * D + o] = ex * (1.0 + l * dt + l2 * h);
+                        A[o * D + o + 1] = ex * (dt + 2.0 * l * h);
+                        A[o * D + o + 2] = ex * h;
+                        A[(o + 1) * D + o] = ex * (-l3 * h);
+                        A[(o + 1) * D + o + 1] = ex * (1.0 + l * dt - 2.0 * l2 * h);
+                        A[(o + 1) * D + o + 2] = ex * (dt - l * h);
+                        A[(o + 2) * D + o] = ex * (-l3 * dt + l4 * h);
+                        A[(o + 2) * D + o + 1] = ex * (-3.0 * l2 * dt + 2.0 * l3 * h);
+                        A[(o + 2) * D + o + 2] = ex * (1.0 - 2.0 * l * dt + l2 * h);
+                    }
+                }
+            };
+            double off[D], Q[ET];
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) off[i] = ks.mean[i];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) Q[tix(i, j)] = Pinf[i * D + j] + (i == j ? ks.jitter : 0.0);
+            } else {
+                build_A(dts[(size_t)b * (n - 1) + (t - 1)]);
+                double AP[EF];
+                gemm<D>(A, Pinf, AP);
+                bool zero = true;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double o = ks.mean[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) o = __builtin_fma(-A[i * D + k], ks.mean[k], o);
+                    off[i] = o;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double q = Pinf[i * D + j];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) q = __builtin_fma(-AP[i * D + k], A[j * D + k], q);
+                        q += (i == j ? ks.jitter : 0.0);
+                        Q[tix(i, j)] = q;
+                        zero = zero && (q == 0.0);
+                    }
+                }
+                if (zero) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) Q[tix(i, i)] = 1.0;   // cholesky_or_zero: factor the identity, store zeros
+                }
+                double invd[D];
+                int bd = 0;
+                chol_inplace<D>(Q, invd, bd);
+                bad |= bd;
+                if (zero) {
+#pragma unroll
+                    for (int e = 0; e < ET; ++e) Q[e] = 0.0;
+                }
+            }
+            if (t == 0) {
+                double invd[D];
+                int bd = 0;
+                chol_inplace<D>(Q, invd, bd);
+                bad |= bd;
+            }
+            st_node<D>(offg, R, s, me, off);
+            st_node<ET>(cholg, R, s, me, Q);
+            // --- outgoing transition t -> t+1 ---
+            if (t + 1 < n) {
+                build_A(dts[(size_t)b * (n - 1) + t]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EF; ++e) A[e] = 0.0;
+            }
+            st_node<EF>(Ag, R, s, me, A);
+        }
+    }
+    if (bad) atomicMax(info, 1);
+}
+
+}  // namespace mfgm

@@ -1,0 +1,204 @@
+"""
+Host-side mirror of the stationary SDE kernels on the path (markovflow/kernels/matern.py: `Matern12`,
+`OrnsteinUhlenbeck`, `Matern32`, `Matern52`; markovflow/kernels/sde_kernel.py: `StationaryKernel`, `Sum`).
+`state_space_model(time_points)` evaluates the closed-form matrix exponentials, the process covariances and their
+Cholesky factors in one HIP kernel (k_stationary_ssm) directly in the packed layout.
+"""
+import math
+
+import torch
+
+from . import _lib
+from .emission_model import EmissionModel
+from .packed import Plan
+from .state_space_model import _flat
+from .variational_cvi_sde import _ssm_from_packed
+
+
+class StationaryKernel:
+    """kernels/sde_kernel.py:367-475."""
+
+    state_dim = None
+
+    def __init__(self, output_dim=1, jitter=0.0, state_mean=None):
+        if output_dim != 1:
+            raise ValueError("only output_dim == 1 kernels are on the hot path")
+        self.output_dim = output_dim
+        self.jitter = float(jitter)
+        self._state_mean = state_mean
+
+    # components: list of (order, lam, var) -------------------------------------------------------------
+    def _components(self):
+        raise NotImplementedError
+
+    @property
+    def state_mean(self):
+        if self._state_mean is None:
+            return torch.zeros(self.state_dim, dtype=torch.float64)
+        return torch.as_tensor(self._state_mean, dtype=torch.float64).reshape(self.state_dim)
+
+    def set_state_mean(self, state_mean, trainable=False):
+        self._state_mean = state_mean
+
+    def _spec(self):
+        comps = self._components()
+        if len(comps) > 8 or self.state_dim > 8:
+            raise ValueError("the HIP path supports up to 8 components and state_dim <= 8")
+        spec = _lib.KernelSpec()
+        spec.ncomp = len(comps)
+        off = 0
+        for i, (order, lam, var) in enumerate(comps):
+            spec.order[i], spec.offset[i], spec.lam[i], spec.var[i] = order, off, lam, var
+            off += order
+        m = self.state_mean
+        for i in range(self.state_dim):
+            spec.mean[i] = float(m[i])
+        spec.jitter = self.jitter
+        return spec
+
+    def _block_diag(self, blocks):
+        return torch.block_diag(*blocks)
+
+    @property
+    def steady_state_covariance(self):
+        blocks = []
+        for order, lam, var in self._components():
+            if order == 1:
+                blocks.append(torch.tensor([[var]], dtype=torch.float64))
+            elif order == 2:
+                blocks.append(var * torch.tensor([[1.0, 0.0], [0.0, lam ** 2]], dtype=torch.float64))
+            else:
+                l23 = lam ** 2 / 3.0
+                blocks.append(var * torch.tensor([[1.0, 0.0, -l23], [0.0, l23, 0.0], [-l23, 0.0, lam ** 4]], dtype=torch.float64))
+        return self._block_diag(blocks)
+
+    @property
+    def feedback_matrix(self):
+        blocks = []
+        for order, lam, var in self._components():
+            if order == 1:
+                blocks.append(torch.tensor([[-lam]], dtype=torch.float64))
+            elif order == 2:
+                blocks.append(torch.tensor([[0.0, 1.0], [-lam ** 2, -2.0 * lam]], dtype=torch.float64))
+            else:
+                blocks.append(torch.tensor([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [-lam ** 3, -3.0 * lam ** 2, -3.0 * lam]],
+                                           dtype=torch.float64))
+        return self._block_diag(blocks)
+
+    def state_space_model(self, time_points, plan=None):
+        """SDEKernel.state_space_model (sde_kernel.py:153-171): prior SSM at the given (sorted) time points [..., T]."""
+        t, bs = _flat(time_points, 1)
+        B, T = t.shape
+        if plan is None:
+            plan = Plan(B, T, self.state_dim, device=t.device)
+        dts = (t[:, 1:] - t[:, :-1]).contiguous()
+        A, off, chol = plan.stationary_ssm(self._spec(), dts)
+        plan.check_info()
+        ssm = _ssm_from_packed(plan, A, off, chol)
+        ssm.batch_shape = bs
+        return ssm
+
+    def transition_statistics(self, transition_times, time_deltas):
+        """(A_k, Q_k) (sde_kernel.py:421-446), natural tensors."""
+        td, bs = _flat(time_deltas, 1)
+        B, N = td.shape
+        t = torch.cat([torch.zeros((B, 1), dtype=td.dtype, device=td.device), torch.cumsum(td, dim=1)], dim=1)
+        ssm = self.state_space_model(t)
+        A = ssm.state_transitions
+        c = ssm.cholesky_process_covariances
+        return A.reshape(bs + tuple(A.shape[1:])), (c @ c.transpose(-1, -2)).reshape(bs + tuple(c.shape[1:]))
+
+    def state_transitions(self, transition_times, time_deltas):
+        return self.transition_statistics(transition_times, time_deltas)[0]
+
+    def generate_emission_model(self, time_points):
+        """H = [1, 0, ...] per component, tiled over the time points (sde_kernel.py:173-211, 670-687)."""
+        h = torch.zeros((1, self.state_dim), dtype=torch.float64, device=time_points.device)
+        off = 0
+        for order, _, _ in self._components():
+            h[0, off] = 1.0
+            off += order
+        return EmissionModel(h.expand(tuple(time_points.shape) + (1, self.state_dim)).contiguous())
+
+
+def _check(lengthscale, variance):
+    if lengthscale <= 0.0 or variance <= 0.0:
+        raise ValueError("lengthscale and variance must be positive")     # matern.py `_check_lengthscale_and_variance`
+
+
+class Matern12(StationaryKernel):
+    """matern.py:27-127."""
+    state_dim = 1
+
+    def __init__(self, lengthscale, variance, output_dim=1, jitter=0.0):
+        super().__init__(output_dim, jitter)
+        _check(lengthscale, variance)
+        self.lengthscale, self.variance = float(lengthscale), float(variance)
+
+    def _components(self):
+        return [(1, 1.0 / self.lengthscale, self.variance)]
+
+
+class OrnsteinUhlenbeck(StationaryKernel):
+    """matern.py:130-234: decay lambda, diffusion q, Pinf = q / (2 lambda)."""
+    state_dim = 1
+
+    def __init__(self, decay, diffusion, output_dim=1, jitter=0.0):
+        super().__init__(output_dim, jitter)
+        _check(decay, diffusion)
+        self.decay, self.diffusion = float(decay), float(diffusion)
+
+    def _components(self):
+        return [(1, self.decay, self.diffusion / (2.0 * self.decay))]
+
+
+class Matern32(StationaryKernel):
+    """matern.py:237-373."""
+    state_dim = 2
+
+    def __init__(self, lengthscale, variance, output_dim=1, jitter=0.0):
+        super().__init__(output_dim, jitter)
+        _check(lengthscale, variance)
+        self.lengthscale, self.variance = float(lengthscale), float(variance)
+
+    def _components(self):
+        return [(2, math.sqrt(3.0) / self.lengthscale, self.variance)]
+
+
+class Matern52(StationaryKernel):
+    """matern.py:376-520."""
+    state_dim = 3
+
+    def __init__(self, lengthscale, variance, output_dim=1, jitter=0.0):
+        super().__init__(output_dim, jitter)
+        _check(lengthscale, variance)
+        self.lengthscale, self.variance = float(lengthscale), float(variance)
+
+    def _components(self):
+        return [(3, math.sqrt(5.0) / self.lengthscale, self.variance)]
+
+
+class Sum(StationaryKernel):
+    """sde_kernel.py:540-687 (ConcatKernel / Sum of stationary kernels): block-diagonal state, summed emissions."""
+
+    def __init__(self, kernels, jitter=0.0):
+        super().__init__(1, jitter)
+        self.kernels = list(kernels)
+        self.state_dim = sum(k.state_dim for k in self.kernels)
+
+    @property
+    def state_mean(self):
+        return torch.cat([k.state_mean for k in self.kernels])
+
+    def _components(self):
+        out = []
+        for k in self.kernels:
+            out.extend(k._components())
+        return out
+
+    def _spec(self):
+        spec = super()._spec()
+        # each component kernel adds its own jitter to its Q block; Sum adds its own on top (sde_kernel.py:640-656)
+        if any(k.jitter != 0.0 for k in self.kernels):
+            raise ValueError("per-component jitter inside Sum is not supported on the HIP path; set it on the Sum")
+        return spec

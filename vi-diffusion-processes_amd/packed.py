@@ -174,6 +174,14 @@ class Plan:
                                                         _ptr(chol), _stream()), "mfgm_packed_linearize_cubic")
         return A, off, chol
 
+    def stationary_ssm(self, spec, time_deltas):
+        """Stationary kernel -> packed SSM parameters (A, off, chol); time_deltas natural [B, T-1]."""
+        A, off, chol = self.empty(FULL), self.empty(VEC), self.empty(TRI)
+        td = time_deltas.contiguous() if time_deltas is not None else None
+        _lib.check(self.lib.mfgm_packed_stationary_ssm(self.h, ctypes.byref(spec), _ptr(td), _ptr(A), _ptr(off), _ptr(chol),
+                                                       _ptr(self.info), _stream()), "mfgm_packed_stationary_ssm")
+        return A, off, chol
+
     def node_ids(self, time_index):
         """int64 device tensor b*T + t for every chain and every index in `time_index` ([n] or [B, n])."""
         ti = torch.as_tensor(time_index, dtype=torch.int64, device=self.device)
