@@ -152,3 +152,68 @@ class CVISitesSDE(CVISitesSSM):
         _, grads = self._np_sde.sde_ssm_kl_closed_form(mu, cov, q.subsequent_covariances(cov), alpha, beta, np.diag(self.sde.q),
                                                        self.dt, self.init_mu, self.init_cov)
         return grads
+
+
+class GaussianLik:
+    """gpflow.likelihoods.Gaussian (third-party, GPflow 2.2.1): scalar Gaussian with variance `variance`."""
+
+    def __init__(self, variance):
+        self.variance = float(variance)
+
+    def variational_expectations(self, mu, var, y):
+        v = self.variance
+        return -0.5 * np.log(2 * np.pi) - 0.5 * np.log(v) - 0.5 * ((y - mu) ** 2 + var) / v
+
+    def grads_expectation(self, mu, var, y):
+        v = self.variance
+        dmu, dvar = (y - mu) / v, -0.5 / v * np.ones_like(var)
+        return dmu - 2.0 * dvar * mu, dvar
+
+
+class CVIGaussianProcess:
+    """variational_cvi.py:225-421, single batch element: sites on f = H s, kernel prior."""
+
+    def __init__(self, time_points, observations, kernel, likelihood, learning_rate=0.1):
+        self.t, self.y = np.asarray(time_points, dtype=np.float64), np.asarray(observations, dtype=np.float64)
+        self.kernel, self.lik, self.lr = kernel, likelihood, learning_rate
+        self.nat1 = np.zeros_like(self.y)
+        self.nat2 = -1e-10 * np.ones(self.y.shape + (1,))
+
+    @property
+    def dist_p(self):
+        return self.kernel.state_space_model(self.t)
+
+    @property
+    def dist_q(self):
+        pd, ps = self.dist_p.precision()
+        H = self.kernel.emission_matrix(self.t)
+        bp1 = np.sum(H * self.nat1[..., None], axis=-2)
+        bp2 = np.sum(self.nat2[..., 0][..., None, None] * H[..., None] * H[..., None, :], axis=-3)
+        return np_transforms.ssm_from_params(np_transforms.naturals_to_ssm_params(bp1, -0.5 * pd + bp2, -ps))
+
+    def predict_f(self):
+        mu, cov = self.dist_q.marginals
+        H = self.kernel.emission_matrix(self.t)
+        return np.einsum("...ij,...j->...i", H, mu), np.einsum("...ij,...jk,...ik->...i", H, cov, H)
+
+    def update_sites(self):
+        mu, var = self.predict_f()
+        g1, g2 = self.lik.grads_expectation(mu, var, self.y)
+        self.nat1 = (1 - self.lr) * self.nat1 + self.lr * g1
+        self.nat2 = (1 - self.lr) * self.nat2 + self.lr * g2[..., None]
+
+    def elbo(self):
+        sites = np_kalman.GaussianSitesNat(self.nat1, self.nat2)
+        return np_kalman.KalmanFilterWithSites(self.dist_p, self.kernel.emission_matrix(self.t), sites).log_likelihood()
+
+    def classic_elbo(self):
+        mu, var = self.predict_f()
+        return np.sum(self.lik.variational_expectations(mu, var, self.y)) - np.sum(self.dist_q.kl_divergence(self.dist_p))
+
+
+def gpr_log_likelihood(time_points, observations, kernel, noise_variance):
+    """GaussianProcessRegression.log_likelihood (gaussian_process_regression.py:152) through the Kalman filter."""
+    t = np.asarray(time_points, dtype=np.float64)
+    kf = np_kalman.KalmanFilter(kernel.state_space_model(t), kernel.emission_matrix(t), observations,
+                                np.sqrt(noise_variance) * np.eye(1))
+    return kf.log_likelihood()

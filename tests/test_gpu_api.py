@@ -315,3 +315,38 @@ def test_kalman_filter_sparse_sites(amd, rng):
     gkf = KalmanFilterWithSparseSites(gk.state_space_model(dev(t)), gk.generate_emission_model(dev(t)),
                                       GaussianSitesNat(dev(nat1), dev(nat2)), T, dev(idx), dev(y))
     np.testing.assert_allclose(float(gkf.log_likelihood()), okf.log_likelihood(), rtol=1e-8)
+
+
+@pytest.mark.parametrize("kname", ["m12", "m52", "sum"])
+def test_cvi_gaussian_process(amd, rng, kname):
+    """KA7 on the GPU: CVIGaussianProcess one-step optimum == GPR log-likelihood, sites == (y, -1/2)/sigma^2, and the
+    damped iteration against the oracle (reference tests/integration/models/test_variational_cvi.py:82-141)."""
+    from oracle import np_kernels
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.variational_cvi import CVIGaussianProcess, GaussianProcessRegression
+    mk = {"m12": (lambda m: m.Matern12(2.0, 2.25)), "m52": (lambda m: m.Matern52(0.8, 1.5)),
+          "sum": (lambda m: m.Sum([m.Matern32(1.1, 0.7), m.Matern12(0.5, 1.2)]))}[kname]
+    t = np.sort(rng.uniform(0, 4, size=8))
+    y = np.cos(3 * t)[:, None] + 0.1 * rng.normal(size=(8, 1))
+    noise = 1.0
+    g = CVIGaussianProcess((dev(t), dev(y)), mk(K), Gaussian(noise), learning_rate=1.0)
+    g.update_sites()
+    np.testing.assert_allclose(host(g.sites.nat1), y / noise, rtol=1e-9)
+    np.testing.assert_allclose(host(g.sites.nat2), -0.5 / noise * np.ones((8, 1, 1)), rtol=1e-9)
+    gpr = GaussianProcessRegression((dev(t), dev(y)), mk(K), dev(np.sqrt(noise) * np.eye(1)))
+    ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), noise)
+    # Matern-5/2 process covariances Q = Pinf - A Pinf A^T lose ~8 digits to cancellation at the small random gaps used
+    # here (in the reference as well), which bounds the agreement of any two evaluation orders: 5e-6 << the 1e-5 bound
+    tol = 1e-8 if kname == "m12" else 5e-6
+    np.testing.assert_allclose(float(gpr.log_likelihood()), ref, rtol=tol)
+    np.testing.assert_allclose(float(g.elbo()), ref, rtol=tol)
+    np.testing.assert_allclose(float(g.classic_elbo()), ref, rtol=max(tol, 1e-6))
+    # damped updates follow the oracle
+    g2 = CVIGaussianProcess((dev(t), dev(y)), mk(K), Gaussian(0.3), learning_rate=0.4)
+    o2 = np_models.CVIGaussianProcess(t, y, mk(np_kernels), np_models.GaussianLik(0.3), learning_rate=0.4)
+    for _ in range(3):
+        g2.update_sites()
+        o2.update_sites()
+        np.testing.assert_allclose(float(g2.elbo()), o2.elbo(), rtol=max(tol, 1e-7))
+        np.testing.assert_allclose(float(g2.classic_elbo()), o2.classic_elbo(), rtol=max(tol, 1e-6))

@@ -99,3 +99,23 @@ def test_cvi_dp_double_well_elbo_improves(rng):
         m.update_data_sites(0.5)
         m.update_girsanov_sites(0.3)
     assert m.classic_elbo() > e0
+
+
+def test_cvi_gp_one_step_optimum(rng):
+    """KA7 (reference tests/integration/models/test_variational_cvi.py:82-141): Matern12(l=2, var=2.25), 8 points,
+    Gaussian noise 1: after one update_sites with lr=1 the ELBO is the GPR log-likelihood and the sites are (y, -1/2)/sigma^2."""
+    from oracle import np_kernels
+    t = np.sort(rng.uniform(0, 4, size=8))
+    y = np.cos(3 * t)[:, None] + 0.1 * rng.normal(size=(8, 1))
+    k = np_kernels.Matern12(lengthscale=2.0, variance=2.25)
+    m = np_models.CVIGaussianProcess(t, y, k, np_models.GaussianLik(1.0), learning_rate=1.0)
+    m.update_sites()
+    np.testing.assert_allclose(m.nat1, y / 1.0, rtol=1e-9)
+    np.testing.assert_allclose(m.nat2, -0.5 * np.ones_like(m.nat2), rtol=1e-9)
+    gpr = np_models.gpr_log_likelihood(t, y, k, 1.0)
+    # dense check of the GPR log-likelihood itself
+    Kxx = 2.25 * np.exp(-np.abs(t[:, None] - t[None, :]) / 2.0) + np.eye(8)
+    dense = -0.5 * y[:, 0] @ np.linalg.solve(Kxx, y[:, 0]) - 0.5 * np.linalg.slogdet(Kxx)[1] - 4 * np.log(2 * np.pi)
+    np.testing.assert_allclose(gpr, dense, rtol=1e-9)
+    np.testing.assert_allclose(m.elbo(), gpr, rtol=1e-8)
+    np.testing.assert_allclose(m.classic_elbo(), gpr, rtol=1e-7)

@@ -1,0 +1,173 @@
+"""
+Host-side mirror of markovflow/models/variational_cvi.py (`GaussianProcessWithSitesBase`, `CVIGaussianProcess`,
+`back_project_nats`, `gradient_transformation_mean_var_to_expectation`; variational_cvi.py:32-462) and of
+`GaussianProcessRegression` (models/gaussian_process_regression.py:118-152, the known-answer oracle of the reference's
+CVI tests).  Sites live on f = H s (one scalar site per data point); the posterior is prior naturals + back-projected
+sites, refreshed by the HIP sweeps.
+"""
+import torch
+
+from ._lib import FULL, SYM, TRI, VEC
+from .kalman_filter import GaussianSitesNat, KalmanFilter, KalmanFilterWithSites
+from .ssm_gaussian_transformations import naturals_to_ssm_params_packed
+
+
+def back_project_nats(nat1, nat2, C):
+    """[theta_g1, theta_g2] = [theta_f1 C, theta_f2 C^T C] (variational_cvi.py:423-445): nat1, nat2 [N, 1], C [N, 1, D]."""
+    if nat1.shape[-1] != 1 or nat2.shape[-1] != 1 or C.shape[-2] != 1:
+        raise ValueError("back_project_nats expects nat1 [N, 1], nat2 [N, 1] and C [N, 1, D]")
+    bp1 = (C * nat1[..., None]).sum(dim=-2)
+    bp2 = (nat2[..., None, None] * C[..., None] * C[..., None, :]).sum(dim=-3)
+    return bp1, bp2
+
+
+def gradient_transformation_mean_var_to_expectation(inputs, grads):
+    """Gradient wrt [mu, sigma^2] -> gradient wrt [mu, sigma^2 + mu^2] (variational_cvi.py:448-462)."""
+    if grads[1].dim() == 2:
+        return grads[0] - 2.0 * grads[1] * inputs[0], grads[1]
+    return grads[0] - 2.0 * (grads[1] @ inputs[0][..., None])[:, :, 0], grads[1]
+
+
+class GaussianProcessRegression:
+    """GPR by Kalman filtering (gaussian_process_regression.py:118-152): log_likelihood() is the exact log marginal likelihood."""
+
+    def __init__(self, input_data, kernel, chol_obs_covariance=None, mean_function=None):
+        self._time_points, self._observations = input_data
+        self._kernel = kernel
+        if chol_obs_covariance is None:
+            chol_obs_covariance = torch.zeros((1, 1), dtype=torch.float64, device=self._observations.device)
+        self._chol_obs_covariance = chol_obs_covariance
+
+    @property
+    def _kalman(self):
+        ssm = self._kernel.state_space_model(self._time_points)
+        return KalmanFilter(ssm, self._kernel.generate_emission_model(self._time_points), self._observations,
+                            self._chol_obs_covariance)
+
+    def log_likelihood(self):
+        return self._kalman.log_likelihood()
+
+    @property
+    def posterior_state_space_model(self):
+        return self._kalman.posterior_state_space_model()
+
+
+class GaussianProcessWithSitesBase:
+    """variational_cvi.py:32-222."""
+
+    def __init__(self, input_data, kernel, likelihood, mean_function=None):
+        self._time_points, self._observations = input_data
+        if self._observations.shape[-1] != 1:
+            raise ValueError("sites are univariate: observation_dim must be 1")
+        self._kernel = kernel
+        self._likelihood = likelihood
+        y = self._observations
+        # nat1 = 0, nat2 = -1e-10 (variational_cvi.py:99-103)
+        self.sites = GaussianSitesNat(torch.zeros_like(y), torch.full(tuple(y.shape) + (1,), -1e-10, dtype=y.dtype, device=y.device))
+        self._dist_p = None
+        self._cache = None
+
+    @property
+    def time_points(self):
+        return self._time_points
+
+    @property
+    def observations(self):
+        return self._observations
+
+    @property
+    def kernel(self):
+        return self._kernel
+
+    @property
+    def likelihood(self):
+        return self._likelihood
+
+    @property
+    def dist_p(self):
+        """Prior Gauss-Markov distribution at the data points (variational_cvi.py:212-216); cached: the kernel is fixed here."""
+        if self._dist_p is None:
+            self._dist_p = self._kernel.state_space_model(self._time_points)
+        return self._dist_p
+
+    def _emission(self):
+        return self._kernel.generate_emission_model(self._time_points)
+
+    def _posterior_naturals(self):
+        """theta = prior naturals + back-projected sites (variational_cvi.py:106-135), packed."""
+        ssm = self.dist_p
+        pl = ssm.plan
+        pk = ssm.packed
+        nat = pl.ssm_to_naturals(pk.A, pk.off, pk.chol, precision=False)
+        H = self._emission().emission_matrix
+        bp1, bp2 = back_project_nats(self.sites.nat1, self.sites.nat2[..., 0], H)
+        B, T, d = ssm.B, ssm.T, ssm.d
+        lin = pl.pack(VEC, bp1.expand(ssm.batch_shape + (T, d)).reshape(B, T, d).contiguous())
+        # the reference uses bp_nat1 alone as theta_linear (variational_cvi.py:124-127): the prior mean is zero here
+        diag = pl.pack(SYM, bp2.expand(ssm.batch_shape + (T, d, d)).reshape(B, T, d, d).contiguous())
+        pl.lincomb(diag, 1.0, diag, 1.0, nat["diag"])
+        return pl, lin, diag, nat["sub"]
+
+    @property
+    def dist_q(self):
+        pl, lin, diag, sub = self._posterior_naturals()
+        q = naturals_to_ssm_params_packed(pl, lin, diag, sub)
+        q.batch_shape = self.dist_p.batch_shape
+        return q
+
+    @property
+    def posterior_kalman(self):
+        return KalmanFilterWithSites(self.dist_p, self._emission(), self.sites)
+
+    def log_likelihood(self):
+        return self.posterior_kalman.log_likelihood()
+
+    def loss(self):
+        return -self.log_likelihood()
+
+    def predict_f_at_data(self):
+        """posterior.predict_f(self.time_points): at the conditioning points this is (H mu, H Sigma H^T) of dist_q."""
+        pl, lin, diag, sub = self._posterior_naturals()
+        f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
+        s = pl.selinv(f["L"], f["G"], f["y"], want_sub=False)
+        pl.check_info()
+        ssm = self.dist_p
+        mu = pl.unpack(VEC, s["x"]).reshape(ssm.batch_shape + (ssm.T, ssm.d))
+        cov = pl.unpack(SYM, s["Sig"]).reshape(ssm.batch_shape + (ssm.T, ssm.d, ssm.d))
+        em = self._emission()
+        return em.project_state_to_f(mu), em.project_state_covariance_to_f(cov, full_output_cov=False)
+
+
+class CVIGaussianProcess(GaussianProcessWithSitesBase):
+    """variational_cvi.py:225-421."""
+
+    def __init__(self, input_data, kernel, likelihood, mean_function=None, learning_rate=0.1):
+        super().__init__(input_data, kernel, likelihood, mean_function)
+        self.learning_rate = learning_rate
+
+    def local_objective(self, Fmu, Fvar, Y):
+        return self._likelihood.variational_expectations(Fmu, Fvar, Y)
+
+    def local_objective_and_gradients(self, Fmu, Fvar):
+        """Local objective and its gradient wrt [mu, sigma^2 + mu^2] (variational_cvi.py:332-349), closed form per likelihood."""
+        obj = self.local_objective(Fmu, Fvar, self._observations).sum()
+        return obj, self._likelihood.ve_gradients_expectation(Fmu, Fvar, self._observations)
+
+    def update_sites(self):
+        """theta <- (1 - rho) theta + rho g (variational_cvi.py:351-368)."""
+        fx_mus, fx_covs = self.predict_f_at_data()
+        _, grads = self.local_objective_and_gradients(fx_mus, fx_covs)
+        lr = self.learning_rate
+        self.sites.nat1 = (1 - lr) * self.sites.nat1 + lr * grads[0]
+        self.sites.nat2 = (1 - lr) * self.sites.nat2 + lr * grads[1][..., None]
+
+    def elbo(self):
+        """The marginal likelihood of the model whose likelihood terms are the Gaussian sites (variational_cvi.py:370-379)."""
+        return self.log_likelihood()
+
+    def classic_elbo(self):
+        """sum_i E_q log p(y_i | f_i) - KL[q(s) || p(s)] (variational_cvi.py:381-404)."""
+        fx_mus, fx_covs = self.predict_f_at_data()
+        ve = self._likelihood.variational_expectations(fx_mus, fx_covs, self._observations).sum()
+        kl = self.dist_q.kl_divergence(self.dist_p).sum()
+        return ve - kl
