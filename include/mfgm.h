@@ -157,6 +157,36 @@ typedef struct mfgm_kernel_spec {
 int mfgm_packed_stationary_ssm(const mfgm_plan* plan, const mfgm_kernel_spec* spec, const double* time_deltas, double* A,
                                double* off, double* chol, int* info, void* stream);
 
+/* VDP (markovflow/models/vi_sde.py `VariationalMarkovGP`): drift f_i(x) = af_i x - bf_i x^3, diagonal diffusion q,
+ * q(x0) = N(mu0, chol0 chol0^T) (packed lower triangle), grid step dt, learning rate lr. */
+typedef struct mfgm_vdp_params {
+    double af[8], bf[8];
+    double q[8];
+    double mu0[8];
+    double chol0[36];
+    double dt;
+    double lr;
+} mfgm_vdp_params;
+
+/* forward_pass (vi_sde.py:171-204; LinearDrift(-A, b).to_ssm, drift.py:66-117): variational parameters Am (FULL), bm (VEC),
+ * stored at node t for the transition t -> t+1, to packed SSM parameters A, off, chol. */
+int mfgm_packed_vdp_to_ssm(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm, double* A,
+                           double* off, double* chol, void* stream);
+/* E_sde / dt per chain (vi_sde.py:422-434; squared_drift_difference_along_Gaussian_path, sde_utils.py:182-249) in closed
+ * form; gm (VEC) / gS (SYM) receive dE/dm / dt and dE/dS / dt (vi_sde.py:206-239) when non-NULL. */
+int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
+                         const double* Am, const double* bm, double* e_over_dt, double* gm, double* gS, void* ws, void* stream);
+/* update_lagrange (vi_sde.py:289-347): psi (FULL) and lambda (VEC) on nodes 0..T-2.  yR (VEC) = R^{-1} y and dobsS (SYM) =
+ * -1/2 R^{-1} at the observation nodes, zero elsewhere (jump conditions of a Gaussian likelihood, vi_sde.py:262-287).
+ * seg: scratch of mfgm_vdp_workspace_doubles(plan) doubles. */
+size_t mfgm_vdp_workspace_doubles(const mfgm_plan* plan);
+int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
+                             const double* Am, const double* bm, const double* yR, const double* dobsS, double* psi,
+                             double* lam, double* seg, void* stream);
+/* update_param (vi_sde.py:377-414): A <- (1-lr) A + lr (-E f' + 2 q psi), b <- (1-lr) b + lr (E f + A~ m - q lambda). */
+int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
+                                 const double* psi, const double* lam, double* Am, double* bm, void* stream);
+
 /* Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 =
  * finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call with the
  * same arguments; outputs are overwritten with identical values.  Used by bench.py to time the dominant kernel alone. */

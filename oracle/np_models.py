@@ -217,3 +217,95 @@ def gpr_log_likelihood(time_points, observations, kernel, noise_variance):
     kf = np_kalman.KalmanFilter(kernel.state_space_model(t), kernel.emission_matrix(t), observations,
                                 np.sqrt(noise_variance) * np.eye(1))
     return kf.log_likelihood()
+
+
+class VariationalMarkovGP:
+    """
+    VDP (Archambeau et al. 2007), restating markovflow/models/vi_sde.py:63-482 for a single trajectory.
+    E_sde follows the reference's quadrature (squared_drift_difference_along_Gaussian_path); its gradients use the
+    closed form of oracle/np_sde.py (pinned to finite differences of that quadrature in tests/test_oracle_sde.py) in
+    place of the reference's GradientTape.  The Lagrange sweep reproduces the reference's Python loop exactly,
+    including `psi @ A + psi @ A`, the t-1 write and the untouched last row (vi_sde.py:337-347).
+    PARITY UNPINNED: the reference has no test for this class.
+    """
+
+    def __init__(self, obs_index, observations, sde, grid, likelihood, init_mu, init_cov):
+        from . import np_sde
+        self._np_sde = np_sde
+        self.obs_index, self.y = np.asarray(obs_index), np.asarray(observations, dtype=np.float64)
+        self.sde, self.grid, self.lik = sde, np.asarray(grid, dtype=np.float64), likelihood
+        self.d = sde.state_dim
+        self.N = self.grid.shape[0] - 1
+        self.dt = float(self.grid[1] - self.grid[0])
+        self.A = np.zeros((self.N, self.d, self.d))
+        self.b = np.zeros((self.N, self.d))
+        self.p0_mu, self.p0_cov = np.asarray(init_mu, dtype=np.float64), np.asarray(init_cov, dtype=np.float64)
+        self.q0_mu, self.q0_chol = self.p0_mu.copy(), np.linalg.cholesky(self.p0_cov)
+        self.lam = np.zeros((self.N, self.d))
+        self.psi = 1e-10 * np.broadcast_to(np.eye(self.d), (self.N, self.d, self.d)).copy()
+
+    def forward_pass(self):
+        """vi_sde.py:171-204: marginals of the SSM of the linear drift -A x + b."""
+        q = np.broadcast_to(self.sde.q, (self.N, self.d, self.d))
+        ssm = self._np_sde.linear_drift_to_ssm(-self.A, self.b, q, self.grid, self.q0_mu, self.q0_chol)
+        return ssm.marginals
+
+    def E_sde(self, m=None, S=None):
+        if m is None:
+            m, S = self.forward_pass()
+            m, S = m[:-1], S[:-1]
+        return self._np_sde.squared_drift_difference_along_gaussian_path(self.sde, -self.A, self.b, m, S, self.dt)
+
+    def _grad_E_sde(self, m, S):
+        af, bf = self._np_sde.drift_cubic(self.sde)
+        _, dm, dS = self._np_sde.e_sde_closed_form(af, bf, np.diag(self.sde.q), -self.A, self.b, m[:-1], S[:-1], self.dt)
+        return dm / self.dt, dS / self.dt
+
+    def _jump_conditions(self, m, S):
+        """Gradients of the variational expectations wrt (m, S) at the observation times, scattered on the grid (vi_sde.py:262-287)."""
+        mu, cov = m[self.obs_index], S[self.obs_index]
+        dmu = (self.lik.inv_cov @ (self.y - mu)[..., None])[..., 0]
+        dS = np.broadcast_to(-0.5 * self.lik.inv_cov, cov.shape)
+        d_obs_m, d_obs_S = np.zeros_like(m), np.zeros_like(S)
+        np.add.at(d_obs_m, self.obs_index, dmu)
+        np.add.at(d_obs_S, self.obs_index, dS)
+        return d_obs_m, d_obs_S
+
+    def update_lagrange(self, m, S):
+        dEdm, dEdS = self._grad_E_sde(m, S)
+        d_obs_m, d_obs_S = self._jump_conditions(m, S)
+        self.lam = np.zeros_like(self.lam)
+        self.psi = 1e-10 * np.broadcast_to(np.eye(self.d), (self.N, self.d, self.d)).copy()
+        for t in range(self.N - 1, 0, -1):
+            d_psi = self.psi[t] @ self.A[t] + self.psi[t] @ self.A[t] - dEdS[t]
+            d_lam = self.A[t] @ self.lam[t] - dEdm[t]
+            self.psi[t - 1] = self.psi[t] - self.dt * d_psi - d_obs_S[t]
+            self.lam[t - 1] = self.lam[t] - self.dt * d_lam - d_obs_m[t]
+
+    def update_param(self, m, S, lr):
+        m, S = m[:-1], S[:-1]
+        q = self.sde.q
+        Egrad = -self.sde.expected_gradient_drift(m[None], S[None])[0]
+        Ef = self.sde.expected_drift(m[None], S[None])[0]
+        A_tilde = Egrad[:, :, None] * np.eye(self.d) + 2.0 * q[None] @ self.psi
+        b_tilde = Ef + (A_tilde @ m[..., None])[..., 0] - (q[None] @ self.lam[..., None])[..., 0]
+        self.A = (1 - lr) * self.A + lr * A_tilde
+        self.b = (1 - lr) * self.b + lr * b_tilde
+
+    def update_initial_statistics(self, lr):
+        """vi_sde.py:241-260."""
+        mean = self.p0_mu - self.p0_cov @ self.lam[0]
+        cov = np.linalg.inv(np.linalg.inv(self.p0_cov) + 2.0 * self.psi[0])
+        q0_cov = self.q0_chol @ self.q0_chol.T
+        self.q0_mu = (1 - lr) * self.q0_mu + lr * mean
+        self.q0_chol = np.linalg.cholesky((1 - lr) * q0_cov + lr * cov)
+
+    def KL_initial_state(self):
+        return self._np_sde.gauss_kl(self.q0_mu, self.q0_chol @ self.q0_chol.T, self.p0_mu, self.p0_cov)
+
+    def elbo(self, m=None, S=None):
+        """vi_sde.py:436-455: E_obs - E_sde - KL(q0 || p0); note E_sde() is re-evaluated from the current parameters."""
+        if m is None:
+            m, S = self.forward_pass()
+        E_obs = np.sum(self.lik.variational_expectations(m[self.obs_index], S[self.obs_index], self.y))
+        return E_obs - self.E_sde() - self.KL_initial_state()

@@ -249,3 +249,59 @@ def sde_ssm_kl_closed_form(mu, Sig, Sub, alpha, beta, qdiag, dt, init_mu, init_c
     g1[:-1] -= (_T(GC) @ mu[1:, :, None])[..., 0]
     g1[1:] -= (GC @ mu[:-1, :, None])[..., 0]
     return kl, (g1, GS, GC)
+
+
+# ---- VDP (vi_sde.py) drift-difference energy ------------------------------------------------------------------
+def squared_drift_difference_along_gaussian_path(sde, A, b, m, S, dt, H=20):
+    """
+    squared_drift_difference_along_Gaussian_path (sde_utils.py:182-249):
+        1/2 dt sum_t E_{N(m_t, S_t)} (f_L(x) - f(x))^T q^{-1} (f_L(x) - f(x)),   f_L(x) = A_t x + b_t
+    A [N, D, D], b [N, D] are the LINEAR DRIFT's parameters (the VDP model passes -A_model, b_model).
+    """
+    N, D = m.shape
+    qinv = np.linalg.inv(sde.q)
+
+    def func(x):
+        x = x.reshape(-1, N, D)
+        tmp = ((A[None] @ x[..., None])[..., 0] + b[None]) - sde.drift(x)
+        return np.einsum("pni,ij,pnj->pn", tmp, qinv, tmp).reshape(-1)
+
+    val = mvnquad(func, m, S, H, D)
+    return 0.5 * np.sum(val) * dt
+
+
+def drift_cubic(sde):
+    """f_i(x) = af x - bf x^3 for the two per-dimension drifts on the path."""
+    if isinstance(sde, OrnsteinUhlenbeckSDE):
+        return -sde.decay, 0.0
+    return sde.scale * sde.c, sde.scale
+
+
+def e_sde_closed_form(af, bf, qdiag, A, b, m, S, dt, want_grads=True):
+    """Closed form of the energy above for a per-dimension cubic drift and DIAGONAL q, with dE/dm [N,D] and the
+    symmetric-convention dE/dS [N,D,D]."""
+    N, D = m.shape
+    w = 1.0 / qdiag
+    v = np.einsum("nii->ni", S)
+    Ef, Jf, Vf, d = cubic_moments(af, bf, m, v)
+    El = (A @ m[..., None])[..., 0] + b
+    LS = A @ S
+    LSL = np.einsum("nik,nik->ni", LS, A)
+    LSii = np.einsum("nii->ni", LS)
+    r = El - Ef
+    Tm = LSL - 2.0 * LSii * Jf + Vf + r * r
+    E = 0.5 * dt * np.sum(w * Tm)
+    if not want_grads:
+        return E
+    dm = np.zeros_like(m)
+    dS = np.zeros_like(S)
+    for i in range(D):
+        l = A[:, i, :]                                        # [N, D]
+        ei = np.zeros(D); ei[i] = 1.0
+        gi_m = 2.0 * r[:, i, None] * (l - ei[None] * Jf[:, i, None])
+        gi_m[:, i] += -2.0 * LSii[:, i] * d["J_m"][:, i] + d["V_m"][:, i]
+        dm += 0.5 * dt * w[i] * gi_m
+        gi_S = l[:, :, None] * l[:, None, :] - Jf[:, i, None, None] * (l[:, :, None] * ei[None, None, :] + ei[None, :, None] * l[:, None, :])
+        gi_S[:, i, i] += -2.0 * LSii[:, i] * d["J_v"][:, i] + d["V_v"][:, i] - 2.0 * r[:, i] * d["ubar_v"][:, i]
+        dS += 0.5 * dt * w[i] * gi_S
+    return E, dm, dS

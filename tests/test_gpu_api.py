@@ -350,3 +350,52 @@ def test_cvi_gaussian_process(amd, rng, kname):
         o2.update_sites()
         np.testing.assert_allclose(float(g2.elbo()), o2.elbo(), rtol=max(tol, 1e-7))
         np.testing.assert_allclose(float(g2.classic_elbo()), o2.classic_elbo(), rtol=max(tol, 1e-6))
+
+
+@pytest.mark.parametrize("d,B,T,kind", [(1, 1, 60, "dw"), (2, 2, 47, "dw"), (1, 2, 33, "ou"), (3, 1, 140, "dw")])
+def test_variational_markov_gp(amd, rng, d, B, T, kind):
+    """VDP (vi_sde.py): forward pass, energy and gradients, Lagrange sweep, parameter / initial-state updates and ELBO
+    against the oracle's restatement of the reference loop, per trajectory."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    dt = 0.01
+    qd = np.ones(d)
+    osde = np_sde.OrnsteinUhlenbeckSDE(0.9, np.diag(qd)) if kind == "ou" else np_sde.DoubleWellSDE(np.diag(qd))
+    gs = gsde.OrnsteinUhlenbeckSDE(0.9, torch.from_numpy(np.diag(qd))) if kind == "ou" else gsde.DoubleWellSDE(torch.from_numpy(np.diag(qd)))
+    grid = np.arange(T) * dt
+    idx = np.arange(5, T - 1, 9)
+    y = np.sign(rng.normal(size=(B, len(idx), d))) + 0.1 * rng.normal(size=(B, len(idx), d))
+    cholR = 0.5 * np.eye(d)
+    init = (np.zeros(d), 0.5 * np.eye(d))
+    plan = amd.Plan(B, T, d, R0=8, Rup=3)
+    g = VariationalMarkovGP((grid[idx], dev(y)), gs, grid, MultivariateGaussian(dev(cholR)), prior_initial_state=init, plan=plan)
+    os_ = [np_models.VariationalMarkovGP(idx, y[b], osde, grid, np_models.MultivariateGaussianLik(cholR), *init) for b in range(B)]
+    for it in range(5):
+        mS = g._forward_packed()
+        gm, gS = g._grad_E_sde(mS)
+        g.update_lagrange(mS)
+        g.update_param(mS, lr=0.05)
+        if it > 1:
+            g.update_initial_statistics(0.05)
+        e = host(g.elbo_per_trajectory())
+        psi, lam = host(plan.unpack(amd.FULL, g.psi_lagrange, T - 1)), host(plan.unpack(amd.VEC, g.lambda_lagrange, T - 1))
+        A, bb = host(plan.unpack(amd.FULL, g.A, T - 1)), host(plan.unpack(amd.VEC, g.b, T - 1))
+        for b, o in enumerate(os_):
+            m, S = o.forward_pass()
+            assert_close(host(plan.unpack(amd.VEC, mS[0]))[b], m)
+            assert_close(host(plan.unpack(amd.SYM, mS[1]))[b], S)
+            odm, odS = o._grad_E_sde(m, S)
+            assert_close(host(gm)[b], odm)
+            assert_close(host(gS)[b], odS)
+            o.update_lagrange(m, S)
+            assert_close(psi[b], o.psi)
+            assert_close(lam[b], o.lam)
+            o.update_param(m, S, 0.05)
+            assert_close(A[b], o.A)
+            assert_close(bb[b], o.b)
+            if it > 1:
+                o.update_initial_statistics(0.05)
+            np.testing.assert_allclose(e[b], o.elbo(), rtol=1e-6, atol=1e-6)

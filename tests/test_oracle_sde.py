@@ -62,3 +62,31 @@ def test_linear_prior_gradient_is_natural_parameter_difference(rng):
                                np.full((T - 1, 1, 1), np.sqrt(dt)))
     for g, tq, tp in zip(grads, np_transforms.ssm_to_naturals(q), np_transforms.ssm_to_naturals(p)):
         np.testing.assert_allclose(g, tq - tp, rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("d,kind", [(1, "dw"), (2, "dw"), (2, "ou")])
+def test_e_sde_closed_form(rng, d, kind):
+    """VDP drift-difference energy: the reference's quadrature (sde_utils.py:182-249) vs the closed form and its gradient."""
+    N, dt = 4, 0.05
+    qd = 0.5 + rng.random(d)
+    sde = np_sde.OrnsteinUhlenbeckSDE(0.8, np.diag(qd)) if kind == "ou" else np_sde.DoubleWellSDE(np.diag(qd))
+    A = 0.5 * rng.normal(size=(N, d, d))
+    b = rng.normal(size=(N, d))
+    m = rng.normal(size=(N, d))
+    L = np.tril(0.3 * rng.normal(size=(N, d, d))) + 0.8 * np.eye(d)
+    S = L @ np.swapaxes(L, -1, -2)
+    ref = np_sde.squared_drift_difference_along_gaussian_path(sde, A, b, m, S, dt)
+    af, bf = np_sde.drift_cubic(sde)
+    E, dm, dS = np_sde.e_sde_closed_form(af, bf, qd, A, b, m, S, dt)
+    np.testing.assert_allclose(E, ref, rtol=1e-10)
+    f = lambda mm, SS: np_sde.squared_drift_difference_along_gaussian_path(sde, A, b, mm, SS, dt)
+    eps = 1e-6
+    for idx in np.ndindex(m.shape):
+        e = np.zeros_like(m); e[idx] = eps
+        np.testing.assert_allclose(dm[idx], (f(m + e, S) - f(m - e, S)) / (2 * eps), rtol=1e-5, atol=1e-7)
+    for t, i, j in np.ndindex(S.shape):
+        if j > i:
+            continue
+        e = np.zeros_like(S); e[t, i, j] = eps; e[t, j, i] = eps
+        fd = (f(m, S + e) - f(m, S - e)) / (2 * eps)
+        np.testing.assert_allclose(dS[t, i, j] * (1.0 if i == j else 2.0), fd, rtol=1e-5, atol=1e-7)

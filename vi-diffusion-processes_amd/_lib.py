@@ -39,6 +39,11 @@ EXPORTS = {
     "mfgm_packed_sde_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 14),
     "mfgm_packed_linearize_cubic": (ctypes.c_int, [ctypes.c_void_p] * 8),
     "mfgm_packed_stationary_ssm": (ctypes.c_int, [ctypes.c_void_p] * 8),
+    "mfgm_vdp_workspace_doubles": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "mfgm_packed_vdp_to_ssm": (ctypes.c_int, [ctypes.c_void_p] * 8),
+    "mfgm_packed_vdp_esde": (ctypes.c_int, [ctypes.c_void_p] * 11),
+    "mfgm_packed_vdp_lagrange": (ctypes.c_int, [ctypes.c_void_p] * 12),
+    "mfgm_packed_vdp_update_param": (ctypes.c_int, [ctypes.c_void_p] * 9),
     "mfgm_packed_kl_terms": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
 }
 
@@ -55,6 +60,12 @@ class KernelSpec(ctypes.Structure):
     """mfgm_kernel_spec (include/mfgm.h)."""
     _fields_ = [("ncomp", ctypes.c_int), ("order", ctypes.c_int * 8), ("offset", ctypes.c_int * 8), ("lam", ctypes.c_double * 8),
                 ("var", ctypes.c_double * 8), ("mean", ctypes.c_double * 8), ("jitter", ctypes.c_double)]
+
+
+class VdpParams(ctypes.Structure):
+    """mfgm_vdp_params (include/mfgm.h)."""
+    _fields_ = [("af", ctypes.c_double * 8), ("bf", ctypes.c_double * 8), ("q", ctypes.c_double * 8), ("mu0", ctypes.c_double * 8),
+                ("chol0", ctypes.c_double * 36), ("dt", ctypes.c_double), ("lr", ctypes.c_double)]
 
 
 class MfgmError(RuntimeError):

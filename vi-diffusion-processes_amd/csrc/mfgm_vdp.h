@@ -1,0 +1,359 @@
+// VDP (Archambeau et al. 2007) kernels: markovflow/models/vi_sde.py `VariationalMarkovGP`.
+//   k_vdp_to_ssm       forward_pass: linear drift (-A, b) -> Euler SSM parameters (LinearDrift.to_ssm, drift.py:66-117)
+//   k_vdp_esde         E_sde = 1/2 dt sum_t E_q |f_L - f|^2_{q^{-1}} in closed form (sde_utils.py:182-249)
+//   k_vdp_lagrange<P>  update_lagrange (vi_sde.py:289-347): the backward Euler sweep for (psi, lambda) as a partitioned
+//                      affine recurrence  psi_{t-1} = psi_t (I - 2 dt A_t) + c_t,  lambda_{t-1} = (I - dt A_t) lambda_t + e_t
+//                      (the reference's Python loop with O(T) tensor_scatter_nd_update copies), in three passes:
+//                      segment summaries, a short per-chain scan over segments, and the final sweep.
+//   k_vdp_update_param update_param (vi_sde.py:377-414)
+// Drifts are per-dimension cubics f_i(x) = af x - bf x^3 (OU, double-well) with diagonal diffusion q.
+#pragma once
+#include "mfgm_local.h"
+
+namespace mfgm {
+
+struct VdpParams {
+    double af[8], bf[8];   // drift f_i(x) = af_i x - bf_i x^3
+    double q[8];           // diagonal of the diffusion matrix
+    double mu0[8];         // q(x0) mean
+    double chol0[36];      // q(x0) Cholesky factor (packed lower triangle)
+    double dt;
+    double lr;
+};
+
+// Gaussian moments of the cubic drift: E f, E f', Var f and partials (same algebra as cubic_moments of mfgm_sde.h)
+template <int D>
+MFGM_DEV void drift_moments(const VdpParams& pr, const double (&m)[D], const double (&S)[MFGM_NTRI(D)], double (&Ef)[D],
+                            double (&Jf)[D], double (&Vf)[D], double (&Ef_v)[D], double (&J_m)[D], double (&J_v)[D],
+                            double (&V_m)[D], double (&V_v)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double al = pr.af[i], be = pr.bf[i], mi = m[i], v = S[tix(i, i)];
+        const double m2 = mi * mi, a = m2 + v;
+        Ef[i] = al * mi - be * mi * (m2 + 3.0 * v);
+        Jf[i] = al - 3.0 * be * a;
+        Vf[i] = al * al * v - 6.0 * al * be * v * a + be * be * v * (9.0 * m2 * m2 + 36.0 * m2 * v + 15.0 * v * v);
+        Ef_v[i] = -3.0 * be * mi;
+        J_m[i] = -6.0 * be * mi;
+        J_v[i] = -3.0 * be;
+        V_m[i] = -12.0 * al * be * mi * v + be * be * mi * v * (36.0 * m2 + 72.0 * v);
+        V_v[i] = al * al - 6.0 * al * be * (m2 + 2.0 * v) + be * be * (9.0 * m2 * m2 + 72.0 * m2 * v + 45.0 * v * v);
+    }
+}
+
+// Per-node energy e_t = 1/2 sum_i (1/q_i) E (f_L,i - f_i)^2  (E_sde = dt * sum_t e_t) and, when GRAD, its gradients
+// wrt m (dEdm) and the symmetric block S (dEdS, packed) -- i.e. the reference's dE/dm / dt and dE/dS / dt.
+template <int D, bool GRAD>
+MFGM_DEV double vdp_energy(const VdpParams& pr, const double (&m)[D], const double (&S)[MFGM_NTRI(D)], const double (&A)[D * D],
+                           const double (&b)[D], double (&dEdm)[D], double (&dEdS)[MFGM_NTRI(D)]) {
+    constexpr int ET = MFGM_NTRI(D);
+    double Ef[D], Jf[D], Vf[D], Ef_v[D], J_m[D], J_v[D], V_m[D], V_v[D];
+    drift_moments<D>(pr, m, S, Ef, Jf, Vf, Ef_v, J_m, J_v, V_m, V_v);
+    double e = 0.0;
+    if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) dEdm[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < ET; ++k) dEdS[k] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        // l = row i of the linear drift matrix (-A); LS_i = l^T S ; El_i = l.m + b_i
+        double l[D], ls[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) l[k] = -A[i * D + k];
+        double El = b[i], lsl = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) t = __builtin_fma(l[j], S[six(j, k)], t);
+            ls[k] = t;
+            El = __builtin_fma(l[k], m[k], El);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) lsl = __builtin_fma(ls[k], l[k], lsl);
+        const double r = El - Ef[i], w = 1.0 / pr.q[i];
+        e += 0.5 * w * (lsl - 2.0 * ls[i] * Jf[i] + Vf[i] + r * r);
+        if (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) dEdm[k] += w * r * l[k];
+            dEdm[i] += 0.5 * w * (-2.0 * r * Jf[i] - 2.0 * ls[i] * J_m[i] + V_m[i]);
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int c = 0; c <= a; ++c) {
+                    double g = l[a] * l[c];
+                    if (a == i) g -= Jf[i] * l[c];
+                    if (c == i) g -= Jf[i] * l[a];
+                    dEdS[tix(a, c)] += 0.5 * w * g;
+                }
+            dEdS[tix(i, i)] += 0.5 * w * (-2.0 * ls[i] * J_v[i] + V_v[i] - 2.0 * r * Ef_v[i]);
+        }
+    }
+    return e;
+}
+
+// ---- forward_pass: SSM parameters of dx = (-A x + b) dt + sqrt(q) dB ---------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void k_vdp_to_ssm(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
+                                                  const double* __restrict__ bm, double* __restrict__ Ag,
+                                                  double* __restrict__ offg, double* __restrict__ cholg) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    double bprev[D];
+    if (p > 0) ld_node<D>(bm, R, R - 1, LaneRef::of(lane - 1), bprev);
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            const int t = p * R + s;
+            double off[D], ch[ET], A[EF];
+#pragma unroll
+            for (int e = 0; e < ET; ++e) ch[e] = 0.0;
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) off[i] = pr.mu0[i];
+#pragma unroll
+                for (int e = 0; e < ET; ++e) ch[e] = pr.chol0[e];
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    off[i] = pr.dt * bprev[i];
+                    ch[tix(i, i)] = sqrt(pr.dt * pr.q[i]);
+                }
+            }
+            if (t + 1 < n) {
+                ld_node<EF>(Am, R, s, me, A);
+                ld_node<D>(bm, R, s, me, bprev);
+#pragma unroll
+                for (int e = 0; e < EF; ++e) A[e] = -pr.dt * A[e];
+#pragma unroll
+                for (int i = 0; i < D; ++i) A[i * D + i] += 1.0;
+            } else {
+#pragma unroll
+                for (int e = 0; e < EF; ++e) A[e] = 0.0;
+            }
+            st_node<D>(offg, R, s, me, off);
+            st_node<ET>(cholg, R, s, me, ch);
+            st_node<EF>(Ag, R, s, me, A);
+        }
+    }
+}
+
+// ---- E_sde value (per-lane partials; times dt on the host) and optional gradient arrays --------------------------
+template <int D, bool GRAD>
+__global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
+                                                const double* __restrict__ Sigg, const double* __restrict__ Am,
+                                                const double* __restrict__ bm, double* __restrict__ part,
+                                                double* __restrict__ gm, double* __restrict__ gS) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    double acc = 0.0;
+    for (int s = 0; s < R; ++s) {
+        if (s < len && p * R + s + 1 < n) {
+            double m[D], S[ET], A[EF], bb[D], dm[D], dS[ET];
+            ld_node<D>(mug, R, s, me, m);
+            ld_node<ET>(Sigg, R, s, me, S);
+            ld_node<EF>(Am, R, s, me, A);
+            ld_node<D>(bm, R, s, me, bb);
+            acc += vdp_energy<D, GRAD>(pr, m, S, A, bb, dm, dS);
+            if (GRAD) {
+                st_node<D>(gm, R, s, me, dm);
+                st_node<ET>(gS, R, s, me, dS);
+            }
+        }
+    }
+    part[lane] = acc;
+}
+
+// ---- update_lagrange ------------------------------------------------------------------------------------------------
+// yR (VEC) = R^{-1} y at observation nodes (zero elsewhere), dobsS (SYM) = -1/2 R^{-1} at observation nodes: the jump
+// conditions d_obs_m = yR + 2 dobsS m, d_obs_S = dobsS (vi_sde.py:262-287 for a Gaussian likelihood).
+// PASS 1: per-segment affine summary (Mpsi, Cpsi, Mlam, Clam) with zero input; PASS 3: the sweep from the known value
+// at the segment's last node (bpsi, blam: [lanes] arrays written by k_vdp_lagrange_scan).
+template <int D, int PASS>
+__global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
+                                                    const double* __restrict__ Sigg, const double* __restrict__ Am,
+                                                    const double* __restrict__ bm, const double* __restrict__ yR,
+                                                    const double* __restrict__ dobsS, double* __restrict__ psig,
+                                                    double* __restrict__ lamg, double* __restrict__ seg /* per-lane summaries */) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    constexpr int SEG = 2 * EF + EF + D;   // Mpsi, Cpsi, Mlam, Clam per lane; boundary values reuse the first EF + D slots of a 2nd block
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n, Lp = lv.Lpad;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    const int N = n - 1;                     // number of transitions; psi / lambda live on nodes 0 .. N-1
+    // state: psi (full), lam; in PASS 1 also the running products
+    double psi[EF], lam[D], Mp[EF], Ml[EF];
+    if (PASS == 1) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) { psi[e] = 0.0; Mp[e] = 0.0; Ml[e] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) { lam[i] = 0.0; Mp[i * D + i] = 1.0; Ml[i * D + i] = 1.0; }
+    } else {
+        // boundary value at this segment's last node (slot layout: seg2[(e)*Lpad + lane])
+        const double* bnd = seg + (size_t)SEG * Lp;
+#pragma unroll
+        for (int e = 0; e < EF; ++e) psi[e] = bnd[(size_t)e * Lp + lane];
+#pragma unroll
+        for (int i = 0; i < D; ++i) lam[i] = bnd[(size_t)(EF + i) * Lp + lane];
+    }
+    for (int s = R - 1; s >= 0; --s) {
+        if (s < len) {
+            const int t = p * R + s;
+            if (t <= N - 1) {
+                if (PASS == 3) {
+                    st_node<EF>(psig, R, s, me, psi);
+                    st_node<D>(lamg, R, s, me, lam);
+                }
+                if (t >= 1) {
+                    double m[D], S[ET], A[EF], bb[D], dm[D], dS[ET], yr[D], dob[ET];
+                    ld_node<D>(mug, R, s, me, m);
+                    ld_node<ET>(Sigg, R, s, me, S);
+                    ld_node<EF>(Am, R, s, me, A);
+                    ld_node<D>(bm, R, s, me, bb);
+                    ld_node<D>(yR, R, s, me, yr);
+                    ld_node<ET>(dobsS, R, s, me, dob);
+                    vdp_energy<D, true>(pr, m, S, A, bb, dm, dS);
+                    // psi <- psi - dt (psi A + psi A - dEdS) - d_obs_S ;  lam <- lam - dt (A lam - dEdm) - d_obs_m
+                    double pa[EF], al[D];
+                    gemm<D>(psi, A, pa);
+                    gemv<D>(A, lam, al);
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double dom = yr[i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) dom = __builtin_fma(2.0 * dob[six(i, k)], m[k], dom);
+                        lam[i] = lam[i] - pr.dt * (al[i] - dm[i]) - dom;
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                            psi[i * D + j] = psi[i * D + j] - pr.dt * (2.0 * pa[i * D + j] - dS[six(i, j)]) - dob[six(i, j)];
+                    }
+                    if (PASS == 1) {
+                        // running products: Mp <- Mp (I - 2 dt A),  Ml <- (I - dt A) Ml
+                        double t1[EF], t2[EF];
+                        gemm<D>(Mp, A, t1);
+                        gemm<D>(A, Ml, t2);
+#pragma unroll
+                        for (int e = 0; e < EF; ++e) {
+                            Mp[e] -= 2.0 * pr.dt * t1[e];
+                            Ml[e] -= pr.dt * t2[e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (PASS == 1) {
+        // psi / lam now hold the affine offsets (C) of the segment map: value entering the previous segment's last node
+#pragma unroll
+        for (int e = 0; e < EF; ++e) {
+            seg[(size_t)e * Lp + lane] = Mp[e];
+            seg[(size_t)(EF + e) * Lp + lane] = psi[e];
+            seg[(size_t)(2 * EF + e) * Lp + lane] = Ml[e];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) seg[(size_t)(3 * EF + i) * Lp + lane] = lam[i];
+    }
+}
+
+// PASS 2: one lane per chain walks the segments from the last to the first:
+//   value at the last node of segment p-1 = (value at the last node of segment p) o map_p
+template <int D>
+__global__ __launch_bounds__(64) void k_vdp_lagrange_scan(LevelDesc lv, double* __restrict__ seg) {
+    constexpr int EF = D * D;
+    constexpr int SEG = 3 * EF + D;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b * lv.P >= lv.L) return;
+    const int P = lv.P, Lp = lv.Lpad;
+    double* bnd = seg + (size_t)SEG * Lp;
+    double psi[EF], lam[D];
+#pragma unroll
+    for (int e = 0; e < EF; ++e) psi[e] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { lam[i] = 0.0; psi[i * D + i] = 1e-10; }     // psi_{N-1} = 1e-10 I, lambda_{N-1} = 0
+    for (int p = P - 1; p >= 0; --p) {
+        const int lane = b * P + p;
+        // the last segment's boundary value sits on node N-1 whatever its position inside the segment: the sweep
+        // kernels start writing at t <= N-1, so the same value is correct for them
+#pragma unroll
+        for (int e = 0; e < EF; ++e) bnd[(size_t)e * Lp + lane] = psi[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) bnd[(size_t)(EF + i) * Lp + lane] = lam[i];
+        double Mp[EF], Cp[EF], Ml[EF], Cl[D], t1[EF], t2[D];
+#pragma unroll
+        for (int e = 0; e < EF; ++e) {
+            Mp[e] = seg[(size_t)e * Lp + lane];
+            Cp[e] = seg[(size_t)(EF + e) * Lp + lane];
+            Ml[e] = seg[(size_t)(2 * EF + e) * Lp + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) Cl[i] = seg[(size_t)(3 * EF + i) * Lp + lane];
+        gemm<D>(psi, Mp, t1);
+        gemv<D>(Ml, lam, t2);
+#pragma unroll
+        for (int e = 0; e < EF; ++e) psi[e] = t1[e] + Cp[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) lam[i] = t2[i] + Cl[i];
+    }
+}
+
+// ---- update_param ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void k_vdp_update_param(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
+                                                        const double* __restrict__ Sigg, const double* __restrict__ psig,
+                                                        const double* __restrict__ lamg, double* __restrict__ Am,
+                                                        double* __restrict__ bm) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    for (int s = 0; s < R; ++s) {
+        if (s < len && p * R + s + 1 < n) {
+            double m[D], S[ET], psi[EF], lam[D], A[EF], bb[D];
+            ld_node<D>(mug, R, s, me, m);
+            ld_node<ET>(Sigg, R, s, me, S);
+            ld_node<EF>(psig, R, s, me, psi);
+            ld_node<D>(lamg, R, s, me, lam);
+            ld_node<EF>(Am, R, s, me, A);
+            ld_node<D>(bm, R, s, me, bb);
+            double Ef[D], Jf[D], Vf[D], t0[D], t1[D], t2[D], t3[D], t4[D];
+            drift_moments<D>(pr, m, S, Ef, Jf, Vf, t0, t1, t2, t3, t4);
+            double At[EF], bt[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) At[i * D + j] = 2.0 * pr.q[i] * psi[i * D + j] - (i == j ? Jf[i] : 0.0);
+            gemv<D>(At, m, bt);
+#pragma unroll
+            for (int i = 0; i < D; ++i) bt[i] += Ef[i] - pr.q[i] * lam[i];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) A[e] = (1.0 - pr.lr) * A[e] + pr.lr * At[e];
+#pragma unroll
+            for (int i = 0; i < D; ++i) bb[i] = (1.0 - pr.lr) * bb[i] + pr.lr * bt[i];
+            st_node<EF>(Am, R, s, me, A);
+            st_node<D>(bm, R, s, me, bb);
+        }
+    }
+}
+
+}  // namespace mfgm

@@ -82,6 +82,10 @@ class OrnsteinUhlenbeckSDE(SDE):
     def cubic(self, dt):
         return 1.0 - dt * self.decay, 0.0
 
+    def drift_cubic(self):
+        """f(x) = af x - bf x^3."""
+        return -self.decay, 0.0
+
 
 class DoubleWellSDE(SDE):
     """dx = scale x (c - x^2) dt + dB (sde.py:179-224)."""
@@ -98,3 +102,6 @@ class DoubleWellSDE(SDE):
 
     def cubic(self, dt):
         return 1.0 + dt * self.scale * self.c, dt * self.scale
+
+    def drift_cubic(self):
+        return self.scale * self.c, self.scale

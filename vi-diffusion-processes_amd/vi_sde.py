@@ -1,0 +1,187 @@
+"""
+Host-side mirror of markovflow/models/vi_sde.py: `VariationalMarkovGP` (VDP, Archambeau et al. 2007) --
+`forward_pass`, `update_lagrange`, `update_param`, `update_initial_statistics`, `E_sde`, `KL_initial_state`, `elbo`.
+
+A leading batch of B independent trajectories is supported (observations [B, n_obs, d]); all per-time-step state
+(A, b, psi, lambda, marginals) lives in the packed device layout.  The reference's Python loop over T in
+update_lagrange (with an O(T) tensor copy per step) is a partitioned affine recurrence here.
+Prior / initial distributions are (mean [d], covariance [d, d]) pairs.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FULL, SYM, TRI, VEC
+from .packed import Plan, _ptr, _stream
+from .variational_cvi_sde import grid_indices
+
+
+class VariationalMarkovGP:
+    """vi_sde.py:63-482."""
+
+    def __init__(self, input_data, prior_sde, grid, likelihood, prior_initial_state=None, stabilize_system=False, plan=None):
+        if stabilize_system:
+            raise NotImplementedError("stabilize_system (NaN scrubbing / clipping, vi_sde.py:186-192) is not on the HIP path")
+        obs_times, observations = input_data
+        if observations.dim() == 2:
+            observations = observations[None]
+        self.observations = observations.contiguous()
+        self.B, self.n_obs, self.state_dim = observations.shape
+        self.prior_sde, self.likelihood = prior_sde, likelihood
+        self.grid = torch.as_tensor(grid, dtype=torch.float64)
+        self.num_states = int(self.grid.numel())
+        self.num_transitions = self.num_states - 1
+        self.dt = float(self.grid[1] - self.grid[0])
+        self.device = observations.device
+        d = self.state_dim
+        self.plan = plan if plan is not None else Plan(self.B, self.num_states, d, device=self.device)
+        pl = self.plan
+        self.lib = pl.lib
+        if prior_initial_state is None:
+            # vi_sde.py:93-96: N(0, q * I)
+            prior_initial_state = (np.zeros(d), prior_sde.q.cpu().numpy() * np.eye(d))
+        self.p0_mu = np.asarray(prior_initial_state[0], dtype=np.float64).reshape(d)
+        self.p0_cov = np.asarray(prior_initial_state[1], dtype=np.float64).reshape(d, d)
+        # q(x0) starts at the prior (vi_sde.py:98-100); per trajectory
+        self.q0_mu = torch.from_numpy(self.p0_mu).to(self.device).expand(self.B, d).contiguous()
+        self.q0_chol = torch.from_numpy(np.linalg.cholesky(self.p0_cov)).to(self.device).expand(self.B, d, d).contiguous()
+        self.A, self.b = pl.zeros(FULL), pl.zeros(VEC)
+        self.lambda_lagrange = pl.zeros(VEC)
+        self.psi_lagrange = pl.zeros(FULL)
+        self._reset_lagrange()
+        self.obs_index = grid_indices(self.grid, obs_times).to(self.device)
+        self.obs_node_ids = pl.node_ids(self.obs_index)
+        # jump-condition constants of the Gaussian likelihood: yR = R^{-1} y, dobsS = -1/2 R^{-1} at the observation nodes
+        Rinv = likelihood.inv_covariance
+        n = self.B * self.n_obs
+        self._yR, self._dobsS = pl.zeros(VEC), pl.zeros(SYM)
+        pl.scatter_nodes(VEC, self._yR, self.obs_node_ids, (self.observations.reshape(n, d) @ Rinv), accumulate=True)
+        pl.scatter_nodes(SYM, self._dobsS, self.obs_node_ids, (-0.5 * Rinv).expand(n, d, d).contiguous(), accumulate=True)
+        self._seg = torch.empty(self.lib.mfgm_vdp_workspace_doubles(pl.h), dtype=torch.float64, device=self.device)
+        af, bf = prior_sde.drift_cubic()
+        self._prm = _lib.VdpParams()
+        for i in range(d):
+            self._prm.af[i], self._prm.bf[i], self._prm.q[i] = af, bf, prior_sde.q_diag[i]
+        self._prm.dt = self.dt
+        self._ssm_bufs = None
+        self.dist_q_ssm = None
+
+    def _reset_lagrange(self):
+        """lambda = 0, psi = 1e-10 I on every transition (vi_sde.py:102-103, 328-329)."""
+        self.lambda_lagrange.zero_()
+        d = self.state_dim
+        eye = (1e-10 * torch.eye(d, dtype=torch.float64, device=self.device)).expand(self.B, self.num_states, d, d).contiguous()
+        self.plan.pack(FULL, eye, out=self.psi_lagrange)
+
+    def _params(self, b_index=None, lr=0.0):
+        """Parameter block; q(x0) differs per trajectory only through update_initial_statistics, which is applied per chain
+        on the host side by writing node 0 of the SSM arrays."""
+        self._prm.lr = float(lr)
+        return self._prm
+
+    # -- forward_pass ------------------------------------------------------------------------------------------
+    @property
+    def forward_pass(self):
+        """Marginal means / covariances of the SSM of the current linear drift (vi_sde.py:171-204), natural tensors [B, T, ...]."""
+        m, S = self._forward_packed()
+        return self.plan.unpack(VEC, m), self.plan.unpack(SYM, S)
+
+    def _forward_packed(self):
+        pl = self.plan
+        if self._ssm_bufs is None:
+            self._ssm_bufs = (pl.empty(FULL), pl.empty(VEC), pl.empty(TRI))
+        A, off, chol = self._ssm_bufs
+        prm = self._params()
+        _lib.check(self.lib.mfgm_packed_vdp_to_ssm(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(A), _ptr(off), _ptr(chol),
+                                                   _stream()), "mfgm_packed_vdp_to_ssm")
+        # node 0 carries q(x0), which is per trajectory
+        node0 = pl.node_ids(torch.zeros(1, dtype=torch.int64))
+        pl.scatter_nodes(VEC, off, node0, self.q0_mu)
+        pl.scatter_nodes(TRI, chol, node0, self.q0_chol)
+        pr = pl.ssm_to_naturals(A, off, chol, precision=True)
+        f = pl.factor(pr["diag"], pr["sub"], pr["lin"], want_logdet=False)
+        s = pl.selinv(f["L"], f["G"], f["y"], want_sub=False)
+        self._mS = (s["x"], s["Sig"])
+        return self._mS
+
+    # -- energies ----------------------------------------------------------------------------------------------
+    def E_sde(self, mS=None):
+        """E_sde per trajectory [B] (vi_sde.py:422-434)."""
+        pl = self.plan
+        m, S = mS if mS is not None else self._forward_packed()
+        out = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_packed_vdp_esde(pl.h, ctypes.byref(self._params()), _ptr(m), _ptr(S), _ptr(self.A), _ptr(self.b),
+                                                 _ptr(out), None, None, _ptr(pl.ws), _stream()), "mfgm_packed_vdp_esde")
+        return out * self.dt
+
+    def _grad_E_sde(self, mS=None):
+        """(dE/dm / dt, dE/dS / dt) as natural tensors [B, T-1, ...] (vi_sde.py:206-239)."""
+        pl = self.plan
+        m, S = mS if mS is not None else self._forward_packed()
+        out = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        gm, gS = pl.zeros(VEC), pl.zeros(SYM)
+        _lib.check(self.lib.mfgm_packed_vdp_esde(pl.h, ctypes.byref(self._params()), _ptr(m), _ptr(S), _ptr(self.A), _ptr(self.b),
+                                                 _ptr(out), _ptr(gm), _ptr(gS), _ptr(pl.ws), _stream()), "mfgm_packed_vdp_esde")
+        return pl.unpack(VEC, gm, self.num_transitions), pl.unpack(SYM, gS, self.num_transitions)
+
+    # -- updates -----------------------------------------------------------------------------------------------
+    def update_lagrange(self, mS=None):
+        """Backward sweep with jump conditions for (psi, lambda) (vi_sde.py:289-347)."""
+        pl = self.plan
+        m, S = mS if mS is not None else self._mS
+        _lib.check(self.lib.mfgm_packed_vdp_lagrange(pl.h, ctypes.byref(self._params()), _ptr(m), _ptr(S), _ptr(self.A), _ptr(self.b),
+                                                     _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
+                                                     _ptr(self.lambda_lagrange), _ptr(self._seg), _stream()),
+                   "mfgm_packed_vdp_lagrange")
+
+    def update_param(self, mS=None, lr=0.1):
+        """A <- (1-lr) A + lr A~, b <- (1-lr) b + lr b~ (vi_sde.py:377-414)."""
+        pl = self.plan
+        m, S = mS if mS is not None else self._mS
+        _lib.check(self.lib.mfgm_packed_vdp_update_param(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S),
+                                                         _ptr(self.psi_lagrange), _ptr(self.lambda_lagrange), _ptr(self.A),
+                                                         _ptr(self.b), _stream()), "mfgm_packed_vdp_update_param")
+
+    def update_initial_statistics(self, lr):
+        """q(x0) from the multipliers at t = 0 (vi_sde.py:241-260); tiny per-trajectory d x d algebra."""
+        pl = self.plan
+        node0 = pl.node_ids(torch.zeros(1, dtype=torch.int64))
+        lam0 = pl.gather_nodes(VEC, self.lambda_lagrange, node0)
+        psi0 = pl.gather_nodes(FULL, self.psi_lagrange, node0)
+        P0 = torch.from_numpy(self.p0_cov).to(self.device)
+        mu0 = torch.from_numpy(self.p0_mu).to(self.device)
+        mean = mu0 - (P0 @ lam0[..., None])[..., 0]
+        cov = torch.linalg.inv(torch.linalg.inv(P0) + 2.0 * psi0)
+        q0_cov = self.q0_chol @ self.q0_chol.transpose(-1, -2)
+        self.q0_mu = (1 - lr) * self.q0_mu + lr * mean
+        self.q0_chol = torch.linalg.cholesky((1 - lr) * q0_cov + lr * cov)
+
+    def KL_initial_state(self):
+        """KL[q(x0) || p(x0)] per trajectory (vi_sde.py:416-420)."""
+        d = self.state_dim
+        P0 = torch.from_numpy(self.p0_cov).to(self.device)
+        mu0 = torch.from_numpy(self.p0_mu).to(self.device)
+        P0inv = torch.linalg.inv(P0)
+        S0 = self.q0_chol @ self.q0_chol.transpose(-1, -2)
+        dm = mu0 - self.q0_mu
+        tr = (P0inv * S0).sum(dim=(-1, -2))
+        mh = ((dm @ P0inv) * dm).sum(-1)
+        ld0 = 2.0 * torch.log(torch.diagonal(self.q0_chol, dim1=-2, dim2=-1)).sum(-1)
+        return 0.5 * (tr + mh - d + torch.logdet(P0) - ld0)
+
+    def elbo_per_trajectory(self, mS=None):
+        pl = self.plan
+        m, S = mS if mS is not None else self._forward_packed()
+        mu = pl.gather_nodes(VEC, m, self.obs_node_ids)
+        cov = pl.gather_nodes(SYM, S, self.obs_node_ids)
+        n, d = self.B * self.n_obs, self.state_dim
+        e_obs = self.likelihood.variational_expectations(mu, cov, self.observations.reshape(n, d)).reshape(self.B, self.n_obs).sum(-1)
+        # the reference re-runs forward_pass inside E_sde() (vi_sde.py:443): identical parameters, identical value
+        return e_obs - self.E_sde((m, S)) - self.KL_initial_state()
+
+    def elbo(self, mS=None):
+        """Variational lower bound summed over trajectories (vi_sde.py:436-455)."""
+        return self.elbo_per_trajectory(mS).sum()
