@@ -81,6 +81,21 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
     return out
 
 
+def pmc_traffic(kernel_name, B, T, d):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc/pmc_traffic.json:
+    separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same bench, read side doubled as the gfx950 guide
+    prescribes); None when no PMC profile exists for this workload size."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            prof = json.load(fh)
+        if prof["workload"] != {"B": B, "T": T, "d": d}:
+            return None
+        return float(prof["kernels"][kernel_name]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,7 +203,8 @@ def main():
         alg_bytes = bytes_per_node * B * T
         ach = alg_bytes / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": f"k_backward<{d},true,true,true> (level 0)", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic(f"void mfgm::k_backward<{d}, true, true, true>(mfgm::SweepArgs)", B, T, d),
                            "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if world == 1 and not args.no_cpu_baseline:
             try:
