@@ -126,8 +126,9 @@ typedef struct mfgm_sde_params {
  *   mode 0: kl[B] only;
  *   mode 1: also d KL / d(eta_lin, eta_diag, eta_sub) written to (o1 VEC, od SYM, os FULL);
  *   mode 2: fused update_girsanov_sites (variational_cvi_sde.py:279-299): (o1,od,os) are the Girsanov sites and
- *           (q1,qd,qs) the posterior naturals; both get  -= lr * dKL/d eta  (the sparse data-site term is added by the caller).
- * kl may be NULL in modes 1/2. */
+ *           (q1,qd,qs) the posterior naturals; both get  -= lr * dKL/d eta  (the sparse data-site term is added by the caller);
+ *   mode 3: as mode 2 but only the posterior naturals move (sites kept implicit as theta_q - theta_prior - data sites).
+ * kl may be NULL in modes 1-3. */
 int mfgm_packed_sde_kl(const mfgm_plan* plan, int mode, const mfgm_sde_params* prm, const double* mu, const double* Sig,
                        const double* Sub, double* kl, double* o1, double* od, double* os, double* q1, double* qd, double* qs,
                        void* ws, int* info, void* stream);

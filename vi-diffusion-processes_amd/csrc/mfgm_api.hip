@@ -437,7 +437,8 @@ int sde_kl_impl(const Plan& P, int mode, const SdeParams& pr, const double* mu, 
     dim3 grid(lv.Lpad / 64), block(64);
     if (mode == 0) hipLaunchKernelGGL((k_sde_kl<D, 0>), grid, block, 0, st, lv, pr, mu, Sig, Sub, part, o1, od, os, q1, qd, qs, info);
     else if (mode == 1) hipLaunchKernelGGL((k_sde_kl<D, 1>), grid, block, 0, st, lv, pr, mu, Sig, Sub, part, o1, od, os, q1, qd, qs, info);
-    else hipLaunchKernelGGL((k_sde_kl<D, 2>), grid, block, 0, st, lv, pr, mu, Sig, Sub, part, o1, od, os, q1, qd, qs, info);
+    else if (mode == 2) hipLaunchKernelGGL((k_sde_kl<D, 2>), grid, block, 0, st, lv, pr, mu, Sig, Sub, part, o1, od, os, q1, qd, qs, info);
+    else hipLaunchKernelGGL((k_sde_kl<D, 3>), grid, block, 0, st, lv, pr, mu, Sig, Sub, part, o1, od, os, q1, qd, qs, info);
     MFGM_CHECK_LAUNCH();
     if (kl) {
         hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, kl, (double*)nullptr);
@@ -460,10 +461,10 @@ extern "C" {
 int mfgm_packed_sde_kl(const mfgm_plan* plan, int mode, const mfgm_sde_params* prm, const double* mu, const double* Sig,
                        const double* Sub, double* kl, double* o1, double* od, double* os, double* q1, double* qd, double* qs,
                        void* ws, int* info, void* stream) {
-    if (!plan || !prm || !mu || !Sig || !Sub || !info || !ws || mode < 0 || mode > 2) return 1;
+    if (!plan || !prm || !mu || !Sig || !Sub || !info || !ws || mode < 0 || mode > 3) return 1;
     if (mode == 0 && !kl) return 1;
-    if (mode >= 1 && (!o1 || !od || !os)) return 1;
-    if (mode == 2 && (!q1 || !qd || !qs)) return 1;
+    if ((mode == 1 || mode == 2) && (!o1 || !od || !os)) return 1;
+    if (mode >= 2 && (!q1 || !qd || !qs)) return 1;
     const Plan& P = plan->p;
     SdeParams pr;
     memcpy(&pr, prm, sizeof(pr));

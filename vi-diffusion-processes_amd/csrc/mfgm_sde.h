@@ -221,29 +221,35 @@ __global__ __launch_bounds__(64) void k_sde_kl(LevelDesc lv, SdeParams pr, const
                 st_node<D>(o1, R, s, me, g1);
                 st_node<ET>(od, R, s, me, gd);
                 st_node<EF>(os, R, s, me, gs);
-            } else if (MODE == 2) {
+            } else if (MODE >= 2) {
+                // MODE 2 moves the Girsanov sites (o*) and the posterior naturals (q*) by -lr * gradient; MODE 3 only the
+                // posterior naturals (the sites are implied by theta_q - theta_prior - data sites and need no storage)
                 double a1[D], ad[ET], as_[EF];
-                ld_node<D>(o1, R, s, me, a1);
+                if (MODE == 2) {
+                    ld_node<D>(o1, R, s, me, a1);
 #pragma unroll
-                for (int e = 0; e < D; ++e) a1[e] = __builtin_fma(-pr.lr, g1[e], a1[e]);
-                st_node<D>(o1, R, s, me, a1);
+                    for (int e = 0; e < D; ++e) a1[e] = __builtin_fma(-pr.lr, g1[e], a1[e]);
+                    st_node<D>(o1, R, s, me, a1);
+                    ld_node<ET>(od, R, s, me, ad);
+#pragma unroll
+                    for (int e = 0; e < ET; ++e) ad[e] = __builtin_fma(-pr.lr, gd[e], ad[e]);
+                    st_node<ET>(od, R, s, me, ad);
+                    if (has_next) {
+                        ld_node<EF>(os, R, s, me, as_);
+#pragma unroll
+                        for (int e = 0; e < EF; ++e) as_[e] = __builtin_fma(-pr.lr, gs[e], as_[e]);
+                        st_node<EF>(os, R, s, me, as_);
+                    }
+                }
                 ld_node<D>(q1, R, s, me, a1);
 #pragma unroll
                 for (int e = 0; e < D; ++e) a1[e] = __builtin_fma(-pr.lr, g1[e], a1[e]);
                 st_node<D>(q1, R, s, me, a1);
-                ld_node<ET>(od, R, s, me, ad);
-#pragma unroll
-                for (int e = 0; e < ET; ++e) ad[e] = __builtin_fma(-pr.lr, gd[e], ad[e]);
-                st_node<ET>(od, R, s, me, ad);
                 ld_node<ET>(qd, R, s, me, ad);
 #pragma unroll
                 for (int e = 0; e < ET; ++e) ad[e] = __builtin_fma(-pr.lr, gd[e], ad[e]);
                 st_node<ET>(qd, R, s, me, ad);
                 if (has_next) {
-                    ld_node<EF>(os, R, s, me, as_);
-#pragma unroll
-                    for (int e = 0; e < EF; ++e) as_[e] = __builtin_fma(-pr.lr, gs[e], as_[e]);
-                    st_node<EF>(os, R, s, me, as_);
                     ld_node<EF>(qs, R, s, me, as_);
 #pragma unroll
                     for (int e = 0; e < EF; ++e) as_[e] = __builtin_fma(-pr.lr, gs[e], as_[e]);

@@ -59,8 +59,10 @@ class CVISitesSSM:
         self.obs_sites_indices = grid_indices(self.time_grid, obs_times).to(self.device)
         self.obs_node_ids = plan.node_ids(self.obs_sites_indices)
         d, pl = self.state_dim, plan
-        # Girsanov sites: nat1 = 0, nat2 = -1e-10 * ones  (variational_cvi_sde.py:141-152)
-        self.girsanov_sites = PackedBTDNat(pl.zeros(VEC), pl.zeros(SYM).fill_(-1e-10), pl.zeros(FULL).fill_(-1e-10))
+        # Girsanov sites start at nat1 = 0, nat2 = -1e-10 * ones (variational_cvi_sde.py:141-152).  They are not stored:
+        # theta_q = theta_prior + girsanov + scatter(data) is the resident state and the sites are recovered from it on
+        # demand (property `girsanov_sites`), which halves the traffic of every Girsanov update.
+        self._g_init = True
         # data sites: nat1 = 0, nat2 = +1e-10 * I  (variational_cvi_sde.py:96-103)
         n = self.B * self.n_obs
         self.data_nat1 = torch.zeros((n, d), dtype=torch.float64, device=self.device)
@@ -92,25 +94,43 @@ class CVISitesSSM:
         self.dist_p = ssm
         pk = ssm.packed
         nat = self.plan.ssm_to_naturals(pk.A, pk.off, pk.chol, precision=False, want_logdet=True)
+        old_p, had_q = getattr(self, "_theta_p", None), getattr(self, "_theta_q_valid", False)
         self._theta_p = PackedBTDNat(nat["lin"], nat["diag"], nat["sub"])
+        if had_q and old_p is not None:
+            # the (implicit) Girsanov sites stay what they are: theta_q moves with the prior
+            tq = self._theta_q
+            for qq, new_, old_ in ((tq.lin, nat["lin"], old_p.lin), (tq.diag, nat["diag"], old_p.diag), (tq.sub, nat["sub"], old_p.sub)):
+                self.plan.lincomb(qq, 1.0, qq, 1.0, new_, -1.0, old_)
         self._p_sumlogchol = nat["sumlogchol"]
         # prior marginal means K theta_lin: one factor + solve of the prior itself
         f = self.plan.factor(nat["diag"], nat["sub"], nat["lin"], aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
         s = self.plan.selinv(f["L"], f["G"], f["y"], want_sub=False)
         self._p_mu = s["x"]
         self._q = None
-        self._theta_q_valid = False
+        self._theta_q_valid = bool(had_q and old_p is not None)
 
     # -- sites -> posterior --------------------------------------------------------------------------------
-    def _rebuild_theta_q(self):
+    def _rebuild_theta_q(self, g=None):
         """theta_q = theta_prior + girsanov sites + scattered data sites (variational_cvi_sde.py:161-174), from scratch."""
-        pl, tq, tp, g = self.plan, self._theta_q, self._theta_p, self.girsanov_sites
+        pl, tq, tp = self.plan, self._theta_q, self._theta_p
+        if g is None:   # initial Girsanov sites
+            g = PackedBTDNat(pl.zeros(VEC), pl.zeros(SYM).fill_(-1e-10), pl.zeros(FULL).fill_(-1e-10))
         pl.lincomb(tq.lin, 1.0, tp.lin, 1.0, g.lin)
         pl.lincomb(tq.diag, 1.0, tp.diag, 1.0, g.diag)
         pl.lincomb(tq.sub, 1.0, tp.sub, 1.0, g.sub)
         pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True)
         pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True)
         self._theta_q_valid = True
+
+    @property
+    def girsanov_sites(self):
+        """The Girsanov sites (BTDGaussian in the reference): theta_q - theta_prior - scatter(data sites), packed."""
+        pl, tq, tp = self.plan, self.full_sites(), self._theta_p
+        g = PackedBTDNat(pl.lincomb(pl.empty(VEC), 1.0, tq.lin, -1.0, tp.lin), pl.lincomb(pl.empty(SYM), 1.0, tq.diag, -1.0, tp.diag),
+                         pl.lincomb(pl.empty(FULL), 1.0, tq.sub, -1.0, tp.sub))
+        pl.scatter_nodes(VEC, g.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=-1.0)
+        pl.scatter_nodes(SYM, g.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=-1.0)
+        return g
 
     def full_sites(self):
         """
@@ -190,12 +210,11 @@ class CVISitesSSM:
         g <- g + lr (scatter(data sites) - dKL/d eta) (variational_cvi_sde.py:279-299), with dKL/d eta = theta_q - theta_p.
         Sites and posterior naturals are updated together: theta_q <- theta_q + (g_new - g).
         """
-        pl, g, tq, tp = self.plan, self.girsanov_sites, self.full_sites(), self._theta_p
-        for gg, qq, pp in ((g.lin, tq.lin, tp.lin), (g.diag, tq.diag, tp.diag), (g.sub, tq.sub, tp.sub)):
-            pl.lincomb(gg, 1.0, gg, -lr, qq, lr, pp)          # g += lr (theta_p - theta_q)
+        pl, tq, tp = self.plan, self.full_sites(), self._theta_p
+        for qq, pp in ((tq.lin, tp.lin), (tq.diag, tp.diag), (tq.sub, tp.sub)):
             pl.lincomb(qq, 1.0 - lr, qq, lr, pp)               # theta_q += lr (theta_p - theta_q)
-        for kind, gg, qq, val in ((VEC, g.lin, tq.lin, self.data_nat1), (SYM, g.diag, tq.diag, self.data_nat2)):
-            pl.scatter_nodes(kind, gg, self.obs_node_ids, val, accumulate=True, scale=lr, packed2=qq)
+        pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=lr)
+        pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=lr)
         self._q = None
         self._gather_obs()
 
@@ -279,11 +298,14 @@ class CVISitesSDE(CVISitesSSM):
         unchanged: the trainer's sequence `dist_p_last = dist_p; set_linearized_prior(); tranform_girsanov_sites(...)`
         (docs/diffusion_processes/cvi_dp_trainer.py:127-134, sde_utils.py:550-568).
         """
-        old = self._theta_p
         q_valid = self._q
+        tq = self.full_sites()
+        keep = PackedBTDNat(tq.lin.clone(), tq.diag.clone(), tq.sub.clone())
         self.set_linearized_prior()
-        tranform_girsanov_sites(self.plan, self.girsanov_sites, old, self._theta_p)
-        # theta_q = theta_p + g + data is invariant under the transformation: the cached posterior stays valid
+        # tranform_girsanov_sites adds theta(old prior) - theta(new prior) to the sites, i.e. it keeps
+        # theta_q = theta_p + g + data fixed.  The sites are implicit here (theta_q - theta_p - data), so restoring
+        # theta_q under the new prior IS the transformation and the cached posterior stays valid.
+        self._theta_q = keep
         self._theta_q_valid = True
         self._q = q_valid
 
@@ -303,12 +325,11 @@ class CVISitesSDE(CVISitesSSM):
     def update_girsanov_sites(self, lr: float):
         """Fused: g <- g + lr (scatter(data) - dKL/d eta), theta_q moves by the same increment (variational_cvi_sde.py:279-299)."""
         q = self._refresh()
-        pl, g, tq = self.plan, self.girsanov_sites, self.full_sites()
+        pl, tq = self.plan, self.full_sites()
         self._sde_prm.lr = float(lr)
-        pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=2, grads=(g.lin, g.diag, g.sub),
-                  theta_q=(tq.lin, tq.diag, tq.sub), want_kl=False)
-        for kind, gg, qq, val in ((VEC, g.lin, tq.lin, self.data_nat1), (SYM, g.diag, tq.diag, self.data_nat2)):
-            pl.scatter_nodes(kind, gg, self.obs_node_ids, val, accumulate=True, scale=lr, packed2=qq)
+        pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=3, theta_q=(tq.lin, tq.diag, tq.sub), want_kl=False)
+        pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=lr)
+        pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=lr)
         self._q = None
         self._gather_obs()
 
