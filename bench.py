@@ -187,8 +187,8 @@ def main():
         reps = 20
 
         def one():
-            rc = lib.mfgm_packed_selinv_level(plan.h, 0, _ptr(f["L"]), _ptr(f["G"]), _ptr(f["y"]), _ptr(s["Sig"]), _ptr(s["Sub"]),
-                                              _ptr(s["x"]), _ptr(plan.ws), _stream())
+            rc = lib.mfgm_packed_selinv_mom(plan.h, 0, _ptr(f["L"]), _ptr(f["G"]), _ptr(f["y"]), _ptr(s["Sig"]), None,
+                                            _ptr(s["x"]), _ptr(s["mom"]), _ptr(plan.ws), _stream())
             assert rc == 0
         one()
         torch.cuda.synchronize()
@@ -199,12 +199,14 @@ def main():
         torch.cuda.synchronize()
         k_ms = ev[0].elapsed_time(ev[1]) / reps
         ET = d * (d + 1) // 2
-        bytes_per_node = 8 * 2 * (ET + d * d + d)        # read L, L_sub, y; write Sigma, Sigma_sub, mu (packed)
+        # read L, L_sub, y; write Sigma (packed), mu, and the 3d moment array (mu, diag Sigma, diag Sigma_sub)
+        bytes_per_node = 8 * ((ET + d * d + d) + (ET + d + 3 * d))
         alg_bytes = bytes_per_node * B * T
         ach = alg_bytes / (k_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": f"k_backward<{d},true,true,true> (level 0)", "achieved": ach,
+        kname = f"void mfgm::k_backward<{d}, true, true, false, true>(mfgm::SweepArgs)"
+        out["roofline"] = {"bound": "hbm", "kernel": kname + " (level 0: selected inverse + back-substitution)", "achieved": ach,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic(f"void mfgm::k_backward<{d}, true, true, true>(mfgm::SweepArgs)", B, T, d),
+                           "traffic": pmc_traffic(kname, B, T, d),
                            "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -133,6 +133,22 @@ int mfgm_packed_sde_kl(const mfgm_plan* plan, int mode, const mfgm_sde_params* p
                        const double* Sub, double* kl, double* o1, double* od, double* os, double* q1, double* qd, double* qs,
                        void* ws, int* info, void* stream);
 
+/* mfgm_packed_selinv that additionally writes the moment array mom [3d per node] = (mu_t, diag Sigma_t, diag Sigma_{t+1,t})
+ * consumed by mfgm_packed_sde_lean; Sub may be NULL (then the full cross-covariance blocks are never written).
+ * only_level < 0 runs every level; >= 0 launches that level's kernel alone (profiling, see mfgm_packed_selinv_level). */
+int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* L, const double* G, const double* y, double* Sig,
+                           double* Sub, double* x, double* mom, void* ws, void* stream);
+
+/* CVI-DP on the moment array: KL[q||p] = -H[q] - E_q[log p] where E_q[log p] of a per-dimension cubic drift with diagonal
+ * diffusion depends on q only through mom, so d KL / d eta = theta_q - theta~(mom) with explicit "effective prior naturals"
+ * theta~ (csrc/mfgm_sde.h) and no d x d factorisation:
+ *   mode 0: kl_part[B] = sum_t 1/2 [ sum_i W_i T_i + logdet Qp ] + the x0 term; KL = kl_part + log|L_q| - T d / 2
+ *           (Sig: packed marginal covariances, read at node 0 only);
+ *   mode 3: update_girsanov_sites (variational_cvi_sde.py:279-299) as theta_q <- (1 - lr) theta_q + lr theta~
+ *           (the sparse data-site term lr * scatter(data) is added by the caller). */
+int mfgm_packed_sde_lean(const mfgm_plan* plan, int mode, const mfgm_sde_params* prm, const double* mom, const double* Sig,
+                         double* kl_part, double* q1, double* qd, double* qs, void* ws, void* stream);
+
 /* Linearise the SDE on the posterior path (set_linearized_prior, variational_cvi_sde.py:408-432; linearize_sde,
  * sde_utils.py:119-179; LinearDrift.to_ssm, drift.py:66-117): packed SSM parameters A (FULL), off (VEC), chol (TRI). */
 int mfgm_packed_linearize_cubic(const mfgm_plan* plan, const mfgm_sde_params* prm, const double* mu, const double* Sig,

@@ -222,6 +222,9 @@ def test_cvi_sites_sde(amd, rng, d, kind, B, T):
         for b, o in enumerate(os_):
             assert_close(mu[b], o.fx_mus)
             assert_close(cov[b], o.fx_covs)
+        # the lean (moment-array) KL equals the full-block transition-wise KL, and the implied gradient theta_q - theta~
+        # equals the full-block gradient
+        np.testing.assert_allclose(host(g.KL_q_p()), host(g.KL_q_p_full()), rtol=1e-9)
         # re-linearise on the current posterior and transform the Girsanov sites (posterior unchanged)
         g.relinearize()
         for o in os_:

@@ -44,6 +44,8 @@ EXPORTS = {
     "mfgm_packed_vdp_esde": (ctypes.c_int, [ctypes.c_void_p] * 11),
     "mfgm_packed_vdp_lagrange": (ctypes.c_int, [ctypes.c_void_p] * 12),
     "mfgm_packed_vdp_update_param": (ctypes.c_int, [ctypes.c_void_p] * 9),
+    "mfgm_packed_selinv_mom": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9),
+    "mfgm_packed_sde_lean": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9),
     "mfgm_packed_kl_terms": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
 }
 

@@ -72,13 +72,18 @@ int launch_forward(const SweepArgs& a, bool has_rhs, bool has_corr, bool has_up,
 template <int D>
 int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub, hipStream_t st) {
     dim3 grid(a.lv.Lpad / 64), block(64);
-#define BW(R_, U_, S_) hipLaunchKernelGGL((k_backward<D, R_, U_, S_>), grid, block, 0, st, a)
-    if (has_rhs) {
-        if (has_up) { if (want_sub) BW(true, true, true); else BW(true, true, false); }
-        else { if (want_sub) BW(true, false, true); else BW(true, false, false); }
+    const bool mom = (a.momg != nullptr);
+#define BW(R_, U_, S_, M_) hipLaunchKernelGGL((k_backward<D, R_, U_, S_, M_>), grid, block, 0, st, a)
+    if (mom) {
+        // the moment array needs the means: has_rhs is guaranteed by the entry point
+        if (has_up) { if (want_sub) BW(true, true, true, true); else BW(true, true, false, true); }
+        else { if (want_sub) BW(true, false, true, true); else BW(true, false, false, true); }
+    } else if (has_rhs) {
+        if (has_up) { if (want_sub) BW(true, true, true, false); else BW(true, true, false, false); }
+        else { if (want_sub) BW(true, false, true, false); else BW(true, false, false, false); }
     } else {
-        if (has_up) { if (want_sub) BW(false, true, true); else BW(false, true, false); }
-        else { if (want_sub) BW(false, false, true); else BW(false, false, false); }
+        if (has_up) { if (want_sub) BW(false, true, true, false); else BW(false, true, false, false); }
+        else { if (want_sub) BW(false, false, true, false); else BW(false, false, false, false); }
     }
 #undef BW
     MFGM_CHECK_LAUNCH();
@@ -160,7 +165,7 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
 
 template <int D>
 int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub,
-                double* x, double* ws, hipStream_t st, int only_level = -1) {
+                double* x, double* ws, hipStream_t st, int only_level = -1, double* mom = nullptr) {
     const bool has_rhs = (yg != nullptr);
     const int K = P.nlevels - 1;
     for (int l = K; l >= 0; --l) {
@@ -170,7 +175,7 @@ int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double*
         a.lv = P.lv[l];
         if (l == 0) {
             a.Lg = const_cast<double*>(Lg); a.Gg = const_cast<double*>(Gg); a.yg = const_cast<double*>(yg);
-            a.Sigg = Sig; a.Subg = Sub; a.mug = x;
+            a.Sigg = Sig; a.Subg = Sub; a.mug = x; a.momg = mom;
         } else {
             bind_level_inputs(P, l, ws, a);
         }
@@ -588,6 +593,50 @@ int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* p
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(3, P, pr, mu, Sig, psi, lam, nullptr, nullptr, Am, bm, nullptr, nullptr, st)));
+}
+
+}  // extern "C"
+
+namespace {
+template <int D>
+int sde_lean_impl(const Plan& P, int mode, const SdeParams& pr, const double* mom, const double* Sig, double* out, double* q1,
+                  double* qd, double* qs, double* ws, hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    dim3 grid(lv.Lpad / 64), block(64);
+    if (mode == 0) {
+        double* part = ws + P.off_part[0];
+        hipLaunchKernelGGL((k_sde_lean<D, 0>), grid, block, 0, st, lv, pr, mom, Sig, part, q1, qd, qs);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, out, (double*)nullptr);
+    } else {
+        hipLaunchKernelGGL((k_sde_lean<D, 3>), grid, block, 0, st, lv, pr, mom, Sig, (double*)nullptr, q1, qd, qs);
+    }
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* L, const double* G, const double* y, double* Sig,
+                           double* Sub, double* x, double* mom, void* ws, void* stream) {
+    if (!plan || !L || !G || !Sig || !y || !x || !mom) return 1;
+    const Plan& P = plan->p;
+    if (only_level >= P.nlevels) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st, only_level, mom)));
+}
+
+int mfgm_packed_sde_lean(const mfgm_plan* plan, int mode, const mfgm_sde_params* prm, const double* mom, const double* Sig,
+                         double* kl_part, double* q1, double* qd, double* qs, void* ws, void* stream) {
+    if (!plan || !prm || !mom || !ws || (mode != 0 && mode != 3)) return 1;
+    if (mode == 0 && (!kl_part || !Sig)) return 1;
+    if (mode == 3 && (!q1 || !qd || !qs)) return 1;
+    const Plan& P = plan->p;
+    SdeParams pr;
+    memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (sde_lean_impl<DD>(P, mode, pr, mom, Sig, kl_part, q1, qd, qs, (double*)ws, st)));
 }
 
 }  // extern "C"

@@ -330,3 +330,151 @@ __global__ __launch_bounds__(64) void k_linearize_cubic(LevelDesc lv, SdeParams 
 }
 
 }  // namespace mfgm
+
+namespace mfgm {
+
+// ---- "lean" CVI-DP kernel on the moment array ---------------------------------------------------------------------------
+// With KL[q||p] = -H[q] - E_q[log p], the entropy part of d KL / d eta is theta_q itself and E_q[log p] depends on q only
+// through (mu_t, diag Sigma_t, diag Sigma_{t+1,t}) for a per-dimension cubic drift with diagonal diffusion:
+//   E_q log N(x'; u(x), Qp) = -1/2 sum_i W_i [ S'_ii + m'_i^2 - 2 (J_i C_ii + ubar_i m'_i) + V_i + ubar_i^2 ] - 1/2 log det(2 pi Qp).
+// So d KL / d eta = theta_q - theta~ with the "effective prior naturals"
+//   theta~_sub[t]  = diag(W J_t)
+//   theta~_diag[t] = -1/2 W [t>=1] - 1/2 P0^{-1} [t=0] + diag(k J_v - We ubar_v - 1/2 W V_v)_t [t<T-1]        (k = W C_ii)
+//   theta~_lin[t]  = F_m[t] - 2 theta~_diag[t] m_t - W J_t m_{t+1} [t<T-1] - W J_{t-1} m_{t-1} [t>=1]
+//   F_m[t] = We_{t-1} [t>=1] - P0^{-1}(m_0 - mu0) [t=0] + (k J_m - We J - 1/2 W V_m)_t [t<T-1],   We_t = W (ubar_t - m_{t+1})
+// and the Girsanov update g <- g + lr (data - dKL/d eta) is  theta_q <- (1 - lr) theta_q + lr (theta~ + data)
+// (variational_cvi_sde.py:279-299).  No d x d factorisation is needed.  mom: [3D per node] = (mu, diag Sigma, diag Sigma_{t+1,t}).
+// MODE 0: per-lane partial of  sum_t 1/2 [ sum_i W_i T_i + logdet Qp ] + node-0 term  (host adds log|L_q| - N/2);
+// MODE 3: theta_q update (data-site part added by the caller).
+template <int D, int MODE>
+__global__ __launch_bounds__(64) void k_sde_lean(LevelDesc lv, SdeParams pr, const double* __restrict__ momg,
+                                                const double* __restrict__ Sigg, double* __restrict__ part, double* q1,
+                                                double* qd, double* qs) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    (void)b;
+    double acc = 0.0;
+    // previous node's (We, W J m) contributions entering node t
+    double pWe[D], pWJm[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { pWe[i] = 0.0; pWJm[i] = 0.0; }
+    double cur[3 * D];
+    ld_node<3 * D>(momg, R, 0, me, cur);
+    if (p > 0) {
+        double prv[3 * D];
+        ld_node<3 * D>(momg, R, R - 1, LaneRef::of(lane - 1), prv);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double al = pr.alpha[i], be = pr.beta[i], mi = prv[i], v = prv[D + i], m2 = mi * mi;
+            const double ub = al * mi - be * mi * (m2 + 3.0 * v), J = al - 3.0 * be * (m2 + v);
+            pWe[i] = pr.W[i] * (ub - cur[i]);
+            pWJm[i] = pr.W[i] * J * mi;
+        }
+    }
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            const int t = p * R + s;
+            const bool has_next = (t + 1 < n);
+            double nxt[3 * D];
+            if (has_next) {
+                if (s + 1 < len) ld_node<3 * D>(momg, R, s + 1, me, nxt);
+                else ld_node<3 * D>(momg, R, 0, LaneRef::of(lane + 1), nxt);
+            }
+            double t1[D], tdg[D], tsb[D], nWe[D], nWJm[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double al = pr.alpha[i], be = pr.beta[i], W = pr.W[i];
+                const double mi = cur[i], v = cur[D + i], c = cur[2 * D + i], m2 = mi * mi, a = m2 + v;
+                double Fm = pWe[i], dg = (t >= 1) ? -0.5 * W : 0.0, sb = 0.0, we = 0.0, wjm = 0.0, corr = pWJm[i];
+                if (has_next) {
+                    const double ub = al * mi - be * mi * (m2 + 3.0 * v), J = al - 3.0 * be * a;
+                    const double V = al * al * v - 6.0 * al * be * v * a + be * be * v * (9.0 * m2 * m2 + 36.0 * m2 * v + 15.0 * v * v);
+                    const double ub_v = -3.0 * be * mi, J_m = -6.0 * be * mi, J_v = -3.0 * be;
+                    const double V_m = -12.0 * al * be * mi * v + be * be * mi * v * (36.0 * m2 + 72.0 * v);
+                    const double V_v = al * al - 6.0 * al * be * (m2 + 2.0 * v) + be * be * (9.0 * m2 * m2 + 72.0 * m2 * v + 45.0 * v * v);
+                    const double mn = nxt[i], vn = nxt[D + i];
+                    const double k = W * c;
+                    we = W * (ub - mn);
+                    Fm += k * J_m - we * J - 0.5 * W * V_m;
+                    dg += k * J_v - we * ub_v - 0.5 * W * V_v;
+                    sb = W * J;
+                    wjm = W * J * mi;
+                    corr += W * J * mn;
+                    if (MODE == 0) acc += 0.5 * W * (vn + mn * mn - 2.0 * (J * c + ub * mn) + V + ub * ub);
+                }
+                t1[i] = Fm - corr;           // still missing -2 theta~_diag m (added below, needs the full diag block at t = 0)
+                tdg[i] = dg;
+                tsb[i] = sb;
+                nWe[i] = we;
+                nWJm[i] = wjm;
+            }
+            if (MODE == 0 && has_next) acc += 0.5 * pr.logdetQp;
+            if (t == 0) {
+                double S0[ET];
+                if (MODE == 0) ld_node<ET>(Sigg, R, 0, me, S0);
+                double tr = 0.0, mh = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double pm = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        pm = __builtin_fma(pr.P0inv[six(i, j)], cur[j] - pr.mu0[j], pm);
+                        if (MODE == 0) tr = __builtin_fma(pr.P0inv[six(i, j)], S0[six(i, j)], tr);
+                    }
+                    mh = __builtin_fma(pm, cur[i] - pr.mu0[i], mh);
+                    // F_m[0] = -P0inv (m0 - mu0);  -2 theta~_diag[0] m0 contributes + P0inv m0  =>  net + P0inv mu0 ... done via the block below
+                    t1[i] -= pm;
+                }
+                if (MODE == 0) acc += 0.5 * (tr + mh + pr.logdetP0);
+            }
+            if (MODE == 3) {
+                const double lr = pr.lr, kp = 1.0 - pr.lr;
+                double a1[D], ad[ET], as_[EF];
+                ld_node<D>(q1, R, s, me, a1);
+                ld_node<ET>(qd, R, s, me, ad);
+                // theta~_lin = t1 - 2 theta~_diag m  (theta~_diag = diag(tdg) (+ -1/2 P0inv at t = 0))
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double tl = t1[i] - 2.0 * tdg[i] * cur[i];
+                    if (t == 0) {
+#pragma unroll
+                        for (int j = 0; j < D; ++j) tl = __builtin_fma(pr.P0inv[six(i, j)], cur[j], tl);
+                    }
+                    a1[i] = kp * a1[i] + lr * tl;
+                }
+#pragma unroll
+                for (int e = 0; e < ET; ++e) ad[e] *= kp;
+#pragma unroll
+                for (int i = 0; i < D; ++i) ad[tix(i, i)] += lr * tdg[i];
+                if (t == 0) {
+#pragma unroll
+                    for (int e = 0; e < ET; ++e) ad[e] -= 0.5 * lr * pr.P0inv[e];
+                }
+                st_node<D>(q1, R, s, me, a1);
+                st_node<ET>(qd, R, s, me, ad);
+                if (has_next) {
+                    ld_node<EF>(qs, R, s, me, as_);
+#pragma unroll
+                    for (int e = 0; e < EF; ++e) as_[e] *= kp;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) as_[i * D + i] += lr * tsb[i];
+                    st_node<EF>(qs, R, s, me, as_);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) { pWe[i] = nWe[i]; pWJm[i] = nWJm[i]; }
+            if (has_next) {
+#pragma unroll
+                for (int e = 0; e < 3 * D; ++e) cur[e] = nxt[e];
+            }
+        }
+    }
+    if (part) part[lane] = acc;
+}
+
+}  // namespace mfgm

@@ -60,6 +60,7 @@ struct SweepArgs {
     double* Sigg;          // tri-packed S_tt
     double* Subg;          // full S_{t+1,t} at node t (may be null)
     double* mug;           // L^{-T} y
+    double* momg;          // optional [3d per node]: (mu, diag Sigma_tt, diag Sigma_{t+1,t}) for the local CVI-DP kernels
     // coarser level arrays
     double* uDhat; double* uRsub; double* uS; double* urhat; double* urho;   // written by reduce
     const double* uL; const double* uy;                                         // read by forward
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
 }
 
 // ---- backward -----------------------------------------------------------------------------------
-template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB>
+template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM>
 __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
@@ -346,6 +347,19 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     st_node<ET>(a.Sigg, R, se, me, Sn);
     if (HAS_RHS) st_node<D>(a.mug, R, se, me, xn);
     if (WANT_SUB && (p * R + se == n - 1)) st_node_zero<EF>(a.Subg, R, se, me);
+    if (WANT_MOM) {
+        // (mu, diag Sigma) of the separator now; diag Sigma_{t+1,t} of the separator is written by the lane on its right
+        double mm[3 * D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { mm[i] = xn[i]; mm[D + i] = Sn[tix(i, i)]; mm[2 * D + i] = 0.0; }
+        double* pm = a.momg + ((size_t)me.tile * R + se) * (size_t)(3 * D * 64);
+#pragma unroll
+        for (int e = 0; e < 2 * D; ++e) pm[e * 64 + me.l] = mm[e];
+        if (p * R + se == n - 1) {
+#pragma unroll
+            for (int e = 2 * D; e < 3 * D; ++e) pm[e * 64 + me.l] = 0.0;
+        }
+    }
 
     double Ln[ET], Gn[EF], yn[D];
     if (len > 1) {
@@ -389,11 +403,17 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
             }
             st_node<ET>(a.Sigg, R, s, me, Sig);
             if (WANT_SUB) st_node<EF>(a.Subg, R, s, me, Ssub);
+            if (WANT_MOM) {
+                double mm[3 * D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) { mm[i] = x[i]; mm[D + i] = Sig[tix(i, i)]; mm[2 * D + i] = Ssub[i * D + i]; }
+                st_node<3 * D>(a.momg, R, s, me, mm);
+            }
 #pragma unroll
             for (int e = 0; e < ET; ++e) Sn[e] = Sig[e];
         }
     }
-    if (WANT_SUB && p > 0) {
+    if ((WANT_SUB || WANT_MOM) && p > 0) {
         // S_{t0, t0-1} for the separator on the left, whose own blocks belong to lane-1
         double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF];
         ld_node<ET>(a.Lg, R, R - 1, LaneRef::of(lane - 1), Lt);
@@ -405,7 +425,13 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
         gemm_sym_full<D>(Sn, H, Ssub);
 #pragma unroll
         for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
-        st_node<EF>(a.Subg, R, R - 1, LaneRef::of(lane - 1), Ssub);
+        if (WANT_SUB) st_node<EF>(a.Subg, R, R - 1, LaneRef::of(lane - 1), Ssub);
+        if (WANT_MOM) {
+            const LaneRef left = LaneRef::of(lane - 1);
+            double* pm = a.momg + ((size_t)left.tile * R + (R - 1)) * (size_t)(3 * D * 64);
+#pragma unroll
+            for (int i = 0; i < D; ++i) pm[(2 * D + i) * 64 + left.l] = Ssub[i * D + i];
+        }
     }
 }
 

@@ -190,6 +190,29 @@ class Plan:
         base = torch.arange(self.B, dtype=torch.int64, device=self.device).unsqueeze(1) * self.T
         return (base + ti).reshape(-1).contiguous()
 
+    def selinv_mom(self, L, G, y, want_sub=False, out=None):
+        """Selected inverse that also writes the moment array (mu, diag Sigma, diag Sigma_sub).  Returns dict(Sig, Sub, x, mom)."""
+        out = {} if out is None else out
+        Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
+        Sub = None
+        if want_sub:
+            Sub = out.get("Sub") if out.get("Sub") is not None else self.empty(FULL)
+        x = out.get("x") if out.get("x") is not None else self.empty(VEC)
+        mom = out.get("mom")
+        if mom is None:
+            mom = torch.empty(3 * x.numel(), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_packed_selinv_mom(self.h, -1, _ptr(L), _ptr(G), _ptr(y), _ptr(Sig), _ptr(Sub), _ptr(x), _ptr(mom),
+                                                   _ptr(self.ws), _stream()), "mfgm_packed_selinv_mom")
+        return dict(Sig=Sig, Sub=Sub, x=x, mom=mom)
+
+    def sde_lean(self, prm, mom, Sig=None, mode=0, theta_q=None):
+        """Moment-array CVI-DP kernel: mode 0 -> per-chain KL partial (add log|L_q| - T d / 2), mode 3 -> theta_q update."""
+        q = theta_q if theta_q is not None else (None, None, None)
+        out = torch.empty(self.B, dtype=torch.float64, device=self.device) if mode == 0 else None
+        _lib.check(self.lib.mfgm_packed_sde_lean(self.h, int(mode), ctypes.byref(prm), _ptr(mom), _ptr(Sig), _ptr(out), _ptr(q[0]),
+                                                 _ptr(q[1]), _ptr(q[2]), _ptr(self.ws), _stream()), "mfgm_packed_sde_lean")
+        return out
+
     def check_info(self):
         """Raise ArithmeticError if a pivot block was not positive definite (synchronises)."""
         if int(self.info.item()) != 0:

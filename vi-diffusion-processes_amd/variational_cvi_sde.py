@@ -141,21 +141,28 @@ class CVISitesSSM:
             self._rebuild_theta_q()
         return self._theta_q
 
-    def _refresh(self):
-        """theta_q -> (L, log|L|, mu, Sigma_tt, Sigma_{t+1,t}) in one forward and one backward sweep."""
+    _need_sub = True     # the linear-prior KL (kl_terms) reads the full cross-covariance blocks
+
+    def _refresh(self, want_sub=None):
+        """theta_q -> (L, log|L|, mu, Sigma_tt, [Sigma_{t+1,t}], moments) in one forward and one backward sweep."""
+        want_sub = self._need_sub if want_sub is None else want_sub
+        if self._q is not None and want_sub and self._q["Sub"] is None:
+            self._q = None      # cached refresh lacks the cross-covariances now requested
         if self._q is None:
             pl = self.plan
             tq = self.full_sites()
             f = pl.factor(tq.diag, tq.sub, tq.lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=self._bufs["f"])
-            s = pl.selinv(f["L"], f["G"], f["y"], want_sub=True, out=self._bufs["s"])
+            s = pl.selinv_mom(f["L"], f["G"], f["y"], want_sub=want_sub, out=self._bufs["s"])
             self._bufs["f"].update(L=f["L"], G=f["G"], y=f["y"])
-            self._bufs["s"].update(Sig=s["Sig"], Sub=s["Sub"], x=s["x"])
-            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=s["Sub"])
+            self._bufs["s"].update(Sig=s["Sig"], x=s["x"], mom=s["mom"])
+            if s["Sub"] is not None:
+                self._bufs["s"]["Sub"] = s["Sub"]
+            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=s["Sub"], mom=s["mom"])
         return self._q
 
     @property
     def dist_q_marginals_packed(self):
-        q = self._refresh()
+        q = self._refresh(want_sub=True)
         return q["mu"], q["Sig"], q["Sub"]
 
     @property
@@ -309,14 +316,25 @@ class CVISitesSDE(CVISitesSSM):
         self._theta_q_valid = True
         self._q = q_valid
 
+    _need_sub = False    # the closed-form SDE KL needs only (mu, diag Sigma, diag Sigma_sub): the moment array
+
     def KL_q_p(self):
-        """KL between the posterior chain and the SDE prior, per trajectory [B] (variational_cvi_sde.py:446-486)."""
+        """
+        KL between the posterior chain and the SDE prior, per trajectory [B] (variational_cvi_sde.py:446-486), as
+        -H[q] - E_q[log p]: log|L_q| - T d / 2 + the moment-array sum of k_sde_lean.
+        """
         q = self._refresh()
+        part = self.plan.sde_lean(self._sde_prm, q["mom"], q["Sig"], mode=0)
+        return part + q["logdetL"] - 0.5 * self.T * self.state_dim
+
+    def KL_q_p_full(self):
+        """The same KL through the full-block kernel (k_sde_kl mode 0): transition-wise Gaussian conditionals."""
+        q = self._refresh(want_sub=True)
         return self.plan.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=0)
 
     def grad_kl_wrt_exp_param(self):
         """(KL [B], (d/d eta_lin, d/d eta_diag, d/d eta_sub) packed) (variational_cvi_sde.py:488-493)."""
-        q = self._refresh()
+        q = self._refresh(want_sub=True)
         pl = self.plan
         grads = (pl.empty(VEC), pl.empty(SYM), pl.empty(FULL))
         kl = pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=1, grads=grads)
@@ -327,7 +345,7 @@ class CVISitesSDE(CVISitesSSM):
         q = self._refresh()
         pl, tq = self.plan, self.full_sites()
         self._sde_prm.lr = float(lr)
-        pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=3, theta_q=(tq.lin, tq.diag, tq.sub), want_kl=False)
+        pl.sde_lean(self._sde_prm, q["mom"], mode=3, theta_q=(tq.lin, tq.diag, tq.sub))
         pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=lr)
         pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=lr)
         self._q = None
