@@ -204,6 +204,21 @@ int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, 
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
                                  const double* psi, const double* lam, double* Am, double* bm, void* stream);
 
+/* ---- natural-layout convenience entry points (what a TF custom-op kernel for the reference would call) -------------------
+ * Inputs / outputs are the reference's row-major tensors: diag [B,T,d,d] (lower triangles read), sub [B,T-1,d,d],
+ * rhs [B,T,d].  `nws` is scratch of mfgm_natural_workspace_bytes(plan) bytes (packed temporaries + the plan workspace).
+ *   mfgm_btd_cholesky : L_diag [B,T,d,d] (upper triangles zero), L_sub [B,T-1,d,d] (may be NULL with T == 1), logdet[B]
+ *                       = SymmetricBlockTriDiagonal.cholesky + abs_log_det (block_tri_diag.py:428-440, 353-366)
+ *   mfgm_btd_posterior: logdet[B], x = K^{-1} rhs [B,T,d] (rhs / x may be NULL), Sdiag [B,T,d,d], Ssub [B,T-1,d,d] (may be NULL)
+ *                       = cholesky + solve + block_diagonal_of_inverse fused (block_tri_diag.py:318-351; the marginals route of
+ *                       state_space_model.py:232-262 and naturals_to_ssm_params, ssm_gaussian_transformations.py:440-458).
+ * aD, aS, aR scale the inputs on load (-2, -1, 1 turn natural parameters into a precision). */
+size_t mfgm_natural_workspace_bytes(const mfgm_plan* plan);
+int mfgm_btd_cholesky(const mfgm_plan* plan, const double* diag, const double* sub, double aD, double aS, double* Ldiag,
+                      double* Lsub, double* logdet, void* nws, int* info, void* stream);
+int mfgm_btd_posterior(const mfgm_plan* plan, const double* diag, const double* sub, const double* rhs, double aD, double aS,
+                       double aR, double* logdet, double* x, double* Sdiag, double* Ssub, void* nws, int* info, void* stream);
+
 /* Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 =
  * finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call with the
  * same arguments; outputs are overwritten with identical values.  Used by bench.py to time the dominant kernel alone. */

@@ -402,3 +402,34 @@ def test_variational_markov_gp(amd, rng, d, B, T, kind):
             if it > 1:
                 o.update_initial_statistics(0.05)
             np.testing.assert_allclose(e[b], o.elbo(), rtol=1e-6, atol=1e-6)
+
+
+def test_ssm_sample_log_pdf_and_udu(amd, rng):
+    """StateSpaceModel.sample / log_pdf (state_space_model.py:298-324, 485-526) and upper_diagonal_lower
+    (block_tri_diag.py:442-549; reference test_block_tri_diag.py:207-225: U D U^T recombines to the matrix)."""
+    import torch
+    from vidp_amd.block_tri_diag import SymmetricBlockTriDiagonal
+    from vidp_amd.state_space_model import StateSpaceModel
+    B, T, d = 2, 12, 3
+    prm = random_ssm_params(rng, (B,), T, d)
+    o = np_ssm.StateSpaceModel(*prm)
+    g = StateSpaceModel(*[dev(p) for p in prm])
+    x = o.sample((4,), rng)
+    assert_close(host(g.log_pdf(dev(x))), o.log_pdf(x))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    xs = g.sample((3000,), generator=gen)
+    assert tuple(xs.shape) == (3000, B, T, d)
+    mu, cov = o.marginals
+    np.testing.assert_allclose(host(xs.mean(0)), mu, atol=0.15)
+    np.testing.assert_allclose(host(xs.var(0)), np.einsum("...ii->...i", cov), rtol=0.25, atol=0.05)
+    assert tuple(g.sample((0,)).shape) == (0, B, T, d)
+    diag, sub = random_dominant_btd(rng, (B,), 9, d)
+    sym = SymmetricBlockTriDiagonal(dev(diag), dev(sub))
+    ut, chol_d = sym.upper_diagonal_lower()
+    Ut = host(ut.to_dense())
+    cd = host(chol_d.block_diagonal)
+    D = np_btd.to_dense(cd @ np.swapaxes(cd, -1, -2), None)
+    np.testing.assert_allclose(np.swapaxes(Ut, -1, -2) @ D @ Ut, np_btd.to_dense(diag, sub), rtol=1e-6, atol=1e-8)
+    ou, ocd = np_btd.upper_diagonal_lower(diag, sub)
+    assert_close(host(ut.block_sub_diagonal), ou)
+    assert_close(cd, ocd)

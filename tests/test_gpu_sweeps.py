@@ -136,3 +136,35 @@ def test_partition_invariance_large(amd, rng):
             assert_close(a, b)
     x = outs[0][1]
     np.testing.assert_allclose(np_btd.dense_mult(diag, sub, x, symmetric=True), r, rtol=1e-7, atol=1e-8)
+
+
+def test_natural_layout_entry_points(amd, rng):
+    """mfgm_btd_cholesky / mfgm_btd_posterior: the natural-layout C entry points a TF custom-op kernel would call."""
+    import torch
+    from vidp_amd.packed import _ptr, _stream
+    B, T, d = 3, 57, 3
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    plan = amd.Plan(B, T, d, R0=8, Rup=4)
+    lib = plan.lib
+    nws = torch.empty(lib.mfgm_natural_workspace_bytes(plan.h) // 8, dtype=torch.float64, device="cuda")
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")
+    Ld, Ls, logdet = z(B, T, d, d), z(B, T - 1, d, d), z(B)
+    # natural parameters in, precision on load: theta_diag = -K/2, theta_sub = -K_sub
+    th_d, th_s, dg, sb, rr = _dev(-0.5 * diag), _dev(-sub), _dev(diag), _dev(sub), _dev(r)   # keep the inputs alive across the calls
+    rc = lib.mfgm_btd_cholesky(plan.h, _ptr(th_d), _ptr(th_s), -2.0, -1.0, _ptr(Ld), _ptr(Ls), _ptr(logdet), _ptr(nws),
+                               _ptr(plan.info), _stream())
+    assert rc == 0
+    plan.check_info()
+    oLd, oLs = np_btd.cholesky(diag, sub)
+    assert_close(Ld.cpu().numpy(), oLd)
+    assert_close(Ls.cpu().numpy(), oLs)
+    assert_close(logdet.cpu().numpy(), np_btd.abs_log_det(oLd))
+    x, Sd, Ss = z(B, T, d), z(B, T, d, d), z(B, T - 1, d, d)
+    rc = lib.mfgm_btd_posterior(plan.h, _ptr(dg), _ptr(sb), _ptr(rr), 1.0, 1.0, 1.0, _ptr(logdet), _ptr(x), _ptr(Sd),
+                                _ptr(Ss), _ptr(nws), _ptr(plan.info), _stream())
+    assert rc == 0
+    oSd, oSs = np_btd.inverse_blocks(oLd, oLs)
+    assert_close(Sd.cpu().numpy(), oSd)
+    assert_close(Ss.cpu().numpy(), oSs)
+    assert_close(x.cpu().numpy(), np_btd.solve(oLd, oLs, np_btd.solve(oLd, oLs, r), transpose_left=True))

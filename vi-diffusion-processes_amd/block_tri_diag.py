@@ -168,6 +168,28 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
             Ls = self._unflat(pl.unpack(FULL, f["G"], self.outer_dim - 1))
         return LowerTriangularBlockTriDiagonal(Ld, Ls, plan=pl, _packed=(f["L"], f["G"], pl.epoch))
 
+    def upper_diagonal_lower(self):
+        """
+        U D U^T factorisation (block_tri_diag.py:442-549): returns (U^T as LowerTriangularBlockTriDiagonal with identity
+        diagonal, chol(D) as LowerTriangularBlockTriDiagonal).  With K^{-1} = this matrix, A_k = -U_k^T and D_k = Q_k^{-1}
+        (D_0 = P_0^{-1}) are the parameters of the chain whose precision this is, so they come out of the same
+        forward/backward sweeps as naturals_to_ssm_params instead of the reference's O(T^2) tf.while_loop.
+        """
+        if self._sub is None:
+            raise ValueError("upper_diagonal_lower needs a sub-diagonal")
+        from .ssm_gaussian_transformations import naturals_to_ssm_params_packed
+        pl = self.plan
+        td = pl.lincomb(pl.empty(SYM), -0.5, pl.pack(SYM, self._diag))
+        ts = pl.lincomb(pl.empty(FULL), -1.0, pl.pack(FULL, self._sub))
+        ssm = naturals_to_ssm_params_packed(pl, pl.zeros(VEC), td, ts)
+        chols = torch.cat([ssm._cholP0[:, None], ssm._cholQ], dim=1)
+        eye = torch.eye(self.inner_dim, dtype=chols.dtype, device=chols.device).expand(chols.shape)
+        chol_d = torch.linalg.cholesky(torch.cholesky_solve(eye, chols))
+        u_s = -ssm._A
+        identities = eye.contiguous()
+        return (LowerTriangularBlockTriDiagonal(self._unflat(identities), self._unflat(u_s), plan=pl),
+                LowerTriangularBlockTriDiagonal(self._unflat(chol_d), plan=pl))
+
     def solve_and_marginals(self, rhs=None):
         """
         Fused path used by the models: one factor + one selected inverse giving

@@ -640,3 +640,79 @@ int mfgm_packed_sde_lean(const mfgm_plan* plan, int mode, const mfgm_sde_params*
 }
 
 }  // extern "C"
+
+// ---- natural-layout convenience entry points ---------------------------------------------------------------------------
+namespace {
+struct NatWs {
+    double *D, *S, *r, *L, *G, *y, *Sig, *Sub, *x, *ws;
+};
+NatWs carve(const Plan& P, void* nws) {
+    const LevelDesc& lv = P.lv[0];
+    const int d = P.d, ET = d * (d + 1) / 2, EF = d * d;
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    double* p = (double*)nws;
+    NatWs w;
+    w.D = p; p += al(packed_elems(lv, ET));
+    w.S = p; p += al(packed_elems(lv, EF));
+    w.r = p; p += al(packed_elems(lv, d));
+    w.L = p; p += al(packed_elems(lv, ET));
+    w.G = p; p += al(packed_elems(lv, EF));
+    w.y = p; p += al(packed_elems(lv, d));
+    w.Sig = p; p += al(packed_elems(lv, ET));
+    w.Sub = p; p += al(packed_elems(lv, EF));
+    w.x = p; p += al(packed_elems(lv, d));
+    w.ws = p;
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+size_t mfgm_natural_workspace_bytes(const mfgm_plan* plan) {
+    if (!plan) return 0;
+    const Plan& P = plan->p;
+    const LevelDesc& lv = P.lv[0];
+    const int d = P.d, ET = d * (d + 1) / 2, EF = d * d;
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    size_t n = 3 * al(packed_elems(lv, ET)) + 3 * al(packed_elems(lv, EF)) + 3 * al(packed_elems(lv, d)) + P.ws_doubles;
+    return n * sizeof(double);
+}
+
+int mfgm_btd_cholesky(const mfgm_plan* plan, const double* diag, const double* sub, double aD, double aS, double* Ldiag,
+                      double* Lsub, double* logdet, void* nws, int* info, void* stream) {
+    if (!plan || !diag || !Ldiag || !nws || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && (!sub || !Lsub)) return 1;
+    NatWs w = carve(P, nws);
+    int rc;
+    if ((rc = mfgm_pack(plan, MFGM_SYM, diag, P.T, w.D, stream))) return rc;
+    if (P.T > 1 && (rc = mfgm_pack(plan, MFGM_FULL, sub, P.T - 1, w.S, stream))) return rc;
+    if ((rc = mfgm_packed_factor(plan, w.D, w.S, nullptr, aD, aS, 1.0, w.L, w.G, nullptr, logdet, nullptr, w.ws, info, stream))) return rc;
+    if ((rc = mfgm_unpack(plan, MFGM_TRI, w.L, Ldiag, P.T, stream))) return rc;
+    if (P.T > 1 && (rc = mfgm_unpack(plan, MFGM_FULL, w.G, Lsub, P.T - 1, stream))) return rc;
+    return 0;
+}
+
+int mfgm_btd_posterior(const mfgm_plan* plan, const double* diag, const double* sub, const double* rhs, double aD, double aS,
+                       double aR, double* logdet, double* x, double* Sdiag, double* Ssub, void* nws, int* info, void* stream) {
+    if (!plan || !diag || !Sdiag || !nws || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !sub) return 1;
+    if ((rhs != nullptr) != (x != nullptr)) return 1;
+    NatWs w = carve(P, nws);
+    int rc;
+    if ((rc = mfgm_pack(plan, MFGM_SYM, diag, P.T, w.D, stream))) return rc;
+    if (P.T > 1 && (rc = mfgm_pack(plan, MFGM_FULL, sub, P.T - 1, w.S, stream))) return rc;
+    if (rhs && (rc = mfgm_pack(plan, MFGM_VEC, rhs, P.T, w.r, stream))) return rc;
+    if ((rc = mfgm_packed_factor(plan, w.D, w.S, rhs ? w.r : nullptr, aD, aS, aR, w.L, w.G, rhs ? w.y : nullptr, logdet, nullptr,
+                                 w.ws, info, stream))) return rc;
+    const bool want_sub = (Ssub != nullptr) && P.T > 1;
+    if ((rc = mfgm_packed_selinv(plan, w.L, w.G, rhs ? w.y : nullptr, w.Sig, want_sub ? w.Sub : nullptr, rhs ? w.x : nullptr, w.ws,
+                                 stream))) return rc;
+    if ((rc = mfgm_unpack(plan, MFGM_SYM, w.Sig, Sdiag, P.T, stream))) return rc;
+    if (want_sub && (rc = mfgm_unpack(plan, MFGM_FULL, w.Sub, Ssub, P.T - 1, stream))) return rc;
+    if (rhs && (rc = mfgm_unpack(plan, MFGM_VEC, w.x, x, P.T, stream))) return rc;
+    return 0;
+}
+
+}  // extern "C"

@@ -185,6 +185,55 @@ class StateSpaceModel:
         return self._unflat(kl)
 
 
+def _ssm_sample(self, sample_shape, generator=None):
+    """
+    Sample trajectories (state_space_model.py:298-324): x = (A^{-1})^{-1} (m + chol eps), i.e. a solve against the unit
+    lower block-bidiagonal A^{-1} (partitioned on the device).  Returns sample_shape + batch_shape + [T, d].
+    """
+    from .block_tri_diag import LowerTriangularBlockTriDiagonal
+    if isinstance(sample_shape, int):
+        sample_shape = (sample_shape,)
+    sample_shape = tuple(sample_shape)
+    S = 1
+    for v in sample_shape:
+        S *= int(v)
+    B, T, d = self.B, self.T, self.d
+    dev, dt = self._A.device, self._A.dtype
+    if S == 0:
+        return torch.zeros(sample_shape + self.batch_shape + (T, d), dtype=dt, device=dev)
+    eps = torch.randn((S, B, T, d), dtype=dt, device=dev, generator=generator)
+    chols = torch.cat([self._cholP0[:, None], self._cholQ], dim=1)
+    off = torch.cat([self._mu0[:, None, :], self._b], dim=1)
+    z = (chols[None] @ eps[..., None])[..., 0] + off[None]
+    eye = torch.eye(d, dtype=dt, device=dev).expand(S * B, T, d, d).contiguous()
+    negA = (-self._A)[None].expand(S, B, T - 1, d, d).reshape(S * B, T - 1, d, d).contiguous()
+    x = LowerTriangularBlockTriDiagonal(eye, negA).solve(z.reshape(S * B, T, d))
+    return x.reshape(sample_shape + self.batch_shape + (T, d))
+
+
+def _ssm_log_pdf(self, states):
+    """log p(x) = log p(x0) + sum_k log p(x_{k+1} | x_k) (state_space_model.py:485-526); shape sample_shape + batch_shape."""
+    import math
+    d, T = self.d, self.T
+    x = states.reshape((-1, self.B, T, d))
+
+    def mvn(xx, mean, chol):
+        diff = (xx - mean)[..., None]
+        cinv = torch.linalg.inv(chol)            # tiny d x d triangular blocks
+        z = (cinv @ diff)[..., 0]
+        logdet = torch.log(torch.abs(torch.diagonal(chol, dim1=-2, dim2=-1))).sum(-1)
+        return -0.5 * (z * z).sum(-1) - logdet - 0.5 * d * math.log(2 * math.pi)
+
+    first = mvn(x[:, :, 0], self._mu0[None], self._cholP0[None])
+    cond = (self._A[None] @ x[:, :, :-1, :, None])[..., 0] + self._b[None]
+    rest = mvn(x[:, :, 1:], cond, self._cholQ[None]).sum(-1)
+    return (first + rest).reshape(tuple(states.shape[:-2 - len(self.batch_shape)]) + self.batch_shape)
+
+
+StateSpaceModel.sample = _ssm_sample
+StateSpaceModel.log_pdf = _ssm_log_pdf
+
+
 def state_space_model_from_covariances(initial_mean, initial_covariance, state_transitions, state_offsets,
                                        process_covariances):
     """state_space_model.py:613-664 (tiny d x d Cholesky factorisations: done with torch on the device)."""
