@@ -433,3 +433,41 @@ def test_ssm_sample_log_pdf_and_udu(amd, rng):
     ou, ocd = np_btd.upper_diagonal_lower(diag, sub)
     assert_close(host(ut.block_sub_diagonal), ou)
     assert_close(cd, ocd)
+
+
+def test_trainers(amd, rng):
+    """The trainer loops (cvi_dp_trainer.py:63-136, vi_markov_gp_trainer.py:50-135) on an OU problem: the CVI-DP trainer reaches
+    the exact posterior (ELBO == log marginal likelihood of the Euler SSM) and both trainers' ELBOs end higher than they start."""
+    import torch
+    from oracle import np_btd
+    from tests.test_oracle_models import ou_euler_ssm
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.trainers import CVISitesTrainer, VIMarkovGPTrainer
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    T, dt, decay = 80, 0.01, 1.2
+    grid = np.arange(T) * dt
+    idx = np.sort(rng.choice(np.arange(1, T - 1), size=10, replace=False))
+    test_idx = np.array([i for i in range(3, T - 1, 7) if i not in set(idx)])
+    y = rng.normal(size=(1, 10, 1))
+    y_test = rng.normal(size=(1, len(test_idx), 1))
+    lik = MultivariateGaussian(dev(0.3 * np.eye(1)))
+    init = (np.zeros(1), np.eye(1) / (2 * decay))
+    m = CVISitesSDE(gsde.OrnsteinUhlenbeckSDE(decay, torch.eye(1, dtype=torch.float64)), grid, (grid[idx], dev(y)), lik, prior_initial_state=init)
+    tr = CVISitesTrainer(m, test_data=(grid[test_idx], dev(y_test)), girsanov_sites_lr=1.0, data_sites_lr=1.0, max_itr=3, max_itr_sites_optim=3)
+    elbos, nlpds, rmses, _ = tr.optimize()
+    ssm = ou_euler_ssm(T, dt, decay, 1.0)
+    pd, ps = ssm.precision()
+    K = np.linalg.inv(np_btd.to_dense(pd, ps))
+    Kyy = K[np.ix_(idx, idx)] + 0.09 * np.eye(10)
+    loglik = -0.5 * y[0, :, 0] @ np.linalg.solve(Kyy, y[0, :, 0]) - 0.5 * np.linalg.slogdet(Kyy)[1] - 5 * np.log(2 * np.pi)
+    np.testing.assert_allclose(elbos[-1], loglik, rtol=1e-6, atol=1e-5)
+    assert np.isfinite(nlpds[-1]) and np.isfinite(rmses[-1]) and elbos[-1] >= elbos[0]
+    v = VariationalMarkovGP((grid[idx], dev(y)), gsde.OrnsteinUhlenbeckSDE(decay, torch.eye(1, dtype=torch.float64)), grid, lik,
+                            prior_initial_state=init)
+    tv = VIMarkovGPTrainer(v, test_data=(grid[test_idx], dev(y_test)), q_lr=0.05, x0_lr=0.05, max_itr=15, warmup_itr=2)
+    ev, nv, rv, _ = tv.optimize()
+    assert ev[-1] > ev[0] and np.isfinite(nv[-1])
+    # VDP and CVI-DP approximate the same posterior: the VDP bound stays below the exact log marginal likelihood
+    assert ev[-1] <= loglik + 1e-6

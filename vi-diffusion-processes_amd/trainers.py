@@ -1,0 +1,159 @@
+"""
+Host-side mirror of the experiment trainers that drive the hot path: `CVISitesTrainer`
+(docs/diffusion_processes/cvi_dp_trainer.py:19-200) and `VIMarkovGPTrainer`
+(docs/diffusion_processes/vi_markov_gp_trainer.py:17-135): the inference loops with their learning-rate decay and
+convergence rules, NLPD / RMSE on held-out grid points (exp_dp_utils.py:189-224).  Prior-parameter learning and the
+wandb / hydra plumbing are out of scope.  One host synchronisation per iteration remains (the ELBO scalar decides
+the learning-rate decay), everything else stays on the device.
+"""
+import logging
+import math
+
+import torch
+
+from ._lib import SYM, VEC
+from .variational_cvi_sde import grid_indices
+
+logger = logging.getLogger(__name__)
+
+
+class _Metrics:
+    """NLPD / RMSE of the (batched) posterior at held-out grid points."""
+
+    def __init__(self, model, test_data, time_grid):
+        self.model = model
+        if test_data is None:
+            self.idx = None
+            return
+        t_test, y_test = test_data
+        if y_test.dim() == 2:
+            y_test = y_test[None]
+        self.y = y_test
+        self.idx = grid_indices(time_grid, t_test).to(y_test.device)
+        self.node_ids = model.plan.node_ids(self.idx)
+
+    def __call__(self, mu_packed, Sig_packed):
+        if self.idx is None:
+            return float("nan"), float("nan")
+        pl, lik = self.model.plan, self.model.likelihood
+        B, n, d = self.y.shape
+        m = pl.gather_nodes(VEC, mu_packed, self.node_ids)
+        S = pl.gather_nodes(SYM, Sig_packed, self.node_ids)
+        # likelihood.predict_mean_and_var: y* ~ N(m, S + R)
+        R = lik.chol_covariance @ lik.chol_covariance.transpose(-1, -2)
+        chol = torch.linalg.cholesky(S + R)
+        diff = (self.y.reshape(B * n, d) - m)[..., None]
+        z = (torch.linalg.inv(chol) @ diff)[..., 0]
+        logp = -0.5 * (z * z).sum(-1) - torch.log(torch.diagonal(chol, dim1=-2, dim2=-1)).sum(-1) - 0.5 * d * math.log(2 * math.pi)
+        nlpd = float(-logp.mean())
+        rmse = float(torch.sqrt(((m - self.y.reshape(B * n, d)) ** 2).mean()))
+        return nlpd, rmse
+
+
+class CVISitesTrainer:
+    """cvi_dp_trainer.py:19-200 (inference part)."""
+
+    def __init__(self, model, test_data=None, prior_sde=None, max_itr=100, optim_tol=1e-2, max_itr_sites_optim=20,
+                 girsanov_sites_lr=0.1, data_sites_lr=0.1):
+        self.model, self.prior_sde = model, prior_sde
+        self.max_itr, self.optim_tol, self.max_itr_sites_optim = max_itr, optim_tol, max_itr_sites_optim
+        self.girsanov_sites_lr, self.data_sites_lr = girsanov_sites_lr, data_sites_lr
+        self._metrics = _Metrics(model, test_data, model.time_grid)
+
+    def _nlpd_rmse(self):
+        q = self.model._refresh()
+        return self._metrics(q["mu"], q["Sig"])
+
+    def _optimize_sites_under_stable_prior(self):
+        """cvi_dp_trainer.py:63-95."""
+        elbos = [float(self.model.classic_elbo())]
+        nlpds, rmses = [], []
+        while (len(elbos) - 1) < self.max_itr_sites_optim:
+            self.model.update_data_sites(self.data_sites_lr)
+            self.model.update_girsanov_sites(self.girsanov_sites_lr)
+            elbos.append(float(self.model.classic_elbo()))
+            nl, rm = self._nlpd_rmse()
+            nlpds.append(nl)
+            rmses.append(rm)
+            if len(elbos) > 2 and elbos[-2] > elbos[-1]:
+                logger.info("Decaying LR! ELBO decreasing!!!")
+                self.girsanov_sites_lr /= 10
+                self.data_sites_lr /= 10
+            if len(elbos) > 2 and abs(elbos[-2] - elbos[-1]) < self.optim_tol:
+                logger.info("Breaking the site updates loop. ELBO converged!")
+                break
+        return elbos[1:], nlpds, rmses
+
+    def perform_inference(self):
+        """cvi_dp_trainer.py:97-136: site optimisation under the stabilised prior, then re-linearisation with site transformation."""
+        elbo_vals, nlpd_vals, rmse_vals = [float(self.model.classic_elbo())], [], []
+        relin = hasattr(self.model, "relinearize")
+        for i in range(self.max_itr):
+            before = float(self.model.classic_elbo())
+            e, n, r = self._optimize_sites_under_stable_prior()
+            # (the reference swaps to the unclipped linearised prior here; the posterior, hence the ELBO under the SDE
+            #  prior, is unchanged by the site transformation)
+            after = float(self.model.classic_elbo())
+            elbo_vals += e
+            nlpd_vals += n
+            rmse_vals += r
+            if abs(before - after) < self.optim_tol:
+                logger.info("ELBO converged! Optimization successfully completed!")
+                break
+            if relin and i != self.max_itr - 1:
+                self.model.relinearize()
+        return elbo_vals[1:], nlpd_vals, rmse_vals
+
+    def optimize(self):
+        """cvi_dp_trainer.py:138-176 without prior learning."""
+        e0 = float(self.model.classic_elbo())
+        n0, r0 = self._nlpd_rmse()
+        e, n, r = self.perform_inference()
+        return [e0] + e, [n0] + n, [r0] + r, {}
+
+
+class VIMarkovGPTrainer:
+    """vi_markov_gp_trainer.py:17-135 (inference part)."""
+
+    def __init__(self, model, test_data=None, q_lr=0.1, x0_lr=0.1, max_itr=1000, lr_tol=1e-2, optim_tol=1e-4, warmup_x0_itr=10,
+                 warmup_itr=20):
+        self.model = model
+        self.q_lr, self.x0_lr, self.max_itr = q_lr, x0_lr, max_itr
+        self.lr_tol, self.optim_tol, self.warmup_x0_itr, self.warmup_itr = lr_tol, optim_tol, warmup_x0_itr, warmup_itr
+        self._metrics = _Metrics(model, test_data, model.grid)
+
+    def perform_inference(self):
+        """vi_markov_gp_trainer.py:50-92."""
+        mdl = self.model
+        elbos, nlpds, rmses = [float(mdl.elbo())], [], []
+        q_lr, x0_lr = self.q_lr, self.x0_lr
+        for i in range(self.max_itr):
+            mS = mdl._forward_packed()
+            mdl.update_lagrange(mS)
+            mdl.update_param(mS, lr=q_lr)
+            if i > self.warmup_x0_itr:
+                mdl.update_initial_statistics(lr=x0_lr)
+            mS = mdl._forward_packed()
+            elbos.append(float(mdl.elbo(mS)))
+            nl, rm = self._metrics(*mS)
+            nlpds.append(nl)
+            rmses.append(rm)
+            if elbos[-2] > elbos[-1] or abs(elbos[-2] - elbos[-1]) < self.lr_tol:
+                q_lr /= 10
+                x0_lr /= 10
+            if abs(elbos[-2] - elbos[-1]) < self.optim_tol:
+                break
+        return elbos[1:], nlpds, rmses
+
+    def optimize(self):
+        """vi_markov_gp_trainer.py:94-135 without prior learning: 20 warm-up iterations at lr = 1e-6, then inference."""
+        mdl = self.model
+        for _ in range(self.warmup_itr):
+            mS = mdl._forward_packed()
+            mdl.update_lagrange(mS)
+            mdl.update_param(mS, lr=1e-6)
+        mS = mdl._forward_packed()
+        e0 = float(mdl.elbo(mS))
+        n0, r0 = self._metrics(*mS)
+        e, n, r = self.perform_inference()
+        return [e0] + e, [n0] + n, [r0] + r, {}
