@@ -471,3 +471,35 @@ def test_trainers(amd, rng):
     assert ev[-1] > ev[0] and np.isfinite(nv[-1])
     # VDP and CVI-DP approximate the same posterior: the VDP bound stays below the exact log marginal likelihood
     assert ev[-1] <= loglik + 1e-6
+
+
+def test_ssm_natgrad_one_step_optimum(amd, rng):
+    """KA9 (reference tests/integration/test_ssm_natgrad.py:46-65): one natural-gradient step with gamma = 1 and a Gaussian
+    likelihood makes the variational ELBO equal to the GPR log-likelihood (atol 1e-5, rtol 1e-6), from any initial q."""
+    from oracle import np_kernels
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.ssm_natgrad import GaussMarkovELBO, SSMNaturalGradient
+    from vidp_amd.state_space_model import StateSpaceModel
+    mk = lambda m: m.Sum([m.Matern52(0.9, 1.3), m.Matern32(1.4, 0.6)])
+    t = np.sort(rng.uniform(0, 5, size=10))
+    y = np.sin(2 * t)[:, None] + 0.1 * rng.normal(size=(10, 1))
+    noise = 0.5
+    gk = mk(K)
+    p = gk.state_space_model(dev(t))
+    plan = p.plan
+    q = StateSpaceModel(*[dev(a) for a in random_ssm_params(rng, (), 10, 5)], plan=plan)
+    loss = GaussMarkovELBO(p, gk.generate_emission_model(dev(t)), Gaussian(noise), dev(y))
+    before = float(loss.elbo(q))
+    SSMNaturalGradient(gamma=1.0).minimize(loss, q)
+    ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), noise)
+    np.testing.assert_allclose(float(loss.elbo(q)), ref, rtol=1e-6, atol=1e-5)
+    assert float(loss.elbo(q)) > before
+    # a damped step moves towards, not onto, the optimum
+    q2 = StateSpaceModel(*[dev(a) for a in random_ssm_params(rng, (), 10, 5)], plan=plan)
+    e0 = float(loss.elbo(q2))
+    SSMNaturalGradient(gamma=0.3).minimize(loss, q2)
+    e1 = float(loss.elbo(q2))
+    assert e0 < e1 < ref + 1e-6
+    with pytest.raises(NotImplementedError):
+        SSMNaturalGradient(gamma=0.1).minimize(lambda: 0.0, q2)
