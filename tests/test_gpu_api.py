@@ -503,3 +503,42 @@ def test_ssm_natgrad_one_step_optimum(amd, rng):
     assert e0 < e1 < ref + 1e-6
     with pytest.raises(NotImplementedError):
         SSMNaturalGradient(gamma=0.1).minimize(lambda: 0.0, q2)
+
+
+@pytest.mark.parametrize("kname", ["m12", "m32sum"])
+def test_sparse_cvi_and_posterior(amd, rng, kname):
+    """KA8 on the GPU: SparseCVIGaussianProcess with z = x (one-step optimum == GPR log-likelihood, optimal sites), with z != x
+    against the oracle, and ConditionalProcess.predict_f at new time points (posterior.py / conditionals.py)."""
+    from oracle import np_conditionals as npc, np_kernels
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
+    mk = {"m12": (lambda m: m.Matern12(0.3, 1.5)), "m32sum": (lambda m: m.Sum([m.Matern32(0.4, 1.0), m.Matern12(0.7, 0.5)]))}[kname]
+    N = 12
+    t = np.linspace(0, 1, N)
+    y = (np.cos(20 * t) + rng.normal(size=N)).reshape(-1, 1)
+    g = SparseCVIGaussianProcess(mk(K), dev(t), Gaussian(1.0), learning_rate=1.0)
+    g.update_sites((dev(t), dev(y)))
+    sd = mk(K).state_dim
+    ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), 1.0)
+    np.testing.assert_allclose(float(g.classic_elbo((dev(t), dev(y)))), ref, rtol=1e-6)
+    if kname == "m12":
+        np.testing.assert_allclose(host(g.nat1)[:-1, sd:], y, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(host(g.nat2)[:-1, sd:, sd:], -0.5 * np.ones((N, 1, 1)), rtol=1e-8)
+    # inducing points different from the data, damped updates: follow the oracle
+    z = np.linspace(-0.1, 1.1, 7)
+    g2 = SparseCVIGaussianProcess(mk(K), dev(z), Gaussian(0.5), learning_rate=0.6)
+    o2 = npc.SparseCVIGaussianProcess(mk(np_kernels), z, np_models.GaussianLik(0.5), learning_rate=0.6)
+    prev = -np.inf
+    for _ in range(3):
+        g2.update_sites((dev(t), dev(y)))
+        o2.update_sites(t, y)
+        e = float(g2.classic_elbo((dev(t), dev(y))))
+        np.testing.assert_allclose(e, o2.classic_elbo(t, y), rtol=1e-6)
+        assert e > prev - 1e-9
+        prev = e
+    tn = np.sort(rng.uniform(-0.3, 1.3, size=9))
+    mu, var = g2.posterior.predict_f(dev(tn))
+    omu, ovar = npc.predict_f(o2.dist_q, mk(np_kernels), z, tn)
+    assert_close(host(mu), omu)
+    assert_close(host(var), ovar)

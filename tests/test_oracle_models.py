@@ -119,3 +119,30 @@ def test_cvi_gp_one_step_optimum(rng):
     np.testing.assert_allclose(gpr, dense, rtol=1e-9)
     np.testing.assert_allclose(m.elbo(), gpr, rtol=1e-8)
     np.testing.assert_allclose(m.classic_elbo(), gpr, rtol=1e-7)
+
+
+def test_sparse_cvi_and_conditionals(rng):
+    """KA8 (reference tests/integration/models/test_sparse_variational_cvi.py:88-155): with z = x and a Gaussian likelihood,
+    one update_sites(lr=1) gives sites (y, -1/2)/sigma^2 in the second half-blocks and classic_elbo == GPR log-likelihood;
+    predict_f between the points matches dense GP regression."""
+    from oracle import np_conditionals as npc, np_kernels
+    N = 12
+    t = np.linspace(0, 1, N)
+    y = (np.cos(20 * t) + rng.normal(size=N)).reshape(-1, 1)
+    k = np_kernels.Matern12(lengthscale=0.3, variance=1.5)
+    m = npc.SparseCVIGaussianProcess(k, t, np_models.GaussianLik(1.0), learning_rate=1.0)
+    m.update_sites(t, y)
+    sd = 1
+    np.testing.assert_allclose(m.nat1[:-1, sd:], y, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(m.nat2[:-1, sd:, sd:], -0.5 * np.ones((N, 1, 1)), rtol=1e-9)
+    gpr = np_models.gpr_log_likelihood(t, y, k, 1.0)
+    np.testing.assert_allclose(m.classic_elbo(t, y), gpr, rtol=1e-7)
+    # prediction at new points against dense GP regression with the Matern-1/2 covariance
+    tn = np.sort(rng.uniform(-0.2, 1.2, size=7))
+    kern = lambda a, b: 1.5 * np.exp(-np.abs(a[:, None] - b[None, :]) / 0.3)
+    Kxx = kern(t, t) + np.eye(N)
+    mu_ref = kern(tn, t) @ np.linalg.solve(Kxx, y[:, 0])
+    var_ref = 1.5 - np.einsum("ij,ji->i", kern(tn, t), np.linalg.solve(Kxx, kern(t, tn)))
+    mu, var = npc.predict_f(m.dist_q, k, t, tn)
+    np.testing.assert_allclose(mu[:, 0], mu_ref, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(var[:, 0], var_ref, rtol=1e-6, atol=1e-8)

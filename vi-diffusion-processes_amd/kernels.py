@@ -111,6 +111,43 @@ class StationaryKernel:
     def state_transitions(self, transition_times, time_deltas):
         return self.transition_statistics(transition_times, time_deltas)[0]
 
+    def transition_statistics_local(self, time_deltas):
+        """
+        (A, Q) for arbitrary, unordered time gaps (any shape [...]) as per-element closed forms in torch: used by the
+        conditionals (prediction between conditioning points, conditionals.py:207-256), which are embarrassingly parallel
+        over query points.  Same formulas as k_stationary_ssm.
+        """
+        dt = time_deltas[..., None, None]
+        blocks = []
+        for order, lam, var in self._components():
+            ex = torch.exp(-lam * dt)
+            if order == 1:
+                blocks.append(ex * torch.ones((1, 1), dtype=dt.dtype, device=dt.device))
+            elif order == 2:
+                N = torch.tensor([[lam, 1.0], [-lam ** 2, -lam]], dtype=dt.dtype, device=dt.device)
+                blocks.append(ex * (torch.eye(2, dtype=dt.dtype, device=dt.device) + N * dt))
+            else:
+                N = torch.tensor([[lam, 1.0, 0.0], [0.0, lam, 1.0], [-lam ** 3, -3.0 * lam ** 2, -2.0 * lam]], dtype=dt.dtype,
+                                 device=dt.device)
+                blocks.append(ex * (torch.eye(3, dtype=dt.dtype, device=dt.device) + N * dt + (N @ N) * (0.5 * dt * dt)))
+        d = self.state_dim
+        A = torch.zeros(tuple(time_deltas.shape) + (d, d), dtype=dt.dtype, device=dt.device)
+        o = 0
+        for blk in blocks:
+            k = blk.shape[-1]
+            A[..., o:o + k, o:o + k] = blk
+            o += k
+        Pinf = self.steady_state_covariance.to(dt.device)
+        Q = Pinf - A @ Pinf @ A.transpose(-1, -2) + self.jitter * torch.eye(d, dtype=dt.dtype, device=dt.device)
+        return A, Q
+
+    def initial_mean(self, batch_shape=()):
+        return self.state_mean.expand(tuple(batch_shape) + (self.state_dim,))
+
+    def initial_covariance_matrix(self):
+        """Pinf + jitter (sde_kernel.py:402-419)."""
+        return self.steady_state_covariance + self.jitter * torch.eye(self.state_dim, dtype=torch.float64)
+
     def generate_emission_model(self, time_points):
         """H = [1, 0, ...] per component, tiled over the time points (sde_kernel.py:173-211, 670-687)."""
         h = torch.zeros((1, self.state_dim), dtype=torch.float64, device=time_points.device)
