@@ -117,18 +117,31 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
 #pragma unroll
     for (int e = 0; e < D; ++e) rho[e] = 0.0;
 
-    // Loads of a step are issued at its top and consumed in its second half (S after the spike solve,
-    // D and r at the very end), so their latency hides under the step's own arithmetic and no second
-    // register buffer is needed.  Scales / corrections are applied at the point of use, never at the load.
+    // Cross-iteration register prefetch: the raw blocks of step s+1 are requested at the top of step s and consumed one
+    // iteration later; scales / corrections are applied at the point of use, never at the load.  (Level >= 1 keeps the
+    // simpler same-step loads: the correction arrays would not fit the register file next to a second buffer.)
+    double Gn[EF], Dn[ET], rn[D];
+    auto load_step = [&](int s, double (&Go)[EF], double (&Do)[ET], double (&ro)[D]) {
+        ld_node<EF>(a.Sg, R, s, me, Go);
+        ld_node<ET>(a.Dg, R, s + 1, me, Do);
+        if (HAS_RHS) ld_node<D>(a.rg, R, s + 1, me, ro);
+    };
+    if (!HAS_CORR && len > 1) load_step(0, Gn, Dn, rn);
     for (int s = 0; s < R - 1; ++s) {
         if (s < len - 1) {
-            double G[EF], Dn[ET], rn[D], Dc[HAS_CORR ? ET : 1], rc[HAS_CORR ? D : 1];
-            ld_node<EF>(a.Sg, R, s, me, G);
-            ld_node<ET>(a.Dg, R, s + 1, me, Dn);
-            if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, R, s + 1, me, reinterpret_cast<double(&)[ET]>(Dc));
-            if (HAS_RHS) {
-                ld_node<D>(a.rg, R, s + 1, me, rn);
-                if constexpr (HAS_CORR) ld_node<D>(a.rcorr, R, s + 1, me, reinterpret_cast<double(&)[D]>(rc));
+            double G[EF], Dc_[ET], rc_[D], Dcur[ET], rcur[D];
+            if (HAS_CORR) {
+                load_step(s, G, Dcur, rcur);
+                ld_node<ET>(a.Dcorr, R, s + 1, me, Dc_);
+                if (HAS_RHS) ld_node<D>(a.rcorr, R, s + 1, me, rc_);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EF; ++e) G[e] = Gn[e];
+#pragma unroll
+                for (int e = 0; e < ET; ++e) Dcur[e] = Dn[e];
+#pragma unroll
+                for (int e = 0; e < D; ++e) rcur[e] = HAS_RHS ? rn[e] : 0.0;
+                if (s + 1 < len - 1) load_step(s + 1, Gn, Dn, rn);
             }
             // eliminate interior node s
             double invd[D];
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
             // Schur complement onto node s+1
             syrk_set<D>(G, F);
 #pragma unroll
-            for (int e = 0; e < ET; ++e) F[e] = __builtin_fma(a.aD, Dn[e], -F[e]) - (HAS_CORR ? Dc[e] : 0.0);
+            for (int e = 0; e < ET; ++e) F[e] = __builtin_fma(a.aD, Dcur[e], -F[e]) - (HAS_CORR ? Dc_[e] : 0.0);
 #pragma unroll
             for (int c = 0; c < D; ++c) {          // W := -G W, column by column in place
                 double col[D];
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
                 double t[D];
                 gemv<D>(G, h, t);
 #pragma unroll
-                for (int e = 0; e < D; ++e) h[e] = __builtin_fma(a.aR, rn[e], -t[e]) - (HAS_CORR ? rc[e] : 0.0);
+                for (int e = 0; e < D; ++e) h[e] = __builtin_fma(a.aR, rcur[e], -t[e]) - (HAS_CORR ? rc_[e] : 0.0);
             }
         }
     }

@@ -79,6 +79,7 @@ class CVISitesSSM:
             self.fx_mus_obs = pl.gather_nodes(VEC, self._path[0], self.obs_node_ids)
             self.fx_covs_obs = pl.gather_nodes(SYM, self._path[1], self.obs_node_ids)
         self._theta_q = PackedBTDNat(pl.empty(VEC), pl.empty(SYM), pl.empty(FULL))
+        self._started = False
         self._bufs = dict(f={}, s={})
         self._q = None          # cached posterior refresh (factor + selected inverse) for the current sites
         self.dist_p = None
@@ -190,9 +191,17 @@ class CVISitesSSM:
     def _obs_flat(self):
         return self._observations.reshape(self.B * self.n_obs, self.state_dim)
 
+    def _obs_marginals(self):
+        """(mu, Sigma) at the observation times for the current sites (the reference's self.fx_mus / fx_covs gathered)."""
+        if self._started and not getattr(self, "_obs_fresh", False):
+            self._gather_obs()
+        return self.fx_mus_obs, self.fx_covs_obs
+
     def update_data_sites(self, lr: float):
         """theta_data <- (1-lr) theta_data + lr dVE/d(eta) at the current marginals (variational_cvi_sde.py:301-317)."""
-        g1, g2 = self.likelihood.ve_gradients_expectation(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
+        mu_o, cov_o = self._obs_marginals()
+        self._started = True      # before the first update the marginals are those of the initial posterior path
+        g1, g2 = self.likelihood.ve_gradients_expectation(mu_o, cov_o, self._obs_flat())
         new1 = (1 - lr) * self.data_nat1 + lr * g1
         new2 = (1 - lr) * self.data_nat2 + lr * g2
         tq = self.full_sites()
@@ -200,7 +209,7 @@ class CVISitesSSM:
         self.plan.scatter_nodes(SYM, tq.diag, self.obs_node_ids, new2 - self.data_nat2, accumulate=True)
         self.data_nat1, self.data_nat2 = new1, new2
         self._q = None
-        self._gather_obs()
+        self._obs_fresh = False   # marginals at the observation times are gathered lazily, when next needed
 
     def grad_kl_wrt_exp_param(self):
         """
@@ -223,7 +232,8 @@ class CVISitesSSM:
         pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=lr)
         pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=lr)
         self._q = None
-        self._gather_obs()
+        self._obs_fresh = False
+        self._started = True
 
     # -- objective -----------------------------------------------------------------------------------------
     def variational_expectation(self):
@@ -349,7 +359,8 @@ class CVISitesSDE(CVISitesSSM):
         pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=lr)
         pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=lr)
         self._q = None
-        self._gather_obs()
+        self._obs_fresh = False
+        self._started = True
 
 
 def tranform_girsanov_sites(plan, girsanov_sites, current_prior_nat, new_prior_nat):
