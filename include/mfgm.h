@@ -41,7 +41,11 @@ typedef struct mfgm_plan mfgm_plan;
 
 /* Partition plan for B chains of T nodes with d x d blocks.  R0 = nodes per lane segment at the finest
  * level (0 = choose so that about 64 Ki lanes exist), Rup = segment length of the coarser levels (0 = 8).
- * Supported d: 1..8. */
+ * Supported d: 1..32.  d <= 8 runs the lane-per-segment kernels on the packed wave-tiled layout; 8 < d <= 32 runs the
+ * wavefront-per-segment ("wide") kernels, for which the "packed" arrays are simply the natural [B, T, d*d] / [B, T, d]
+ * arrays (mfgm_pack / mfgm_unpack then only symmetrise / zero-fill) and R0 = 0 chooses about 8 Ki segments.  The wide
+ * path covers pack/unpack, factor, selinv, lincomb, node_io, ssm_to_naturals and kl_terms; the SDE / VDP / stationary-
+ * kernel entry points return 1 for d > 8. */
 int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out);
 void mfgm_plan_destroy(mfgm_plan* plan);
 /* out[0..5] = nlevels, R (level 0), P (level 0), Lpad (level 0), B, T */
@@ -229,6 +233,16 @@ int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, 
                              double* Sub, double* x, void* ws, void* stream);
 
 const char* mfgm_version(void);
+
+/* ---- batched small dense SPD algebra on natural-layout arrays -----------------------------------------------------------
+ * The per-time-step algebra around the sweeps that has no fused kernel of its own: replaces the reference's
+ * tf.linalg.cholesky / tf.linalg.cholesky_solve / tf.linalg.triangular_solve calls on [..., d, d] blocks
+ * (ssm_gaussian_transformations.py:93-178, 459-511, 515-593; conditionals.py:207-256; kalman_filter.py:298-345).
+ * A: [N, d, d] SPD (lower triangle read) -> L: [N, d, d] lower (upper zero); a non-positive pivot sets *info.  d <= 32. */
+int mfgm_batched_cholesky(int N, int d, const double* A, double* L, int* info, void* stream);
+/* X = L^{-1} B (mode 1), L^{-T} B (mode 2) or (L L^T)^{-1} B (mode 3) for B, X: [N, d, m]; L: [lbatch, d, d] with
+ * lbatch = N or 1 (one factor shared by the whole batch).  X may alias B. */
+int mfgm_batched_trsm(int N, int d, int m, int lbatch, const double* L, const double* B, double* X, int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,5 +48,9 @@ def test_plan_creation_and_argument_checks_need_no_gpu():
     assert lib.mfgm_packed_doubles(h, 2) == desc[1] * 21 * desc[3]
     lib.mfgm_plan_destroy(h)
     # unsupported block size and bad arguments are reported, not crashed on
-    assert lib.mfgm_plan_create(1, 10, 9, 0, 0, ctypes.byref(h)) == 1
+    assert lib.mfgm_plan_create(1, 10, 33, 0, 0, ctypes.byref(h)) == 1
+    # 8 < d <= 32 takes the wide path on natural-layout arrays
+    assert lib.mfgm_plan_create(2, 100, 16, 0, 0, ctypes.byref(h)) == 0
+    assert lib.mfgm_packed_doubles(h, 2) == 2 * 100 * 256 and lib.mfgm_packed_doubles(h, 0) == 2 * 100 * 16
+    lib.mfgm_plan_destroy(h)
     assert lib.mfgm_plan_create(0, 10, 3, 0, 0, ctypes.byref(h)) == 1

@@ -1,0 +1,94 @@
+"""
+GPU parity tests for the batched small dense SPD algebra (mfgm_batched_cholesky / mfgm_batched_trsm through
+vidp_amd.linalg) against NumPy/LAPACK on the same seeded inputs; tolerance 1e-12 relative (same arithmetic, IEEE sqrt / div).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(x):
+    return x.detach().cpu().numpy()
+
+
+def spd(rng, shape, d):
+    a = rng.normal(size=shape + (d, d))
+    return a @ np.swapaxes(a, -1, -2) + d * np.eye(d)
+
+
+@pytest.mark.parametrize("shape,d", [((), 1), ((5,), 3), ((2, 7), 6), ((300,), 8), ((3,), 17), ((2,), 32), ((0,), 4)])
+def test_cholesky_and_solves(rng, shape, d):
+    from vidp_amd import linalg
+    A = spd(rng, shape, d)
+    L = host(linalg.cholesky(dev(A)))
+    ref = np.linalg.cholesky(A) if A.size else A
+    np.testing.assert_allclose(L, ref, rtol=1e-12, atol=1e-13)
+    assert np.all(np.triu(L, 1) == 0)
+    for m in (1, d, 3):
+        B = rng.normal(size=shape + (d, m))
+        X = host(linalg.cholesky_solve(dev(B), dev(ref)))
+        np.testing.assert_allclose(X, np.linalg.solve(A, B) if A.size else B, rtol=1e-10, atol=1e-12)
+        Y = host(linalg.solve_lower(dev(ref), dev(B)))
+        np.testing.assert_allclose(ref @ Y, B, rtol=1e-10, atol=1e-11)
+        Z = host(linalg.solve_lower_t(dev(ref), dev(B)))
+        np.testing.assert_allclose(np.swapaxes(ref, -1, -2) @ Z, B, rtol=1e-10, atol=1e-11)
+    v = rng.normal(size=shape + (d,))
+    np.testing.assert_allclose(host(linalg.cholesky_solve(dev(v), dev(ref))),
+                               np.linalg.solve(A, v[..., None])[..., 0] if A.size else v, rtol=1e-10, atol=1e-12)
+    if A.size:
+        np.testing.assert_allclose(host(linalg.spd_inverse(dev(A))), np.linalg.inv(A), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(host(linalg.logdet_spd(dev(A))), np.linalg.slogdet(A)[1], rtol=1e-12)
+
+
+def test_broadcast_and_views(rng):
+    """one shared factor against a batch of right-hand sides, broadcast batch dims, and non-contiguous views."""
+    import torch
+    from vidp_amd import linalg
+    d = 5
+    A = spd(rng, (), d)
+    L = np.linalg.cholesky(A)
+    B = rng.normal(size=(4, 9, d, 2))
+    np.testing.assert_allclose(host(linalg.cholesky_solve(dev(B), dev(L))), np.linalg.solve(A, B), rtol=1e-10)
+    Ab = spd(rng, (9,), d)
+    Lb = np.linalg.cholesky(Ab)
+    np.testing.assert_allclose(host(linalg.cholesky_solve(dev(B), dev(Lb))), np.linalg.solve(Ab[None], B), rtol=1e-10)
+    # column-major / strided views
+    Bt = dev(np.swapaxes(B, -1, -2).copy()).transpose(-1, -2)
+    assert not Bt.is_contiguous()
+    np.testing.assert_allclose(host(linalg.cholesky_solve(Bt, dev(Lb)[:, :, :])), np.linalg.solve(Ab[None], B), rtol=1e-10)
+    sl = dev(Lb)[1:]
+    np.testing.assert_allclose(host(linalg.cholesky_solve(dev(B[:, 1:]), sl)), np.linalg.solve(Ab[None, 1:], B[:, 1:]), rtol=1e-10)
+    eye = torch.eye(d, dtype=torch.float64, device="cuda").expand(9, d, d)
+    np.testing.assert_allclose(host(linalg.cholesky_solve(eye, dev(Lb))), np.linalg.inv(Ab), rtol=1e-10)
+
+
+def test_not_positive_definite(rng):
+    from vidp_amd import linalg
+    A = spd(rng, (6,), 4)
+    A[3] = -A[3]
+    with pytest.raises(ArithmeticError):
+        linalg.cholesky(dev(A))
+    L = linalg.cholesky(dev(A), check=False)      # no raise, no sync: the bad block is flagged only
+    assert np.isfinite(host(L)).all()
+
+
+def test_stiff_no_smoothing_round_trip(rng):
+    """The two-component Matern-5/2 case on which the vendor batched LAPACK behind torch.linalg mis-solved
+    (tools/diag/acc_diag8.py): natural parameters -> SSM parameters, per-step maps only."""
+    import torch
+    from oracle import np_kernels, np_transforms
+    from vidp_amd import ssm_gaussian_transformations as tr
+    okern = np_kernels.Sum([np_kernels.Matern52(lengthscale=0.01, variance=0.01) for _ in range(2)])
+    ossm = okern.state_space_model(np.linspace(0, 1, 1001))
+    tho = np_transforms.ssm_to_naturals_no_smoothing(ossm)
+    ref = (ossm.A, ossm.b, ossm.cholP0, ossm.cholQ, ossm.mu0)
+    for rep in range(3):
+        back = tr.naturals_to_ssm_params_no_smoothing(*[dev(x) for x in tho])
+        for a, b in zip(back, ref):
+            np.testing.assert_allclose(host(a), b, rtol=1e-7, atol=1e-6)

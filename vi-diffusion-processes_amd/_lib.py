@@ -50,6 +50,8 @@ EXPORTS = {
     "mfgm_btd_cholesky": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),
     "mfgm_btd_posterior": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 7),
     "mfgm_packed_kl_terms": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
+    "mfgm_batched_cholesky": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4),
+    "mfgm_batched_trsm": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
 }
 
 

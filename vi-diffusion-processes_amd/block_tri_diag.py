@@ -5,6 +5,7 @@ tensors with the reference's ``[... outer_dim, inner_dim, inner_dim]`` shapes.
 """
 import torch
 
+from . import linalg
 from ._lib import FULL, SYM, TRI, VEC
 from .packed import Plan
 from .state_space_model import _flat
@@ -184,7 +185,7 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         ssm = naturals_to_ssm_params_packed(pl, pl.zeros(VEC), td, ts)
         chols = torch.cat([ssm._cholP0[:, None], ssm._cholQ], dim=1)
         eye = torch.eye(self.inner_dim, dtype=chols.dtype, device=chols.device).expand(chols.shape)
-        chol_d = torch.linalg.cholesky(torch.cholesky_solve(eye, chols))
+        chol_d = linalg.cholesky(linalg.spd_inverse(chol=chols))
         u_s = -ssm._A
         identities = eye.contiguous()
         return (LowerTriangularBlockTriDiagonal(self._unflat(identities), self._unflat(u_s), plan=pl),

@@ -2,9 +2,11 @@
 Host-side mirror of markovflow/conditionals.py: prediction between conditioning points (`conditional_statistics`,
 `_conditional_statistics_from_transitions`, `conditional_predict`, `base_conditional_predict`, `pairwise_marginals`;
 conditionals.py:29-470).  Every query point is independent: these are batched d x d torch operations on the device,
-fed by the marginal / cross-covariance blocks of the HIP sweeps.
+fed by the marginal / cross-covariance blocks of the HIP sweeps (factorisations and solves through vidp_amd.linalg).
 """
 import torch
+
+from . import linalg
 
 APPROX_INF = 1e10   # markovflow/base.py:46
 
@@ -17,14 +19,13 @@ def _conditional_statistics_from_transitions(A_mt, Q_mt, A_tp, Q_tp, return_prec
     """p(x_t | x_-, x_+) = N(D x_- + E x_+, T) from the two transitions around t (conditionals.py:111-204)."""
     A_tp_Q_mt = A_tp @ Q_mt
     Q_mp = Q_tp + A_tp @ _T(A_tp_Q_mt)
-    chol = torch.linalg.cholesky(Q_mp)
-    Linv = torch.linalg.solve_triangular(chol, A_tp_Q_mt, upper=False)
-    E = _T(torch.linalg.solve_triangular(_T(chol), Linv, upper=True))
+    chol = linalg.cholesky(Q_mp)
+    Linv = linalg.solve_lower(chol, A_tp_Q_mt)
+    E = _T(linalg.solve_lower_t(chol, Linv))
     D = A_mt - E @ A_tp @ A_mt
     if return_precision:
-        eye = torch.eye(A_mt.shape[-1], dtype=A_mt.dtype, device=A_mt.device).expand(Q_mt.shape)
-        Q_mt_inv = torch.cholesky_solve(eye, torch.linalg.cholesky(Q_mt))
-        LA = torch.linalg.solve_triangular(torch.linalg.cholesky(Q_tp), A_tp, upper=False)
+        Q_mt_inv = linalg.spd_inverse(Q_mt)
+        LA = linalg.solve_lower(linalg.cholesky(Q_tp), A_tp)
         return D, E, Q_mt_inv + _T(LA) @ LA
     return D, E, Q_mt - _T(Linv) @ Linv
 

@@ -14,6 +14,8 @@
 #include "mfgm_local.h"
 #include "mfgm_sde.h"
 #include "mfgm_vdp.h"
+#include "mfgm_wide.h"
+#include "mfgm_batched.h"
 
 using namespace mfgm;
 
@@ -186,6 +188,109 @@ int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double*
     return 0;
 }
 
+// ---- wide (8 < d <= 32) drivers: same level recursion, one wavefront per segment ------------------------------------
+template <int DM>
+int wide_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
+    dim3 grid(a.lv.L), block(64);
+#define KW(K) hipLaunchKernelGGL((K), grid, block, 0, st, a)
+    if (which == 0) {
+        if (has_rhs) { if (has_corr) KW((kw_reduce<DM, true, true>)); else KW((kw_reduce<DM, true, false>)); }
+        else { if (has_corr) KW((kw_reduce<DM, false, true>)); else KW((kw_reduce<DM, false, false>)); }
+    } else if (which == 1) {
+        if (has_rhs) {
+            if (has_corr) { if (has_up) KW((kw_forward<DM, true, true, true>)); else KW((kw_forward<DM, true, true, false>)); }
+            else { if (has_up) KW((kw_forward<DM, true, false, true>)); else KW((kw_forward<DM, true, false, false>)); }
+        } else {
+            if (has_corr) { if (has_up) KW((kw_forward<DM, false, true, true>)); else KW((kw_forward<DM, false, true, false>)); }
+            else { if (has_up) KW((kw_forward<DM, false, false, true>)); else KW((kw_forward<DM, false, false, false>)); }
+        }
+    } else {
+        if (has_rhs) {
+            if (has_up) { if (want_sub) KW((kw_backward<DM, true, true, true>)); else KW((kw_backward<DM, true, true, false>)); }
+            else { if (want_sub) KW((kw_backward<DM, true, false, true>)); else KW((kw_backward<DM, true, false, false>)); }
+        } else {
+            if (has_up) { if (want_sub) KW((kw_backward<DM, false, true, true>)); else KW((kw_backward<DM, false, true, false>)); }
+            else { if (want_sub) KW((kw_backward<DM, false, false, true>)); else KW((kw_backward<DM, false, false, false>)); }
+        }
+    }
+#undef KW
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wide_dispatch(int d, int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
+    if (d <= 16) return wide_launch<16>(which, a, has_rhs, has_corr, has_up, want_sub, st);
+    return wide_launch<32>(which, a, has_rhs, has_corr, has_up, want_sub, st);
+}
+
+void wide_bind(const Plan& P, int l, double* ws, WideArgs& a) {
+    const int K = P.nlevels - 1;
+    a.lv = P.lv[l];
+    a.d = P.d;
+    if (l > 0) {
+        a.Dg = ws + P.off_Dhat[l]; a.Dcorr = ws + P.off_Rsub[l]; a.Sg = ws + P.off_S[l];
+        a.rg = ws + P.off_rhat[l]; a.rcorr = ws + P.off_rho[l];
+        a.aD = a.aS = a.aR = 1.0;
+        a.Lg = ws + P.off_L[l]; a.Gg = ws + P.off_G[l]; a.yg = ws + P.off_y[l];
+        a.Sigg = ws + P.off_Sig[l]; a.Subg = nullptr; a.mug = ws + P.off_mu[l];
+    }
+    if (l < K) {
+        a.up = P.lv[l + 1];
+        a.uDhat = ws + P.off_Dhat[l + 1]; a.uRsub = ws + P.off_Rsub[l + 1]; a.uS = ws + P.off_S[l + 1];
+        a.urhat = ws + P.off_rhat[l + 1]; a.urho = ws + P.off_rho[l + 1];
+        a.uL = ws + P.off_L[l + 1]; a.uy = ws + P.off_y[l + 1]; a.uSig = ws + P.off_Sig[l + 1]; a.umu = ws + P.off_mu[l + 1];
+    }
+}
+
+int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
+                double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st) {
+    const bool has_rhs = (rg != nullptr);
+    const int K = P.nlevels - 1;
+    auto make = [&](int l) {
+        WideArgs a;
+        memset(&a, 0, sizeof(a));
+        a.info = info;
+        if (l == 0) {
+            a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
+            a.Lg = Lg; a.Gg = Gg; a.yg = yg;
+            a.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
+        }
+        wide_bind(P, l, ws, a);
+        return a;
+    };
+    for (int l = 0; l < K; ++l) {
+        int rc = wide_dispatch(P.d, 0, make(l), has_rhs, l > 0, true, false, st);
+        if (rc) return rc;
+    }
+    for (int l = K; l >= 0; --l) {
+        int rc = wide_dispatch(P.d, 1, make(l), has_rhs, l > 0, l < K, false, st);
+        if (rc) return rc;
+    }
+    if (logdet || quad) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub, double* x,
+                double* ws, hipStream_t st) {
+    const bool has_rhs = (yg != nullptr);
+    const int K = P.nlevels - 1;
+    for (int l = K; l >= 0; --l) {
+        WideArgs a;
+        memset(&a, 0, sizeof(a));
+        if (l == 0) {
+            a.Lg = const_cast<double*>(Lg); a.Gg = const_cast<double*>(Gg); a.yg = const_cast<double*>(yg);
+            a.Sigg = Sig; a.Subg = Sub; a.mug = x;
+        }
+        wide_bind(P, l, ws, a);
+        int rc = wide_dispatch(P.d, 2, a, has_rhs, false, l < K, l == 0 && Sub != nullptr, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -193,18 +298,20 @@ extern "C" {
 const char* mfgm_version(void) { return "mfgm 0.1 (gfx950)"; }
 
 int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
-    if (!out || B < 1 || T < 1 || d < 1 || d > 8) return 1;
+    if (!out || B < 1 || T < 1 || d < 1 || d > 32) return 1;
     mfgm_plan* h = new mfgm_plan();
     Plan& P = h->p;
     memset(&P, 0, sizeof(P));
     P.B = B; P.T = T; P.d = d;
+    P.wide = (d > 8);
     if (Rup <= 1) Rup = 8;   // measured best on MI355X for the coarse levels (tools/sweep_partition.sh)
     if (const char* e = getenv("MFGM_RUP")) { int v = atoi(e); if (v > 1) Rup = v; }
     if (R0 <= 0) {
         if (const char* e = getenv("MFGM_R0")) R0 = atoi(e);
     }
     if (R0 <= 0) {
-        const long long target = 65536;  // ~ one wavefront per SIMD on 256 CUs
+        // narrow: one lane per segment, ~ one wavefront per SIMD on 256 CUs; wide: one wavefront per segment
+        const long long target = P.wide ? 8192 : 65536;
         long long r = ((long long)B * T + target - 1) / target;
         R0 = (int)std::min<long long>(std::max<long long>(r, 8), 1 << 20);
     }
@@ -224,22 +331,22 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
         ++l;
     }
     P.nlevels = l;
-    const int ET = d * (d + 1) / 2, EF = d * d;
     size_t off = 0;
     auto take = [&](size_t nd) { size_t o = off; off += (nd + 63) / 64 * 64; return o; };
-    P.off_part[0] = take(2 * (size_t)P.lv[0].Lpad);
+    // per-segment partial sums; the wide local kernels keep one partial per node
+    P.off_part[0] = take(2 * (P.wide ? std::max<size_t>(P.lv[0].Lpad, (size_t)B * T) : (size_t)P.lv[0].Lpad));
     for (int i = 1; i < P.nlevels; ++i) {
         const LevelDesc& lv = P.lv[i];
-        P.off_Dhat[i] = take(packed_elems(lv, ET));
-        P.off_Rsub[i] = take(packed_elems(lv, ET));
-        P.off_S[i] = take(packed_elems(lv, EF));
-        P.off_rhat[i] = take(packed_elems(lv, d));
-        P.off_rho[i] = take(packed_elems(lv, d));
-        P.off_L[i] = take(packed_elems(lv, ET));
-        P.off_G[i] = take(packed_elems(lv, EF));
-        P.off_y[i] = take(packed_elems(lv, d));
-        P.off_Sig[i] = take(packed_elems(lv, ET));
-        P.off_mu[i] = take(packed_elems(lv, d));
+        P.off_Dhat[i] = take(level_elems(P, lv, 2));
+        P.off_Rsub[i] = take(level_elems(P, lv, 2));
+        P.off_S[i] = take(level_elems(P, lv, 1));
+        P.off_rhat[i] = take(level_elems(P, lv, 0));
+        P.off_rho[i] = take(level_elems(P, lv, 0));
+        P.off_L[i] = take(level_elems(P, lv, 3));
+        P.off_G[i] = take(level_elems(P, lv, 1));
+        P.off_y[i] = take(level_elems(P, lv, 0));
+        P.off_Sig[i] = take(level_elems(P, lv, 2));
+        P.off_mu[i] = take(level_elems(P, lv, 0));
     }
     P.ws_doubles = off;
     *out = h;
@@ -259,7 +366,7 @@ size_t mfgm_plan_workspace_bytes(const mfgm_plan* plan) { return plan ? plan->p.
 
 size_t mfgm_packed_doubles(const mfgm_plan* plan, int kind) {
     if (!plan || kind < 0 || kind > 3) return 0;
-    return packed_elems(plan->p.lv[0], kind_epack(kind, plan->p.d));
+    return level_elems(plan->p, plan->p.lv[0], kind);
 }
 
 static int repack(const mfgm_plan* plan, int kind, const double* src, double* dst, int n_nodes, bool pack, void* stream) {
@@ -268,6 +375,14 @@ static int repack(const mfgm_plan* plan, int kind, const double* src, double* ds
     if (n_nodes < 0 || n_nodes > P.T) return 1;
     const LevelDesc& lv = P.lv[0];
     const int En = kind_enat(kind, P.d);
+    if (P.wide) {
+        const size_t total = (size_t)P.B * (pack ? P.T : n_nodes) * En;
+        if (total == 0) return 0;
+        int blocks = (int)std::min<size_t>((total + 255) / 256, 16384);
+        hipLaunchKernelGGL(kw_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, P.B, P.T, P.d, kind, n_nodes, pack);
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
     int CH = std::max(1, 64 / En);
     CH = std::min(CH, lv.R);
     dim3 grid(lv.Lpad / 64, ceil_div(lv.R, CH)), block(256);
@@ -308,6 +423,12 @@ int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed
     const size_t total = (size_t)n * kind_enat(kind, P.d);
     if (total >= (1ull << 32)) return 1;
     int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    if (P.wide) {
+        hipLaunchKernelGGL(kw_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.d, kind, packed, packed2, node_ids, n,
+                           values, mode, scale);
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.lv[0], P.T, P.d, kind, packed, packed2,
                        node_ids, n, values, mode, scale);
     MFGM_CHECK_LAUNCH();
@@ -336,6 +457,7 @@ int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, 
     if ((r != nullptr) != (y != nullptr)) return 1;
     if (!ws && P.ws_doubles > 0) return 1;
     hipStream_t st = (hipStream_t)stream;
+    if (P.wide) return wide_factor(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, st);
     MFGM_DISPATCH_D(P.d, (factor_impl<DD>(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, st)));
 }
 
@@ -346,6 +468,7 @@ int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, 
     if ((y != nullptr) != (x != nullptr)) return 1;
     if (!ws && P.ws_doubles > 0) return 1;
     hipStream_t st = (hipStream_t)stream;
+    if (P.wide) return wide_selinv(P, L, G, y, Sig, Sub, x, (double*)ws, st);
     MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st)));
 }
 
@@ -389,6 +512,20 @@ int mfgm_packed_ssm_to_naturals(const mfgm_plan* plan, const double* A, const do
     if (P.T > 1 && !A) return 1;
     if ((lin != nullptr) != (off != nullptr)) return 1;
     hipStream_t st = (hipStream_t)stream;
+    if (P.wide) {
+        double* part = sumlogchol ? (double*)ws + P.off_part[0] : nullptr;
+        dim3 grid(P.B * P.T), block(64);
+#define S2N(DM_, LIN_) hipLaunchKernelGGL((kw_ssm_to_naturals<DM_, LIN_>), grid, block, 0, st, P.B, P.T, P.d, A, off, chol, cD, cS, lin, diag, sub, part)
+        if (P.d <= 16) { if (lin) S2N(16, true); else S2N(16, false); }
+        else { if (lin) S2N(32, true); else S2N(32, false); }
+#undef S2N
+        MFGM_CHECK_LAUNCH();
+        if (sumlogchol) {
+            hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, P.T, 0, sumlogchol, (double*)nullptr);
+            MFGM_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     MFGM_DISPATCH_D(P.d, (s2n_impl<DD>(P, A, off, chol, cD, cS, lin, diag, sub, sumlogchol, (double*)ws, st)));
 }
 
@@ -398,6 +535,14 @@ int mfgm_packed_kl_terms(const mfgm_plan* plan, const double* Sig, const double*
     if (!plan || !Sig || !Sub || !mu || !Pd || !Ps || !mup || !trace || !maha || !ws) return 1;
     const Plan& P = plan->p;
     hipStream_t st = (hipStream_t)stream;
+    if (P.wide) {
+        double* part = (double*)ws + P.off_part[0];
+        hipLaunchKernelGGL(kw_kl_terms, dim3(P.B * P.T), dim3(64), 0, st, P.B, P.T, P.d, Sig, Sub, mu, Pd, Ps, aD, aS, mup, part);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, P.T, P.B * P.T, trace, maha);
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
     MFGM_DISPATCH_D(P.d, (kl_impl<DD>(P, Sig, Sub, mu, Pd, Ps, aD, aS, mup, trace, maha, (double*)ws, st)));
 }
 
@@ -648,19 +793,18 @@ struct NatWs {
 };
 NatWs carve(const Plan& P, void* nws) {
     const LevelDesc& lv = P.lv[0];
-    const int d = P.d, ET = d * (d + 1) / 2, EF = d * d;
     auto al = [](size_t n) { return (n + 63) / 64 * 64; };
     double* p = (double*)nws;
     NatWs w;
-    w.D = p; p += al(packed_elems(lv, ET));
-    w.S = p; p += al(packed_elems(lv, EF));
-    w.r = p; p += al(packed_elems(lv, d));
-    w.L = p; p += al(packed_elems(lv, ET));
-    w.G = p; p += al(packed_elems(lv, EF));
-    w.y = p; p += al(packed_elems(lv, d));
-    w.Sig = p; p += al(packed_elems(lv, ET));
-    w.Sub = p; p += al(packed_elems(lv, EF));
-    w.x = p; p += al(packed_elems(lv, d));
+    w.D = p; p += al(level_elems(P, lv, 2));
+    w.S = p; p += al(level_elems(P, lv, 1));
+    w.r = p; p += al(level_elems(P, lv, 0));
+    w.L = p; p += al(level_elems(P, lv, 3));
+    w.G = p; p += al(level_elems(P, lv, 1));
+    w.y = p; p += al(level_elems(P, lv, 0));
+    w.Sig = p; p += al(level_elems(P, lv, 2));
+    w.Sub = p; p += al(level_elems(P, lv, 1));
+    w.x = p; p += al(level_elems(P, lv, 0));
     w.ws = p;
     return w;
 }
@@ -672,9 +816,9 @@ size_t mfgm_natural_workspace_bytes(const mfgm_plan* plan) {
     if (!plan) return 0;
     const Plan& P = plan->p;
     const LevelDesc& lv = P.lv[0];
-    const int d = P.d, ET = d * (d + 1) / 2, EF = d * d;
     auto al = [](size_t n) { return (n + 63) / 64 * 64; };
-    size_t n = 3 * al(packed_elems(lv, ET)) + 3 * al(packed_elems(lv, EF)) + 3 * al(packed_elems(lv, d)) + P.ws_doubles;
+    size_t n = 2 * al(level_elems(P, lv, 2)) + al(level_elems(P, lv, 3)) + 3 * al(level_elems(P, lv, 1)) +
+               3 * al(level_elems(P, lv, 0)) + P.ws_doubles;
     return n * sizeof(double);
 }
 
@@ -712,6 +856,31 @@ int mfgm_btd_posterior(const mfgm_plan* plan, const double* diag, const double* 
     if ((rc = mfgm_unpack(plan, MFGM_SYM, w.Sig, Sdiag, P.T, stream))) return rc;
     if (want_sub && (rc = mfgm_unpack(plan, MFGM_FULL, w.Sub, Ssub, P.T - 1, stream))) return rc;
     if (rhs && (rc = mfgm_unpack(plan, MFGM_VEC, w.x, x, P.T, stream))) return rc;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- batched small dense SPD algebra (natural layout) ------------------------------------------------------------------
+extern "C" {
+
+int mfgm_batched_cholesky(int N, int d, const double* A, double* L, int* info, void* stream) {
+    if (N < 0 || d < 1 || d > 32 || !info) return 1;
+    if (N == 0) return 0;
+    if (!A || !L || A == L) return 1;
+    hipLaunchKernelGGL(k_batched_chol, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, d, A, L, info);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_batched_trsm(int N, int d, int m, int lbatch, const double* L, const double* B, double* X, int mode, void* stream) {
+    if (N < 0 || d < 1 || d > 32 || m < 1 || mode < 1 || mode > 3 || (lbatch != 1 && lbatch != N)) return 1;
+    if (N == 0) return 0;
+    if (!L || !B || !X) return 1;
+    const long long total = (long long)N * m;
+    hipLaunchKernelGGL(k_batched_trsm, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, d, m, lbatch, L, B,
+                       X, mode);
+    MFGM_CHECK_LAUNCH();
     return 0;
 }
 

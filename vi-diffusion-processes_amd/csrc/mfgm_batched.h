@@ -1,0 +1,61 @@
+// Batched small dense SPD algebra on natural-layout arrays [N, d, d] (d <= 32): Cholesky and triangular solves, one
+// thread per matrix (per right-hand-side column for the solves).  These serve the per-time-step algebra around the
+// sweeps (the reference's tf.linalg.cholesky / cholesky_solve / triangular_solve calls, e.g.
+// ssm_gaussian_transformations.py:93-178, 515-593; conditionals.py:207-256) that has no fused kernel of its own, so that
+// no part of the path depends on a vendor batched-LAPACK; sqrt and division are IEEE here (accuracy over speed).
+#pragma once
+#include "mfgm_math.h"
+
+namespace mfgm {
+
+// L = chol(A) (lower; strict upper written as zero).  A non-positive pivot sets *info and is replaced by 1.
+__global__ __launch_bounds__(128) void k_batched_chol(int N, int d, const double* __restrict__ A, double* __restrict__ L,
+                                                      int* info) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double* a = A + (size_t)n * d * d;
+    double* l = L + (size_t)n * d * d;
+    int bad = 0;
+    for (int j = 0; j < d; ++j) {
+        double s = a[j * d + j];
+        for (int k = 0; k < j; ++k) s = __builtin_fma(-l[j * d + k], l[j * d + k], s);
+        if (!(s > 0.0)) { bad = 1; s = 1.0; }
+        const double ljj = sqrt(s);
+        l[j * d + j] = ljj;
+        for (int i = 0; i < j; ++i) l[i * d + j] = 0.0;
+        for (int i = j + 1; i < d; ++i) {
+            double t = a[i * d + j];
+            for (int k = 0; k < j; ++k) t = __builtin_fma(-l[i * d + k], l[j * d + k], t);
+            l[i * d + j] = t / ljj;
+        }
+    }
+    if (bad) atomicMax(info, 1);
+}
+
+// X = op(L) B for B [N, d, m]:  mode 1: L^{-1} B,  2: L^{-T} B,  3: (L L^T)^{-1} B.  lbatch = 1 shares one L.
+__global__ __launch_bounds__(128) void k_batched_trsm(int N, int d, int m, int lbatch, const double* __restrict__ L,
+                                                      const double* __restrict__ B, double* __restrict__ X, int mode) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)N * m) return;
+    const int n = (int)(id / m), c = (int)(id - (long long)n * m);
+    const double* l = L + (lbatch == 1 ? 0 : (size_t)n * d * d);
+    const double* b = B + (size_t)n * d * m + c;
+    double* x = X + (size_t)n * d * m + c;
+    for (int i = 0; i < d; ++i) x[i * m] = b[i * m];
+    if (mode & 1) {
+        for (int i = 0; i < d; ++i) {
+            double t = x[i * m];
+            for (int k = 0; k < i; ++k) t = __builtin_fma(-l[i * d + k], x[k * m], t);
+            x[i * m] = t / l[i * d + i];
+        }
+    }
+    if (mode & 2) {
+        for (int i = d - 1; i >= 0; --i) {
+            double t = x[i * m];
+            for (int k = i + 1; k < d; ++k) t = __builtin_fma(-l[k * d + i], x[k * m], t);
+            x[i * m] = t / l[i * d + i];
+        }
+    }
+}
+
+}  // namespace mfgm

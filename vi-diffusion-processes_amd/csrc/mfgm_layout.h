@@ -29,6 +29,7 @@ constexpr int kMaxLevels = 8;
 
 struct Plan {
     int B, T, d;
+    int wide;      // d > 8: wavefront-per-segment kernels on natural-layout arrays (mfgm_wide.h)
     int nlevels;
     LevelDesc lv[kMaxLevels];
     // per-level workspace offsets (in doubles) into the plan-owned level workspace, levels >= 1
@@ -39,5 +40,11 @@ struct Plan {
 };
 
 inline size_t packed_elems(const LevelDesc& lv, int E) { return (size_t)lv.R * E * lv.Lpad; }
+// kind: 0 vector, 1 full, 2 symmetric, 3 lower triangular (include/mfgm.h)
+inline size_t level_elems(const Plan& P, const LevelDesc& lv, int kind) {
+    const int d = P.d;
+    if (P.wide) return (size_t)P.B * lv.n * (kind == 0 ? d : d * d);
+    return packed_elems(lv, kind == 0 ? d : (kind == 1 ? d * d : d * (d + 1) / 2));
+}
 
 }  // namespace mfgm

@@ -9,6 +9,7 @@ import math
 
 import torch
 
+from . import linalg
 from ._lib import FULL, SYM, TRI, VEC
 from .state_space_model import StateSpaceModel, _flat
 
@@ -24,7 +25,7 @@ class GaussianSitesNat:
 
     @property
     def means(self):
-        return -0.5 * (torch.linalg.inv(self.nat2) @ self.nat1[..., None])[..., 0]
+        return 0.5 * linalg.cholesky_solve(self.nat1, linalg.cholesky(-self.nat2))     # -1/2 nat2^{-1} nat1
 
     @property
     def precisions(self):
@@ -136,8 +137,7 @@ class KalmanFilter(BaseKalmanFilter):
             raise ValueError("The shape of the observations and the state-space-model parameters are not compatible")
         self._chol_obs_covariance = chol_obs_covariance
         self._observations = observations
-        eye = torch.eye(o, dtype=chol_obs_covariance.dtype, device=chol_obs_covariance.device)
-        self._rinv = torch.cholesky_solve(eye, chol_obs_covariance)
+        self._rinv = linalg.spd_inverse(chol=chol_obs_covariance)
 
     @property
     def _r_inv(self):
@@ -149,7 +149,7 @@ class KalmanFilter(BaseKalmanFilter):
 
     @property
     def _log_det_observation_precision(self):
-        return self.prior_ssm.T * torch.logdet(self._rinv)
+        return -2.0 * self.prior_ssm.T * torch.log(torch.diagonal(self._chol_obs_covariance)).sum()
 
 
 class KalmanFilterWithSites(BaseKalmanFilter):
@@ -171,7 +171,7 @@ class KalmanFilterWithSites(BaseKalmanFilter):
 
     @property
     def _log_det_observation_precision(self):
-        return torch.logdet(self._r_inv).sum(-1)
+        return linalg.logdet_spd(self._r_inv).sum(-1)
 
 
 class KalmanFilterWithSparseSites(BaseKalmanFilter):
@@ -214,4 +214,4 @@ class KalmanFilterWithSparseSites(BaseKalmanFilter):
 
     @property
     def _log_det_observation_precision(self):
-        return torch.logdet(self.sites.precisions).sum(-1)
+        return linalg.logdet_spd(self.sites.precisions).sum(-1)

@@ -8,10 +8,10 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, linalg
 from .emission_model import EmissionModel
 from .packed import Plan
-from .state_space_model import _flat
+from .state_space_model import StateSpaceModel, _flat
 from .variational_cvi_sde import _ssm_from_packed
 
 
@@ -92,9 +92,34 @@ class StationaryKernel:
         if plan is None:
             plan = Plan(B, T, self.state_dim, device=t.device)
         dts = (t[:, 1:] - t[:, :-1]).contiguous()
+        if self.state_dim > 8:
+            return self._state_space_model_wide(dts, bs, plan)
         A, off, chol = plan.stationary_ssm(self._spec(), dts)
         plan.check_info()
         ssm = _ssm_from_packed(plan, A, off, chol)
+        ssm.batch_shape = bs
+        return ssm
+
+    def _state_space_model_wide(self, dts, bs, plan):
+        """
+        state_dim > 8 (e.g. the reference's Sum of ten Matern-5/2, d = 30): the fused k_stationary_ssm kernel is
+        specialised for d <= 8, so this one-off model construction uses the per-element closed forms in torch
+        (block-diagonal A, Q = Pinf - A Pinf A^T + jitter, cholesky_or_zero, b = (I - A) m); the sweeps that follow
+        run in the wide HIP kernels.
+        """
+        dev = dts.device
+        d = self.state_dim
+        A, Q = self.transition_statistics_local(dts)
+        zero = (Q == 0).all(dim=-1).all(dim=-1)
+        eye = torch.eye(d, dtype=Q.dtype, device=dev)
+        chol = linalg.cholesky(torch.where(zero[..., None, None], eye, Q))
+        chol = torch.where(zero[..., None, None], torch.zeros_like(chol), chol)
+        m = self.state_mean.to(dev)
+        off = m - torch.einsum("...ij,j->...i", A, m)
+        B = dts.shape[0]
+        P0 = self.initial_covariance_matrix().to(dev)
+        ssm = StateSpaceModel(m.expand(B, d).contiguous(), linalg.cholesky(P0).expand(B, d, d).contiguous(), A, off, chol,
+                              plan=plan)
         ssm.batch_shape = bs
         return ssm
 

@@ -9,6 +9,8 @@ import math
 
 import torch
 
+from . import linalg
+
 
 class MultivariateGaussian:
     """p(y | f) = N(y; f, L L^T) (multivariate_gaussian.py:29-160)."""
@@ -16,9 +18,8 @@ class MultivariateGaussian:
     def __init__(self, chol_covariance):
         self.chol_covariance = chol_covariance
         self.obs_dim = chol_covariance.shape[-1]
-        eye = torch.eye(self.obs_dim, dtype=chol_covariance.dtype, device=chol_covariance.device)
         # one d x d inverse, reused by every call (no per-observation triangular solves)
-        self.inv_covariance = torch.cholesky_solve(eye, chol_covariance)
+        self.inv_covariance = linalg.spd_inverse(chol=chol_covariance)
         self.log_det_chol = torch.log(torch.diagonal(chol_covariance)).sum()
 
     def variational_expectations(self, f_means, f_covariances, observations):

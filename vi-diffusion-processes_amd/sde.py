@@ -34,7 +34,7 @@ class SDE:
 
     def diffusion(self, x, t=None):
         """l(x, t) = sqrt(q) (sde.py:165-176)."""
-        return torch.ones_like(x[..., None]) * torch.linalg.cholesky(self.q.to(x.device))
+        return torch.ones_like(x[..., None]) * torch.sqrt(self.q.to(x.device))     # q is diagonal (see __init__)
 
     def cubic(self, dt):
         """(alpha, beta) of the Euler map u(x) = x + dt f(x) = alpha x - beta x^3."""

@@ -7,6 +7,7 @@ step is independent d x d algebra on the selected-inverse blocks.
 """
 import torch
 
+from . import linalg
 from ._lib import FULL, SYM, TRI, VEC
 from .packed import Plan
 from .state_space_model import StateSpaceModel, _flat
@@ -17,7 +18,7 @@ def _T(x):
 
 
 def _chol_solve(L, B):
-    return torch.cholesky_solve(B, L)
+    return linalg.cholesky_solve(B, L)
 
 
 def ssm_to_expectations(ssm: StateSpaceModel):
@@ -37,11 +38,11 @@ def expectations_to_ssm_params(eta_linear, eta_diag, eta_subdiag):
     m = eta_linear[..., None]
     cov = eta_diag - m @ _T(m)
     cov_sub = _T(eta_subdiag) - m[..., :-1, :, :] @ _T(m[..., 1:, :, :])
-    chols = torch.linalg.cholesky(cov)
+    chols = linalg.cholesky(cov)
     As = _T(_chol_solve(chols[..., :-1, :, :], cov_sub))
     offsets = (m[..., 1:, :, :] - As @ m[..., :-1, :, :])[..., 0]
     cond = cov[..., 1:, :, :] - As @ (cov[..., :-1, :, :] @ _T(As))
-    return As, offsets, chols[..., 0, :, :], torch.linalg.cholesky(cond), m[..., 0, :, 0]
+    return As, offsets, chols[..., 0, :, :], linalg.cholesky(cond), m[..., 0, :, 0]
 
 
 def ssm_to_naturals(ssm: StateSpaceModel):
@@ -64,16 +65,13 @@ def ssm_to_naturals_no_smoothing(ssm: StateSpaceModel):
 def _ssm_params_from_blocks(theta_linear, pd, ps, mu, cov, cov_sub):
     """Per-step algebra of naturals_to_ssm_params (ssm_gaussian_transformations.py:459-511) given the selected inverse."""
     # A_k = (S_kk^{-1} S_{k,k+1})^T
-    As = _T(torch.linalg.solve(cov[:, :-1], _T(cov_sub)))
+    As = _T(linalg.cholesky_solve(_T(cov_sub), linalg.cholesky(cov[:, :-1])))
     low = torch.tril(pd)
     pdsym = low + _T(torch.tril(pd, -1))
     cond_prec = pdsym.clone()
     cond_prec[:, :-1] += _T(As) @ ps      # Q_k^{-1} = P_kk + A_{k+1}^T P_{k+1,k}
     cond_prec = 0.5 * (cond_prec + _T(cond_prec))
-    chol_cp = torch.linalg.cholesky(cond_prec)
-    eye = torch.eye(pd.shape[-1], dtype=pd.dtype, device=pd.device).expand(pd.shape)
-    covs = _chol_solve(chol_cp, eye)
-    chols = torch.linalg.cholesky(covs)
+    chols = linalg.cholesky(linalg.spd_inverse(cond_prec))
     # offsets: Q (A^{-T})^{-1} theta == mu_{k+1} - A_k mu_k (same quantity, no second sequential sweep)
     offsets = mu[:, 1:] - (As @ mu[:, :-1, :, None])[..., 0]
     return As, offsets, chols[:, 0], chols[:, 1:], mu[:, 0]
@@ -93,13 +91,17 @@ def naturals_to_ssm_params_packed(plan: Plan, lin, diag, sub):
     return ssm
 
 
-def naturals_to_ssm_params(theta_linear, theta_diag, theta_subdiag):
-    """ssm_gaussian_transformations.py:333-511.  Returns (As, offsets, chol_P0, chol_Qs, mu0)."""
+def naturals_to_ssm_params(theta_linear, theta_diag, theta_subdiag, plan=None):
+    """
+    ssm_gaussian_transformations.py:333-511.  Returns (As, offsets, chol_P0, chol_Qs, mu0).
+    `plan` (optional) fixes the time partition of the sweeps; `Plan(B, T, d, R0=T)` is the sequential elimination order
+    of the reference ("numerics of the partitioned sweeps").
+    """
     tl, bs = _flat(theta_linear, 2)
     td, _ = _flat(theta_diag, 3)
     ts, _ = _flat(theta_subdiag, 3)
     B, T, d = tl.shape
-    plan = Plan(B, T, d, device=tl.device)
+    plan = Plan(B, T, d, device=tl.device) if plan is None else plan
     ssm = naturals_to_ssm_params_packed(plan, plan.pack(VEC, tl), plan.pack(SYM, td), plan.pack(FULL, ts))
     return (ssm.state_transitions.reshape(bs + (T - 1, d, d)), ssm.state_offsets.reshape(bs + (T - 1, d)),
             ssm.cholesky_initial_covariance.reshape(bs + (d, d)), ssm.cholesky_process_covariances.reshape(bs + (T - 1, d, d)),
@@ -108,9 +110,8 @@ def naturals_to_ssm_params(theta_linear, theta_diag, theta_subdiag):
 
 def naturals_to_ssm_params_no_smoothing(theta_linear, theta_diag, theta_subdiag):
     """ssm_gaussian_transformations.py:515-593 (per-step independent)."""
-    c = torch.linalg.cholesky(-2.0 * theta_diag)
+    c = linalg.cholesky(-2.0 * theta_diag)
     As = _chol_solve(c[..., 1:, :, :], theta_subdiag)
     off = _chol_solve(c, theta_linear[..., None])[..., 0]
-    eye = torch.eye(c.shape[-1], dtype=c.dtype, device=c.device).expand(c.shape)
-    chols = torch.linalg.cholesky(_chol_solve(c, eye))
+    chols = linalg.cholesky(linalg.spd_inverse(chol=c))
     return As, off[..., 1:, :], chols[..., 0, :, :], chols[..., 1:, :, :], off[..., 0, :]

@@ -9,6 +9,7 @@ precision, its Cholesky and the sparse inverse on every property access).
 """
 import torch
 
+from . import linalg
 from ._lib import FULL, SYM, TRI, VEC
 from .packed import Plan
 
@@ -218,9 +219,7 @@ def _ssm_log_pdf(self, states):
     x = states.reshape((-1, self.B, T, d))
 
     def mvn(xx, mean, chol):
-        diff = (xx - mean)[..., None]
-        cinv = torch.linalg.inv(chol)            # tiny d x d triangular blocks
-        z = (cinv @ diff)[..., 0]
+        z = linalg.solve_lower(chol, xx - mean)
         logdet = torch.log(torch.abs(torch.diagonal(chol, dim1=-2, dim2=-1))).sum(-1)
         return -0.5 * (z * z).sum(-1) - logdet - 0.5 * d * math.log(2 * math.pi)
 
@@ -236,12 +235,12 @@ StateSpaceModel.log_pdf = _ssm_log_pdf
 
 def state_space_model_from_covariances(initial_mean, initial_covariance, state_transitions, state_offsets,
                                        process_covariances):
-    """state_space_model.py:613-664 (tiny d x d Cholesky factorisations: done with torch on the device)."""
+    """state_space_model.py:613-664 (per-block Cholesky factorisations through vidp_amd.linalg)."""
     def chol_or_zero(cov):
         mask = (cov == 0).all(dim=-1).all(dim=-1)
         eye = torch.eye(cov.shape[-1], dtype=cov.dtype, device=cov.device)
         fix = torch.where(mask[..., None, None], eye, torch.zeros_like(eye))
-        c = torch.linalg.cholesky(cov + fix)
+        c = linalg.cholesky(cov + fix)
         return torch.where(mask[..., None, None], torch.zeros_like(c), c)
 
     return StateSpaceModel(initial_mean, chol_or_zero(initial_covariance), state_transitions, state_offsets,

@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from . import linalg
 from ._lib import SYM, VEC
 from .variational_cvi_sde import grid_indices
 
@@ -41,9 +42,8 @@ class _Metrics:
         S = pl.gather_nodes(SYM, Sig_packed, self.node_ids)
         # likelihood.predict_mean_and_var: y* ~ N(m, S + R)
         R = lik.chol_covariance @ lik.chol_covariance.transpose(-1, -2)
-        chol = torch.linalg.cholesky(S + R)
-        diff = (self.y.reshape(B * n, d) - m)[..., None]
-        z = (torch.linalg.inv(chol) @ diff)[..., 0]
+        chol = linalg.cholesky(S + R)
+        z = linalg.solve_lower(chol, self.y.reshape(B * n, d) - m)
         logp = -0.5 * (z * z).sum(-1) - torch.log(torch.diagonal(chol, dim1=-2, dim2=-1)).sum(-1) - 0.5 * d * math.log(2 * math.pi)
         nlpd = float(-logp.mean())
         rmse = float(torch.sqrt(((m - self.y.reshape(B * n, d)) ** 2).mean()))

@@ -13,7 +13,7 @@ import math
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, linalg
 from ._lib import FULL, SYM, TRI, VEC
 from .packed import Plan, _ptr, _stream
 from .variational_cvi_sde import grid_indices
@@ -154,23 +154,23 @@ class VariationalMarkovGP:
         P0 = torch.from_numpy(self.p0_cov).to(self.device)
         mu0 = torch.from_numpy(self.p0_mu).to(self.device)
         mean = mu0 - (P0 @ lam0[..., None])[..., 0]
-        cov = torch.linalg.inv(torch.linalg.inv(P0) + 2.0 * psi0)
+        cov = linalg.spd_inverse(linalg.spd_inverse(P0) + 2.0 * psi0)
         q0_cov = self.q0_chol @ self.q0_chol.transpose(-1, -2)
         self.q0_mu = (1 - lr) * self.q0_mu + lr * mean
-        self.q0_chol = torch.linalg.cholesky((1 - lr) * q0_cov + lr * cov)
+        self.q0_chol = linalg.cholesky((1 - lr) * q0_cov + lr * cov)
 
     def KL_initial_state(self):
         """KL[q(x0) || p(x0)] per trajectory (vi_sde.py:416-420)."""
         d = self.state_dim
         P0 = torch.from_numpy(self.p0_cov).to(self.device)
         mu0 = torch.from_numpy(self.p0_mu).to(self.device)
-        P0inv = torch.linalg.inv(P0)
+        P0inv = linalg.spd_inverse(P0)
         S0 = self.q0_chol @ self.q0_chol.transpose(-1, -2)
         dm = mu0 - self.q0_mu
         tr = (P0inv * S0).sum(dim=(-1, -2))
         mh = ((dm @ P0inv) * dm).sum(-1)
         ld0 = 2.0 * torch.log(torch.diagonal(self.q0_chol, dim1=-2, dim2=-1)).sum(-1)
-        return 0.5 * (tr + mh - d + torch.logdet(P0) - ld0)
+        return 0.5 * (tr + mh - d + linalg.logdet_spd(P0) - ld0)
 
     def elbo_per_trajectory(self, mS=None):
         pl = self.plan
