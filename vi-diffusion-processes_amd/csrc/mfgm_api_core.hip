@@ -1,0 +1,266 @@
+// C-ABI entry points (include/mfgm.h): plan construction, re-layout, flat helpers, natural-layout convenience calls,
+// batched small dense algebra.
+#include "mfgm_internal.h"
+#include "mfgm_pack.h"
+#include "mfgm_wide_io.h"
+#include "mfgm_local.h"
+#include "mfgm_batched.h"
+
+using namespace mfgm;
+
+namespace {
+
+void fill_level(LevelDesc& lv, int B, int n, int R) {
+    lv.n = n;
+    lv.R = R;
+    lv.P = ceil_div(n, R);
+    lv.L = B * lv.P;
+    lv.Lpad = ceil_div(lv.L, 64) * 64;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mfgm_version(void) { return "mfgm 0.1 (gfx950)"; }
+
+int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
+    if (!out || B < 1 || T < 1 || d < 1 || d > 32) return 1;
+    mfgm_plan* h = new mfgm_plan();
+    Plan& P = h->p;
+    memset(&P, 0, sizeof(P));
+    P.B = B; P.T = T; P.d = d;
+    P.wide = (d > 8);
+    if (Rup <= 1) Rup = 8;   // measured best on MI355X for the coarse levels (tools/sweep_partition.sh)
+    if (const char* e = getenv("MFGM_RUP")) { int v = atoi(e); if (v > 1) Rup = v; }
+    if (R0 <= 0) {
+        if (const char* e = getenv("MFGM_R0")) R0 = atoi(e);
+    }
+    if (R0 <= 0) {
+        // narrow: one lane per segment, ~ one wavefront per SIMD on 256 CUs; wide: one wavefront per segment
+        const long long target = P.wide ? 8192 : 65536;
+        long long r = ((long long)B * T + target - 1) / target;
+        R0 = (int)std::min<long long>(std::max<long long>(r, 8), 1 << 20);
+    }
+    int n = T, l = 0;
+    const int top = 48;  // chains this short are swept by one lane
+    while (true) {
+        int R = (l == 0) ? R0 : Rup;
+        if (R < 2) R = 2;
+        const bool single = (n <= R) || (l > 0 && n <= top) || (l == kMaxLevels - 1);
+        if (single) {
+            fill_level(P.lv[l], B, n, n);  // one segment per chain: plain sequential sweep
+            ++l;
+            break;
+        }
+        fill_level(P.lv[l], B, n, R);
+        n = P.lv[l].P;
+        ++l;
+    }
+    P.nlevels = l;
+    size_t off = 0;
+    auto take = [&](size_t nd) { size_t o = off; off += (nd + 63) / 64 * 64; return o; };
+    // per-segment partial sums; the wide local kernels keep one partial per node
+    P.off_part[0] = take(2 * (P.wide ? std::max<size_t>(P.lv[0].Lpad, (size_t)B * T) : (size_t)P.lv[0].Lpad));
+    for (int i = 1; i < P.nlevels; ++i) {
+        const LevelDesc& lv = P.lv[i];
+        P.off_Dhat[i] = take(level_elems(P, lv, 2));
+        P.off_Rsub[i] = take(level_elems(P, lv, 2));
+        P.off_S[i] = take(level_elems(P, lv, 1));
+        P.off_rhat[i] = take(level_elems(P, lv, 0));
+        P.off_rho[i] = take(level_elems(P, lv, 0));
+        P.off_L[i] = take(level_elems(P, lv, 3));
+        P.off_G[i] = take(level_elems(P, lv, 1));
+        P.off_y[i] = take(level_elems(P, lv, 0));
+        P.off_Sig[i] = take(level_elems(P, lv, 2));
+        P.off_mu[i] = take(level_elems(P, lv, 0));
+    }
+    P.ws_doubles = off;
+    *out = h;
+    return 0;
+}
+
+void mfgm_plan_destroy(mfgm_plan* plan) { delete plan; }
+
+int mfgm_plan_describe(const mfgm_plan* plan, int* out6) {
+    if (!plan || !out6) return 1;
+    const Plan& P = plan->p;
+    out6[0] = P.nlevels; out6[1] = P.lv[0].R; out6[2] = P.lv[0].P; out6[3] = P.lv[0].Lpad; out6[4] = P.B; out6[5] = P.T;
+    return 0;
+}
+
+size_t mfgm_plan_workspace_bytes(const mfgm_plan* plan) { return plan ? plan->p.ws_doubles * sizeof(double) : 0; }
+
+size_t mfgm_packed_doubles(const mfgm_plan* plan, int kind) {
+    if (!plan || kind < 0 || kind > 3) return 0;
+    return level_elems(plan->p, plan->p.lv[0], kind);
+}
+
+static int repack(const mfgm_plan* plan, int kind, const double* src, double* dst, int n_nodes, bool pack, void* stream) {
+    if (!plan || !src || !dst || kind < 0 || kind > 3) return 1;
+    const Plan& P = plan->p;
+    if (n_nodes < 0 || n_nodes > P.T) return 1;
+    const LevelDesc& lv = P.lv[0];
+    const int En = kind_enat(kind, P.d);
+    if (P.wide) {
+        const size_t total = (size_t)P.B * (pack ? P.T : n_nodes) * En;
+        if (total == 0) return 0;
+        int blocks = (int)std::min<size_t>((total + 255) / 256, 16384);
+        hipLaunchKernelGGL(kw_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, P.B, P.T, P.d, kind, n_nodes, pack);
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
+    int CH = std::max(1, 64 / En);
+    CH = std::min(CH, lv.R);
+    dim3 grid(lv.Lpad / 64, ceil_div(lv.R, CH)), block(256);
+    size_t shmem = (size_t)64 * (CH * En + 1) * sizeof(double);
+    hipStream_t st = (hipStream_t)stream;
+    if (pack) hipLaunchKernelGGL((k_repack<true>), grid, block, shmem, st, src, dst, lv, P.d, kind, n_nodes, CH);
+    else hipLaunchKernelGGL((k_repack<false>), grid, block, shmem, st, src, dst, lv, P.d, kind, n_nodes, CH);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_pack(const mfgm_plan* plan, int kind, const double* natural, int n_nodes, double* packed, void* stream) {
+    return repack(plan, kind, natural, packed, n_nodes, true, stream);
+}
+
+int mfgm_unpack(const mfgm_plan* plan, int kind, const double* packed, double* natural, int n_nodes, void* stream) {
+    return repack(plan, kind, packed, natural, n_nodes, false, stream);
+}
+
+int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, const double* y, double c, const double* z,
+                 void* stream) {
+    if (!out || !x) return 1;
+    if (n == 0) return 0;
+    if (((uintptr_t)out | (uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15) return 1;   // 16-byte aligned flat arrays
+    const size_t n2 = n / 2 + 1;
+    int blocks = (int)std::min<size_t>((n2 + 255) / 256, 2048 * 4);
+    hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, out, a, x, b, y, c, z);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed2, const long long* node_ids, int n,
+                 double* values, int mode, double scale, void* stream) {
+    if (!plan || !packed || kind < 0 || kind > 3 || mode < 0 || mode > 2 || n < 0) return 1;
+    if (n == 0) return 0;
+    if (!node_ids || !values) return 1;
+    const Plan& P = plan->p;
+    const size_t total = (size_t)n * kind_enat(kind, P.d);
+    if (total >= (1ull << 32)) return 1;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    if (P.wide) {
+        hipLaunchKernelGGL(kw_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.d, kind, packed, packed2, node_ids, n,
+                           values, mode, scale);
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(k_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.lv[0], P.T, P.d, kind, packed, packed2,
+                       node_ids, n, values, mode, scale);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+
+}  // extern "C"
+
+// ---- natural-layout convenience entry points ---------------------------------------------------------------------------
+namespace {
+struct NatWs {
+    double *D, *S, *r, *L, *G, *y, *Sig, *Sub, *x, *ws;
+};
+NatWs carve(const Plan& P, void* nws) {
+    const LevelDesc& lv = P.lv[0];
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    double* p = (double*)nws;
+    NatWs w;
+    w.D = p; p += al(level_elems(P, lv, 2));
+    w.S = p; p += al(level_elems(P, lv, 1));
+    w.r = p; p += al(level_elems(P, lv, 0));
+    w.L = p; p += al(level_elems(P, lv, 3));
+    w.G = p; p += al(level_elems(P, lv, 1));
+    w.y = p; p += al(level_elems(P, lv, 0));
+    w.Sig = p; p += al(level_elems(P, lv, 2));
+    w.Sub = p; p += al(level_elems(P, lv, 1));
+    w.x = p; p += al(level_elems(P, lv, 0));
+    w.ws = p;
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+size_t mfgm_natural_workspace_bytes(const mfgm_plan* plan) {
+    if (!plan) return 0;
+    const Plan& P = plan->p;
+    const LevelDesc& lv = P.lv[0];
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    size_t n = 2 * al(level_elems(P, lv, 2)) + al(level_elems(P, lv, 3)) + 3 * al(level_elems(P, lv, 1)) +
+               3 * al(level_elems(P, lv, 0)) + P.ws_doubles;
+    return n * sizeof(double);
+}
+
+int mfgm_btd_cholesky(const mfgm_plan* plan, const double* diag, const double* sub, double aD, double aS, double* Ldiag,
+                      double* Lsub, double* logdet, void* nws, int* info, void* stream) {
+    if (!plan || !diag || !Ldiag || !nws || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && (!sub || !Lsub)) return 1;
+    NatWs w = carve(P, nws);
+    int rc;
+    if ((rc = mfgm_pack(plan, MFGM_SYM, diag, P.T, w.D, stream))) return rc;
+    if (P.T > 1 && (rc = mfgm_pack(plan, MFGM_FULL, sub, P.T - 1, w.S, stream))) return rc;
+    if ((rc = mfgm_packed_factor(plan, w.D, w.S, nullptr, aD, aS, 1.0, w.L, w.G, nullptr, logdet, nullptr, w.ws, info, stream))) return rc;
+    if ((rc = mfgm_unpack(plan, MFGM_TRI, w.L, Ldiag, P.T, stream))) return rc;
+    if (P.T > 1 && (rc = mfgm_unpack(plan, MFGM_FULL, w.G, Lsub, P.T - 1, stream))) return rc;
+    return 0;
+}
+
+int mfgm_btd_posterior(const mfgm_plan* plan, const double* diag, const double* sub, const double* rhs, double aD, double aS,
+                       double aR, double* logdet, double* x, double* Sdiag, double* Ssub, void* nws, int* info, void* stream) {
+    if (!plan || !diag || !Sdiag || !nws || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !sub) return 1;
+    if ((rhs != nullptr) != (x != nullptr)) return 1;
+    NatWs w = carve(P, nws);
+    int rc;
+    if ((rc = mfgm_pack(plan, MFGM_SYM, diag, P.T, w.D, stream))) return rc;
+    if (P.T > 1 && (rc = mfgm_pack(plan, MFGM_FULL, sub, P.T - 1, w.S, stream))) return rc;
+    if (rhs && (rc = mfgm_pack(plan, MFGM_VEC, rhs, P.T, w.r, stream))) return rc;
+    if ((rc = mfgm_packed_factor(plan, w.D, w.S, rhs ? w.r : nullptr, aD, aS, aR, w.L, w.G, rhs ? w.y : nullptr, logdet, nullptr,
+                                 w.ws, info, stream))) return rc;
+    const bool want_sub = (Ssub != nullptr) && P.T > 1;
+    if ((rc = mfgm_packed_selinv(plan, w.L, w.G, rhs ? w.y : nullptr, w.Sig, want_sub ? w.Sub : nullptr, rhs ? w.x : nullptr, w.ws,
+                                 stream))) return rc;
+    if ((rc = mfgm_unpack(plan, MFGM_SYM, w.Sig, Sdiag, P.T, stream))) return rc;
+    if (want_sub && (rc = mfgm_unpack(plan, MFGM_FULL, w.Sub, Ssub, P.T - 1, stream))) return rc;
+    if (rhs && (rc = mfgm_unpack(plan, MFGM_VEC, w.x, x, P.T, stream))) return rc;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- batched small dense SPD algebra (natural layout) ------------------------------------------------------------------
+extern "C" {
+
+int mfgm_batched_cholesky(int N, int d, const double* A, double* L, int* info, void* stream) {
+    if (N < 0 || d < 1 || d > 32 || !info) return 1;
+    if (N == 0) return 0;
+    if (!A || !L || A == L) return 1;
+    hipLaunchKernelGGL(k_batched_chol, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, d, A, L, info);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_batched_trsm(int N, int d, int m, int lbatch, const double* L, const double* B, double* X, int mode, void* stream) {
+    if (N < 0 || d < 1 || d > 32 || m < 1 || mode < 1 || mode > 3 || (lbatch != 1 && lbatch != N)) return 1;
+    if (N == 0) return 0;
+    if (!L || !B || !X) return 1;
+    const long long total = (long long)N * m;
+    hipLaunchKernelGGL(k_batched_trsm, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, d, m, lbatch, L, B,
+                       X, mode);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

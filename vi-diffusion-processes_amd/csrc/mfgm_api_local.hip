@@ -1,0 +1,92 @@
+// Local (per time step) kernels on packed arrays: SSM parameters -> naturals / precision, KL terms, stationary kernels.
+#include "mfgm_internal.h"
+#include "mfgm_sweeps.h"
+#include "mfgm_local.h"
+
+using namespace mfgm;
+
+namespace {
+template <int D>
+int s2n_impl(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
+             double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    double* part = sumlogchol ? ws + P.off_part[0] : nullptr;
+    if (lin) hipLaunchKernelGGL((k_ssm_to_naturals<D, true>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, A, off, chol, cD, cS, lin, diag, sub, part);
+    else hipLaunchKernelGGL((k_ssm_to_naturals<D, false>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, A, off, chol, cD, cS, lin, diag, sub, part);
+    MFGM_CHECK_LAUNCH();
+    if (sumlogchol) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, sumlogchol, (double*)nullptr);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+template <int D>
+int kl_impl(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps, double aD,
+            double aS, const double* mup, double* trace, double* maha, double* ws, hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    double* part = ws + P.off_part[0];
+    hipLaunchKernelGGL((k_kl_terms<D>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, Sig, Sub, mu, Pd, Ps, aD, aS, mup, part);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, lv.Lpad, trace, maha);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int mfgm_packed_ssm_to_naturals(const mfgm_plan* plan, const double* A, const double* off, const double* chol, double cD,
+                                double cS, double* lin, double* diag, double* sub, double* sumlogchol, void* ws,
+                                void* stream) {
+    if (!plan || !chol || !diag || !sub || !ws) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !A) return 1;
+    if ((lin != nullptr) != (off != nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (P.wide) return wide_ssm_to_naturals(P, A, off, chol, cD, cS, lin, diag, sub, sumlogchol, (double*)ws, st);
+    MFGM_DISPATCH_D(P.d, (s2n_impl<DD>(P, A, off, chol, cD, cS, lin, diag, sub, sumlogchol, (double*)ws, st)));
+}
+
+int mfgm_packed_kl_terms(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* mu, const double* Pd,
+                         const double* Ps, double aD, double aS, const double* mup, double* trace, double* maha, void* ws,
+                         void* stream) {
+    if (!plan || !Sig || !Sub || !mu || !Pd || !Ps || !mup || !trace || !maha || !ws) return 1;
+    const Plan& P = plan->p;
+    hipStream_t st = (hipStream_t)stream;
+    if (P.wide) return wide_kl_terms(P, Sig, Sub, mu, Pd, Ps, aD, aS, mup, trace, maha, (double*)ws, st);
+    MFGM_DISPATCH_D(P.d, (kl_impl<DD>(P, Sig, Sub, mu, Pd, Ps, aD, aS, mup, trace, maha, (double*)ws, st)));
+}
+
+}  // extern "C"
+
+static_assert(sizeof(mfgm_kernel_spec) == sizeof(mfgm::KernelSpec), "public and internal kernel spec structs must match");
+
+namespace {
+template <int D>
+int stationary_impl(const Plan& P, const KernelSpec& ks, const double* dts, double* A, double* off, double* chol, int* info,
+                    hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    hipLaunchKernelGGL((k_stationary_ssm<D>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, ks, dts, A, off, chol, info);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" int mfgm_packed_stationary_ssm(const mfgm_plan* plan, const mfgm_kernel_spec* spec, const double* time_deltas,
+                                          double* A, double* off, double* chol, int* info, void* stream) {
+    if (!plan || !spec || !A || !off || !chol || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !time_deltas) return 1;
+    KernelSpec ks;
+    memcpy(&ks, spec, sizeof(ks));
+    if (ks.ncomp < 1 || ks.ncomp > 8) return 1;
+    int dim = 0;
+    for (int c = 0; c < ks.ncomp; ++c) {
+        if (ks.order[c] < 1 || ks.order[c] > 3 || ks.offset[c] != dim) return 1;
+        dim += ks.order[c];
+    }
+    if (dim != P.d) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (stationary_impl<DD>(P, ks, time_deltas, A, off, chol, info, st)));
+}
+

@@ -1,0 +1,218 @@
+// Multi-level drivers of the lane-per-segment sweeps (d <= 8): reduce / forward / backward over the partition levels.
+#include "mfgm_internal.h"
+#include "mfgm_sweeps.h"
+
+using namespace mfgm;
+
+namespace {
+
+template <int D>
+int launch_reduce(const SweepArgs& a, bool has_rhs, bool has_corr, hipStream_t st) {
+    dim3 grid(a.lv.Lpad / 64), block(64);
+    if (has_rhs) {
+        if (has_corr) hipLaunchKernelGGL((k_reduce<D, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_reduce<D, true, false>), grid, block, 0, st, a);
+    } else {
+        if (has_corr) hipLaunchKernelGGL((k_reduce<D, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_reduce<D, false, false>), grid, block, 0, st, a);
+    }
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int D>
+int launch_forward(const SweepArgs& a, bool has_rhs, bool has_corr, bool has_up, hipStream_t st) {
+    dim3 grid(a.lv.Lpad / 64), block(64);
+#define FW(R_, C_, U_) hipLaunchKernelGGL((k_forward<D, R_, C_, U_>), grid, block, 0, st, a)
+    if (has_rhs) {
+        if (has_corr) { if (has_up) FW(true, true, true); else FW(true, true, false); }
+        else { if (has_up) FW(true, false, true); else FW(true, false, false); }
+    } else {
+        if (has_corr) { if (has_up) FW(false, true, true); else FW(false, true, false); }
+        else { if (has_up) FW(false, false, true); else FW(false, false, false); }
+    }
+#undef FW
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int D>
+int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub, hipStream_t st) {
+    dim3 grid(a.lv.Lpad / 64), block(64);
+    const bool mom = (a.momg != nullptr);
+#define BW(R_, U_, S_, M_) hipLaunchKernelGGL((k_backward<D, R_, U_, S_, M_>), grid, block, 0, st, a)
+    if (mom) {
+        // the moment array needs the means: has_rhs is guaranteed by the entry point
+        if (has_up) { if (want_sub) BW(true, true, true, true); else BW(true, true, false, true); }
+        else { if (want_sub) BW(true, false, true, true); else BW(true, false, false, true); }
+    } else if (has_rhs) {
+        if (has_up) { if (want_sub) BW(true, true, true, false); else BW(true, true, false, false); }
+        else { if (want_sub) BW(true, false, true, false); else BW(true, false, false, false); }
+    } else {
+        if (has_up) { if (want_sub) BW(false, true, true, false); else BW(false, true, false, false); }
+        else { if (want_sub) BW(false, false, true, false); else BW(false, false, false, false); }
+    }
+#undef BW
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+// fills the coarse-level pointers of `a` for level l from the workspace
+void bind_level_inputs(const Plan& P, int l, double* ws, SweepArgs& a) {
+    // inputs of level l >= 1 are the reduced system written by reduce(l-1)
+    a.Dg = ws + P.off_Dhat[l];
+    a.Dcorr = ws + P.off_Rsub[l];
+    a.Sg = ws + P.off_S[l];
+    a.rg = ws + P.off_rhat[l];
+    a.rcorr = ws + P.off_rho[l];
+    a.aD = a.aS = a.aR = 1.0;
+    a.Lg = ws + P.off_L[l];
+    a.Gg = ws + P.off_G[l];
+    a.yg = ws + P.off_y[l];
+    a.Sigg = ws + P.off_Sig[l];
+    a.Subg = nullptr;
+    a.mug = ws + P.off_mu[l];
+    a.part = nullptr;
+}
+
+void bind_up(const Plan& P, int l, double* ws, SweepArgs& a) {
+    // coarser level l+1
+    a.up = P.lv[l + 1];
+    a.uDhat = ws + P.off_Dhat[l + 1];
+    a.uRsub = ws + P.off_Rsub[l + 1];
+    a.uS = ws + P.off_S[l + 1];
+    a.urhat = ws + P.off_rhat[l + 1];
+    a.urho = ws + P.off_rho[l + 1];
+    a.uL = ws + P.off_L[l + 1];
+    a.uy = ws + P.off_y[l + 1];
+    a.uSig = ws + P.off_Sig[l + 1];
+    a.umu = ws + P.off_mu[l + 1];
+}
+
+template <int D>
+int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
+                double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info,
+                hipStream_t st, int only_stage = -1, int only_level = -1) {
+    const bool has_rhs = (rg != nullptr);
+    const int K = P.nlevels - 1;  // top level index (single segment per chain)
+    auto make = [&](int l) {
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.lv = P.lv[l];
+        a.info = info;
+        if (l == 0) {
+            a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
+            a.Lg = Lg; a.Gg = Gg; a.yg = yg;
+            a.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
+        } else {
+            bind_level_inputs(P, l, ws, a);
+        }
+        if (l < K) bind_up(P, l, ws, a);
+        return a;
+    };
+    for (int l = 0; l < K; ++l) {
+        if (only_stage >= 0 && !(only_stage == 0 && only_level == l)) continue;
+        SweepArgs a = make(l);
+        int rc = launch_reduce<D>(a, has_rhs, l > 0, st);
+        if (rc) return rc;
+    }
+    for (int l = K; l >= 0; --l) {
+        if (only_stage >= 0 && !(only_stage == 1 && only_level == l)) continue;
+        SweepArgs a = make(l);
+        int rc = launch_forward<D>(a, has_rhs, l > 0, l < K, st);
+        if (rc) return rc;
+    }
+    if (only_stage < 0 && (logdet || quad)) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad,
+                           logdet, quad);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+template <int D>
+int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub,
+                double* x, double* ws, hipStream_t st, int only_level = -1, double* mom = nullptr) {
+    const bool has_rhs = (yg != nullptr);
+    const int K = P.nlevels - 1;
+    for (int l = K; l >= 0; --l) {
+        if (only_level >= 0 && only_level != l) continue;
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.lv = P.lv[l];
+        if (l == 0) {
+            a.Lg = const_cast<double*>(Lg); a.Gg = const_cast<double*>(Gg); a.yg = const_cast<double*>(yg);
+            a.Sigg = Sig; a.Subg = Sub; a.mug = x; a.momg = mom;
+        } else {
+            bind_level_inputs(P, l, ws, a);
+        }
+        if (l < K) bind_up(P, l, ws, a);
+        int rc = launch_backward<D>(a, has_rhs, l < K, l == 0 && Sub != nullptr, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, const double* r, double aD, double aS,
+                       double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                       void* stream) {
+    if (!plan || !D || !L || !G || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !S) return 1;
+    if ((r != nullptr) != (y != nullptr)) return 1;
+    if (!ws && P.ws_doubles > 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (P.wide) return wide_factor(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, st);
+    MFGM_DISPATCH_D(P.d, (factor_impl<DD>(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, st)));
+}
+
+int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, const double* y, double* Sig,
+                       double* Sub, double* x, void* ws, void* stream) {
+    if (!plan || !L || !G || !Sig) return 1;
+    const Plan& P = plan->p;
+    if ((y != nullptr) != (x != nullptr)) return 1;
+    if (!ws && P.ws_doubles > 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (P.wide) return wide_selinv(P, L, G, y, Sig, Sub, x, (double*)ws, st);
+    MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st)));
+}
+
+
+// Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 is
+// the finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call
+// with the same arguments; outputs are overwritten with identical values.
+int mfgm_packed_factor_stage(const mfgm_plan* plan, int stage, int level, const double* D, const double* S, const double* r,
+                             double aD, double aS, double aR, double* L, double* G, double* y, void* ws, int* info,
+                             void* stream) {
+    if (!plan || !D || !L || !G || !info || stage < 0 || stage > 1) return 1;
+    const Plan& P = plan->p;
+    if (level < 0 || level >= P.nlevels || (stage == 0 && level >= P.nlevels - 1)) return 1;
+    if ((r != nullptr) != (y != nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (factor_impl<DD>(P, D, S, r, aD, aS, aR, L, G, y, nullptr, nullptr, (double*)ws, info, st, stage, level)));
+}
+
+int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, const double* G, const double* y, double* Sig,
+                             double* Sub, double* x, void* ws, void* stream) {
+    if (!plan || !L || !G || !Sig) return 1;
+    const Plan& P = plan->p;
+    if (level < 0 || level >= P.nlevels) return 1;
+    if ((y != nullptr) != (x != nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st, level)));
+}
+
+int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* L, const double* G, const double* y, double* Sig,
+                           double* Sub, double* x, double* mom, void* ws, void* stream) {
+    if (!plan || !L || !G || !Sig || !y || !x || !mom) return 1;
+    const Plan& P = plan->p;
+    if (only_level >= P.nlevels) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st, only_level, mom)));
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// VDP (Archambeau et al.) kernels on packed arrays.
+#include "mfgm_internal.h"
+#include "mfgm_sweeps.h"
+#include "mfgm_vdp.h"
+
+using namespace mfgm;
+
+static_assert(sizeof(mfgm_vdp_params) == sizeof(mfgm::VdpParams), "public and internal VDP parameter structs must match");
+
+namespace {
+template <int D>
+int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, const double* a1, const double* a2, const double* a3,
+             const double* a4, const double* a5, double* o0, double* o1, double* o2, double* ws, hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    dim3 grid(lv.Lpad / 64), block(64);
+    if (what == 0) {
+        hipLaunchKernelGGL((k_vdp_to_ssm<D>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2);
+    } else if (what == 1) {
+        double* part = ws + P.off_part[0];
+        if (o1) hipLaunchKernelGGL((k_vdp_esde<D, true>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, part, o1, o2);
+        else hipLaunchKernelGGL((k_vdp_esde<D, false>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, part, o1, o2);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, o0, (double*)nullptr);
+    } else if (what == 2) {
+        hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL((k_vdp_lagrange_scan<D>), dim3((P.B + 63) / 64), block, 0, st, lv, o2);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
+    } else {
+        hipLaunchKernelGGL((k_vdp_update_param<D>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, o0, o1);
+    }
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+size_t mfgm_vdp_workspace_doubles(const mfgm_plan* plan) {
+    if (!plan) return 0;
+    const int d = plan->p.d;
+    return (size_t)(4 * d * d + 2 * d) * plan->p.lv[0].Lpad;
+}
+
+int mfgm_packed_vdp_to_ssm(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm, double* A,
+                           double* off, double* chol, void* stream) {
+    if (!plan || !prm || !Am || !bm || !A || !off || !chol) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(0, P, pr, Am, bm, nullptr, nullptr, nullptr, nullptr, A, off, chol, nullptr, st)));
+}
+
+int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, const double* Am,
+                         const double* bm, double* e_over_dt, double* gm, double* gS, void* ws, void* stream) {
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !e_over_dt || !ws || ((gm != nullptr) != (gS != nullptr))) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(1, P, pr, mu, Sig, Am, bm, nullptr, nullptr, e_over_dt, gm, gS, (double*)ws, st)));
+}
+
+int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
+                             const double* Am, const double* bm, const double* yR, const double* dobsS, double* psi, double* lam,
+                             double* seg, void* stream) {
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !dobsS || !psi || !lam || !seg) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(2, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st)));
+}
+
+int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
+                                 const double* psi, const double* lam, double* Am, double* bm, void* stream) {
+    if (!plan || !prm || !mu || !Sig || !psi || !lam || !Am || !bm) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(3, P, pr, mu, Sig, psi, lam, nullptr, nullptr, Am, bm, nullptr, nullptr, st)));
+}
+
+}  // extern "C"
+

@@ -1,0 +1,144 @@
+// Drivers of the wide (8 < d <= 32) path: one wavefront per segment, same level recursion as the narrow sweeps.
+#include "mfgm_internal.h"
+#include "mfgm_sweeps.h"
+#include "mfgm_wide.h"
+
+using namespace mfgm;
+
+namespace {
+
+// ---- wide (8 < d <= 32) drivers: same level recursion, one wavefront per segment ------------------------------------
+template <int DM>
+int wide_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
+    dim3 grid(a.lv.L), block(64);
+#define KW(K) hipLaunchKernelGGL((K), grid, block, 0, st, a)
+    if (which == 0) {
+        if (has_rhs) { if (has_corr) KW((kw_reduce<DM, true, true>)); else KW((kw_reduce<DM, true, false>)); }
+        else { if (has_corr) KW((kw_reduce<DM, false, true>)); else KW((kw_reduce<DM, false, false>)); }
+    } else if (which == 1) {
+        if (has_rhs) {
+            if (has_corr) { if (has_up) KW((kw_forward<DM, true, true, true>)); else KW((kw_forward<DM, true, true, false>)); }
+            else { if (has_up) KW((kw_forward<DM, true, false, true>)); else KW((kw_forward<DM, true, false, false>)); }
+        } else {
+            if (has_corr) { if (has_up) KW((kw_forward<DM, false, true, true>)); else KW((kw_forward<DM, false, true, false>)); }
+            else { if (has_up) KW((kw_forward<DM, false, false, true>)); else KW((kw_forward<DM, false, false, false>)); }
+        }
+    } else {
+        if (has_rhs) {
+            if (has_up) { if (want_sub) KW((kw_backward<DM, true, true, true>)); else KW((kw_backward<DM, true, true, false>)); }
+            else { if (want_sub) KW((kw_backward<DM, true, false, true>)); else KW((kw_backward<DM, true, false, false>)); }
+        } else {
+            if (has_up) { if (want_sub) KW((kw_backward<DM, false, true, true>)); else KW((kw_backward<DM, false, true, false>)); }
+            else { if (want_sub) KW((kw_backward<DM, false, false, true>)); else KW((kw_backward<DM, false, false, false>)); }
+        }
+    }
+#undef KW
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int wide_dispatch(int d, int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
+    if (d <= 16) return wide_launch<16>(which, a, has_rhs, has_corr, has_up, want_sub, st);
+    return wide_launch<32>(which, a, has_rhs, has_corr, has_up, want_sub, st);
+}
+
+void wide_bind(const Plan& P, int l, double* ws, WideArgs& a) {
+    const int K = P.nlevels - 1;
+    a.lv = P.lv[l];
+    a.d = P.d;
+    if (l > 0) {
+        a.Dg = ws + P.off_Dhat[l]; a.Dcorr = ws + P.off_Rsub[l]; a.Sg = ws + P.off_S[l];
+        a.rg = ws + P.off_rhat[l]; a.rcorr = ws + P.off_rho[l];
+        a.aD = a.aS = a.aR = 1.0;
+        a.Lg = ws + P.off_L[l]; a.Gg = ws + P.off_G[l]; a.yg = ws + P.off_y[l];
+        a.Sigg = ws + P.off_Sig[l]; a.Subg = nullptr; a.mug = ws + P.off_mu[l];
+    }
+    if (l < K) {
+        a.up = P.lv[l + 1];
+        a.uDhat = ws + P.off_Dhat[l + 1]; a.uRsub = ws + P.off_Rsub[l + 1]; a.uS = ws + P.off_S[l + 1];
+        a.urhat = ws + P.off_rhat[l + 1]; a.urho = ws + P.off_rho[l + 1];
+        a.uL = ws + P.off_L[l + 1]; a.uy = ws + P.off_y[l + 1]; a.uSig = ws + P.off_Sig[l + 1]; a.umu = ws + P.off_mu[l + 1];
+    }
+}
+
+}  // namespace
+
+namespace mfgm {
+
+int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
+                double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st) {
+    const bool has_rhs = (rg != nullptr);
+    const int K = P.nlevels - 1;
+    auto make = [&](int l) {
+        WideArgs a;
+        memset(&a, 0, sizeof(a));
+        a.info = info;
+        if (l == 0) {
+            a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
+            a.Lg = Lg; a.Gg = Gg; a.yg = yg;
+            a.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
+        }
+        wide_bind(P, l, ws, a);
+        return a;
+    };
+    for (int l = 0; l < K; ++l) {
+        int rc = wide_dispatch(P.d, 0, make(l), has_rhs, l > 0, true, false, st);
+        if (rc) return rc;
+    }
+    for (int l = K; l >= 0; --l) {
+        int rc = wide_dispatch(P.d, 1, make(l), has_rhs, l > 0, l < K, false, st);
+        if (rc) return rc;
+    }
+    if (logdet || quad) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub, double* x,
+                double* ws, hipStream_t st) {
+    const bool has_rhs = (yg != nullptr);
+    const int K = P.nlevels - 1;
+    for (int l = K; l >= 0; --l) {
+        WideArgs a;
+        memset(&a, 0, sizeof(a));
+        if (l == 0) {
+            a.Lg = const_cast<double*>(Lg); a.Gg = const_cast<double*>(Gg); a.yg = const_cast<double*>(yg);
+            a.Sigg = Sig; a.Subg = Sub; a.mug = x;
+        }
+        wide_bind(P, l, ws, a);
+        int rc = wide_dispatch(P.d, 2, a, has_rhs, false, l < K, l == 0 && Sub != nullptr, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+
+int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
+                         double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st) {
+    double* part = sumlogchol ? ws + P.off_part[0] : nullptr;
+    dim3 grid(P.B * P.T), block(64);
+#define S2N(DM_, LIN_) hipLaunchKernelGGL((kw_ssm_to_naturals<DM_, LIN_>), grid, block, 0, st, P.B, P.T, P.d, A, off, chol, cD, cS, lin, diag, sub, part)
+    if (P.d <= 16) { if (lin) S2N(16, true); else S2N(16, false); }
+    else { if (lin) S2N(32, true); else S2N(32, false); }
+#undef S2N
+    MFGM_CHECK_LAUNCH();
+    if (sumlogchol) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, P.T, 0, sumlogchol, (double*)nullptr);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps,
+                  double aD, double aS, const double* mup, double* trace, double* maha, double* ws, hipStream_t st) {
+    double* part = ws + P.off_part[0];
+    hipLaunchKernelGGL(kw_kl_terms, dim3(P.B * P.T), dim3(64), 0, st, P.B, P.T, P.d, Sig, Sub, mu, Pd, Ps, aD, aS, mup, part);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, P.T, P.B * P.T, trace, maha);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace mfgm

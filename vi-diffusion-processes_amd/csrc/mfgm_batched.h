@@ -9,7 +9,7 @@
 namespace mfgm {
 
 // L = chol(A) (lower; strict upper written as zero).  A non-positive pivot sets *info and is replaced by 1.
-__global__ __launch_bounds__(128) void k_batched_chol(int N, int d, const double* __restrict__ A, double* __restrict__ L,
+static __global__ __launch_bounds__(128) void k_batched_chol(int N, int d, const double* __restrict__ A, double* __restrict__ L,
                                                       int* info) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(128) void k_batched_chol(int N, int d, const double
 }
 
 // X = op(L) B for B [N, d, m]:  mode 1: L^{-1} B,  2: L^{-T} B,  3: (L L^T)^{-1} B.  lbatch = 1 shares one L.
-__global__ __launch_bounds__(128) void k_batched_trsm(int N, int d, int m, int lbatch, const double* __restrict__ L,
+static __global__ __launch_bounds__(128) void k_batched_trsm(int N, int d, int m, int lbatch, const double* __restrict__ L,
                                                       const double* __restrict__ B, double* __restrict__ X, int mode) {
     const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (long long)N * m) return;

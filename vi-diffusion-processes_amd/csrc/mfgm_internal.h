@@ -1,0 +1,51 @@
+// Shared by the translation units of libmfgm: the opaque plan, launch-check and block-size dispatch macros, and the
+// cross-unit entry points of the wide (8 < d <= 32) drivers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/mfgm.h"
+#include "mfgm_layout.h"
+
+struct mfgm_plan {
+    mfgm::Plan p;
+};
+
+namespace mfgm {
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+#define MFGM_CHECK_LAUNCH()                        \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return 3;           \
+    } while (0)
+
+#define MFGM_DISPATCH_D(d, CALL)             \
+    switch (d) {                             \
+        case 1: { constexpr int DD = 1; return CALL; } \
+        case 2: { constexpr int DD = 2; return CALL; } \
+        case 3: { constexpr int DD = 3; return CALL; } \
+        case 4: { constexpr int DD = 4; return CALL; } \
+        case 5: { constexpr int DD = 5; return CALL; } \
+        case 6: { constexpr int DD = 6; return CALL; } \
+        case 7: { constexpr int DD = 7; return CALL; } \
+        case 8: { constexpr int DD = 8; return CALL; } \
+        default: return 1;                   \
+    }
+
+// mfgm_api_wide.hip
+int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
+                double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st);
+int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub, double* x,
+                double* ws, hipStream_t st);
+int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
+                         double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st);
+int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps,
+                  double aD, double aS, const double* mup, double* trace, double* maha, double* ws, hipStream_t st);
+
+}  // namespace mfgm

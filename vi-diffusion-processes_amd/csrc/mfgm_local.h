@@ -17,7 +17,7 @@ MFGM_DEV void ld_next(const double* __restrict__ base, int R, int s, int len, in
 }
 
 // ---- out = a*x + b*y + c*z on flat arrays (y, z optional) ------------------------------------------------
-__global__ __launch_bounds__(256) void k_lincomb(size_t n, double* out, double a, const double* x,
+static __global__ __launch_bounds__(256) void k_lincomb(size_t n, double* out, double a, const double* x,
                                                 double b, const double* y, double c,
                                                 const double* z) {
     const size_t n2 = n / 2;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_lincomb(size_t n, double* out, double a
 // ---- gather / scatter of a sparse list of nodes (observation times) --------------------------------------
 // node_ids[i] = b*T + t.  values: natural [n, E_nat].  mode 0: packed -> values, 1: values -> packed (set),
 // 2: packed += scale*values (and packed2 += scale*values when given).  SYM scatters read the lower triangle.
-__global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int kind, double* packed, double* packed2,
+static __global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int kind, double* packed, double* packed2,
                                                 const long long* __restrict__ node_ids, int n, double* values, int mode,
                                                 double scale) {
     const unsigned En = (kind == 0) ? d : d * d;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int
 // restating ssm_to_naturals (ssm_gaussian_transformations.py:182-253) and _build_precision
 // (state_space_model.py:431-483) with the same operation order (L^{-1}A, then L^{-T}, then the Gram product).
 template <int D, bool WANT_LIN>
-__global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const double* __restrict__ Ag,
+static __global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const double* __restrict__ Ag,
                                                        const double* __restrict__ offg, const double* __restrict__ cholg,
                                                        double cD, double cS, double* __restrict__ ling,
                                                        double* __restrict__ diagg, double* __restrict__ subg,
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void k_ssm_to_naturals(LevelDesc lv, const doub
 //                     part[Lpad + lane] = sum_t dl_t^T P_tt dl_t + 2 dl_{t+1}^T P_{t+1,t} dl_t   (Mahalanobis term)
 // restating StateSpaceModel.kl_divergence (state_space_model.py:557-593).
 template <int D>
-__global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __restrict__ Sigg, const double* __restrict__ Subg,
+static __global__ __launch_bounds__(64) void k_kl_terms(LevelDesc lv, const double* __restrict__ Sigg, const double* __restrict__ Subg,
                                                 const double* __restrict__ mug, const double* __restrict__ Pdg,
                                                 const double* __restrict__ Psg, double aD, double aS,
                                                 const double* __restrict__ mupg, double* __restrict__ part) {
@@ -300,7 +300,7 @@ MFGM_DEV void stationary_pinf(const KernelSpec& ks, double (&Pinf)[D * D]) {
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void k_stationary_ssm(LevelDesc lv, KernelSpec ks, const double* __restrict__ dts /* natural [B, n-1] */,
+static __global__ __launch_bounds__(64) void k_stationary_ssm(LevelDesc lv, KernelSpec ks, const double* __restrict__ dts /* natural [B, n-1] */,
                                                       double* __restrict__ Ag, double* __restrict__ offg,
                                                       double* __restrict__ cholg, int* info) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;

@@ -70,7 +70,7 @@ struct SweepArgs {
 
 // ---- reduce -------------------------------------------------------------------------------------
 template <int D, bool HAS_RHS, bool HAS_CORR>
-__global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
+static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
 
 // ---- forward ------------------------------------------------------------------------------------
 template <int D, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
-__global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
+static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
 
 // ---- backward -----------------------------------------------------------------------------------
 template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM>
-__global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
+static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 
 // ---- per-chain sum of the per-lane partials ---------------------------------------------------------
 // part: [2*Lpad]; out_logdet[b] = sum_p part[b*P+p]; out_quad[b] likewise.  One wave per chain.
-__global__ __launch_bounds__(64) void k_sum_partials(const double* part, int P, int Lpad, double* out_logdet,
+static __global__ __launch_bounds__(64) void k_sum_partials(const double* part, int P, int Lpad, double* out_logdet,
                                                     double* out_quad) {
     const int b = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;

@@ -150,7 +150,7 @@ MFGM_DEV double* wblk(double* base, int b, int n, int t, int E) { return base + 
 
 // ---- reduce ---------------------------------------------------------------------------------------------------------
 template <int DM, bool HAS_RHS, bool HAS_CORR>
-__global__ __launch_bounds__(64) void kw_reduce(WideArgs a) {
+static __global__ __launch_bounds__(64) void kw_reduce(WideArgs a) {
     const int lane = threadIdx.x, d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
     const int b = blockIdx.x / P, p = blockIdx.x - b * P;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) void kw_reduce(WideArgs a) {
 
 // ---- forward --------------------------------------------------------------------------------------------------------
 template <int DM, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
-__global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
+static __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
     const int lane = threadIdx.x, d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
     const int b = blockIdx.x / P, p = blockIdx.x - b * P;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
 // Works with transposed factors held by rows: Lt = L^T (column loads), Gt = G^T, Xt = L^{-T}, Ht = Xt Gt, so that
 //   Sigma_t = Xt Xt^T + Ht Sigma_n Ht^T,   Sigma_{t+1,t} = -Sigma_n Ht^T,   x_t = Xt (y - Gt x_n).
 template <int DM, bool HAS_RHS, bool HAS_UP, bool WANT_SUB>
-__global__ __launch_bounds__(64) void kw_backward(WideArgs a) {
+static __global__ __launch_bounds__(64) void kw_backward(WideArgs a) {
     const int lane = threadIdx.x, d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
     const int b = blockIdx.x / P, p = blockIdx.x - b * P;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void kw_backward(WideArgs a) {
 
 // SSM parameters -> naturals / precision blocks, one wavefront per node (same outputs as k_ssm_to_naturals)
 template <int DM, bool WANT_LIN>
-__global__ __launch_bounds__(64) void kw_ssm_to_naturals(int B, int T, int d, const double* __restrict__ Ag,
+static __global__ __launch_bounds__(64) void kw_ssm_to_naturals(int B, int T, int d, const double* __restrict__ Ag,
                                                         const double* __restrict__ offg, const double* __restrict__ cholg,
                                                         double cD, double cS, double* __restrict__ ling,
                                                         double* __restrict__ diagg, double* __restrict__ subg,
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64) void kw_ssm_to_naturals(int B, int T, int d, co
 }
 
 // KL(q || p) local terms, one wavefront per node; partials part[b*T + t] (trace) and part[B*T + b*T + t] (Mahalanobis)
-__global__ __launch_bounds__(64) void kw_kl_terms(int B, int T, int d, const double* __restrict__ Sigg,
+static __global__ __launch_bounds__(64) void kw_kl_terms(int B, int T, int d, const double* __restrict__ Sigg,
                                                  const double* __restrict__ Subg, const double* __restrict__ mug,
                                                  const double* __restrict__ Pdg, const double* __restrict__ Psg, double aD,
                                                  double aS, const double* __restrict__ mupg, double* __restrict__ part) {
@@ -470,62 +470,6 @@ __global__ __launch_bounds__(64) void kw_kl_terms(int B, int T, int d, const dou
     if (lane == 0) {
         part[blockIdx.x] = tr;
         part[(size_t)B * T + blockIdx.x] = mh;
-    }
-}
-
-// natural [B, n_nat, E] <-> wide [B, T, E] (nodes >= n_nat are zero-filled on pack).  kind 2 symmetrises from the lower
-// triangle on pack; kind 3 zeroes the strict upper triangle in both directions.
-__global__ __launch_bounds__(256) void kw_copy(const double* __restrict__ src, double* __restrict__ dst, int B, int T, int d,
-                                              int kind, int n_nat, int pack) {
-    const int E = (kind == 0) ? d : d * d;
-    const int nout = pack ? T : n_nat;
-    const size_t total = (size_t)B * nout * E;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(idx % E);
-        const size_t bt = idx / E;
-        const int t = (int)(bt % nout), b = (int)(bt / nout);
-        int es = e;
-        bool zero = false;
-        if (kind >= 2) {
-            const int r = e / d, c = e - r * d;
-            if (c > r) {
-                if (kind == 3) zero = true;
-                else if (pack) es = c * d + r;
-            }
-        }
-        double v = 0.0;
-        if (!zero && t < n_nat) v = src[((size_t)b * (pack ? n_nat : T) + t) * E + es];
-        dst[idx] = v;
-    }
-}
-
-// gather / scatter of listed nodes (k_node_io semantics) on wide arrays
-__global__ __launch_bounds__(256) void kw_node_io(int d, int kind, double* packed, double* packed2,
-                                                 const long long* __restrict__ node_ids, int n, double* values, int mode,
-                                                 double scale) {
-    const unsigned E = (kind == 0) ? d : d * d;
-    const unsigned total = (unsigned)n * E;
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const unsigned i = idx / E, e = idx - i * E;
-        const size_t off = (size_t)node_ids[i] * E + e;
-        unsigned es = e;
-        bool zero = false;
-        if (kind >= 2) {
-            const unsigned r = e / d, c = e - r * d;
-            if (c > r) {
-                if (kind == 3) zero = true;
-                else if (mode != 0) es = c * d + r;      // symmetric scatters read the lower triangle
-            }
-        }
-        if (mode == 0) values[idx] = zero ? 0.0 : packed[off];
-        else {
-            const double v = zero ? 0.0 : values[i * E + es];
-            if (mode == 1) packed[off] = v;
-            else {
-                packed[off] += scale * v;
-                if (packed2) packed2[off] += scale * v;
-            }
-        }
     }
 }
 
