@@ -226,3 +226,60 @@ def test_gpr_wide_kernel(amd, rng):
     gpr = GaussianProcessRegression((dev(t), dev(y)), mk(kernels), dev(0.3 * np.eye(1)))
     ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), 0.3 ** 2)
     np.testing.assert_allclose(host(gpr.log_likelihood()), ref, rtol=1e-7)
+
+
+def _sum16(K):
+    """Sum-of-Matern kernel with state dimension 16 (config 5 of BASELINE.json): five Matern-5/2 and one Matern-1/2."""
+    return K.Sum([K.Matern52(lengthscale=0.12 + 0.04 * i, variance=1.0 / (i + 1)) for i in range(5)] + [K.Matern12(0.6, 0.5)])
+
+
+def test_cvi_gp_d16(amd, rng):
+    """CVIGaussianProcess with the d = 16 kernel: one-step optimum == GPR log-likelihood, damped iteration == oracle."""
+    from oracle import np_models
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.variational_cvi import CVIGaussianProcess
+    assert _sum16(K).state_dim == 16
+    N = 60
+    t = np.linspace(0, 4, N) + 0.02 * rng.uniform(size=N)
+    y = np.cos(3 * t)[:, None] + 0.1 * rng.normal(size=(N, 1))
+    g = CVIGaussianProcess((dev(t), dev(y)), _sum16(K), Gaussian(1.0), learning_rate=1.0)
+    g.update_sites()
+    ref = np_models.gpr_log_likelihood(t, y, _sum16(np_kernels), 1.0)
+    np.testing.assert_allclose(float(g.elbo()), ref, rtol=5e-6)
+    np.testing.assert_allclose(float(g.classic_elbo()), ref, rtol=5e-6)
+    g2 = CVIGaussianProcess((dev(t), dev(y)), _sum16(K), Gaussian(0.3), learning_rate=0.4)
+    o2 = np_models.CVIGaussianProcess(t, y, _sum16(np_kernels), np_models.GaussianLik(0.3), learning_rate=0.4)
+    for _ in range(3):
+        g2.update_sites()
+        o2.update_sites()
+        np.testing.assert_allclose(float(g2.elbo()), o2.elbo(), rtol=5e-6)
+        np.testing.assert_allclose(float(g2.classic_elbo()), o2.classic_elbo(), rtol=5e-6)
+
+
+def test_sparse_cvi_d16(amd, rng):
+    """Config 5 in miniature: the sparse / inducing-state CVI variant with the d = 16 Sum-of-Matern kernel against the oracle
+    (damped site updates, monotone ELBO, predictions at new time points)."""
+    from oracle import np_conditionals as npc, np_models
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
+    N = 50
+    t = np.linspace(0, 1, N)
+    y = (np.cos(20 * t) + 0.3 * rng.normal(size=N)).reshape(-1, 1)
+    z = np.linspace(-0.1, 1.1, 15)
+    g = SparseCVIGaussianProcess(_sum16(K), dev(z), Gaussian(0.5), learning_rate=0.6)
+    o = npc.SparseCVIGaussianProcess(_sum16(np_kernels), z, np_models.GaussianLik(0.5), learning_rate=0.6)
+    prev = -np.inf
+    for _ in range(3):
+        g.update_sites((dev(t), dev(y)))
+        o.update_sites(t, y)
+        e = float(g.classic_elbo((dev(t), dev(y))))
+        np.testing.assert_allclose(e, o.classic_elbo(t, y), rtol=5e-6)
+        assert e > prev - 1e-9
+        prev = e
+    tn = np.sort(rng.uniform(-0.3, 1.3, size=9))
+    mu, var = g.posterior.predict_f(dev(tn))
+    omu, ovar = npc.predict_f(o.dist_q, _sum16(np_kernels), z, tn)
+    assert_close(host(mu), omu, rtol=1e-5)
+    assert_close(host(var), ovar, rtol=1e-5)
