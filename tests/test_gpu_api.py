@@ -491,18 +491,72 @@ def test_ssm_natgrad_one_step_optimum(amd, rng):
     q = StateSpaceModel(*[dev(a) for a in random_ssm_params(rng, (), 10, 5)], plan=plan)
     loss = GaussMarkovELBO(p, gk.generate_emission_model(dev(t)), Gaussian(noise), dev(y))
     before = float(loss.elbo(q))
-    SSMNaturalGradient(gamma=1.0).minimize(loss, q)
+    SSMNaturalGradient(gamma=1.0, momentum=False).minimize(loss, q)
     ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), noise)
     np.testing.assert_allclose(float(loss.elbo(q)), ref, rtol=1e-6, atol=1e-5)
     assert float(loss.elbo(q)) > before
     # a damped step moves towards, not onto, the optimum
     q2 = StateSpaceModel(*[dev(a) for a in random_ssm_params(rng, (), 10, 5)], plan=plan)
     e0 = float(loss.elbo(q2))
-    SSMNaturalGradient(gamma=0.3).minimize(loss, q2)
+    SSMNaturalGradient(gamma=0.3, momentum=False).minimize(loss, q2)
     e1 = float(loss.elbo(q2))
     assert e0 < e1 < ref + 1e-6
     with pytest.raises(NotImplementedError):
         SSMNaturalGradient(gamma=0.1).minimize(lambda: 0.0, q2)
+
+
+def test_ssm_natgrad_momentum(amd, rng):
+    """The Adam-like variant (ssm_natgrad.py:177-208, the reference's default; no reference test exists): the Fisher norm of the
+    natural gradient against a dense evaluation of g^T (d eta / d theta) g, and the first update against the documented formulas."""
+    from vidp_amd import kernels as K, ssm_gaussian_transformations as tr
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.ssm_natgrad import GaussMarkovELBO, SSMNaturalGradient
+    from vidp_amd.state_space_model import StateSpaceModel
+    T, d = 7, 3
+    gk = K.Sum([K.Matern32(1.4, 0.6), K.Matern12(0.7, 1.1)])
+    t = np.sort(rng.uniform(0, 5, size=T))
+    y = np.sin(2 * t)[:, None] + 0.1 * rng.normal(size=(T, 1))
+    p = gk.state_space_model(dev(t))
+    q = StateSpaceModel(*[dev(a) for a in random_ssm_params(rng, (), T, d)], plan=p.plan)
+    loss = GaussMarkovELBO(p, gk.generate_emission_model(dev(t)), Gaussian(0.5), dev(y))
+    pl = q.plan
+    (gl, gd, gs), nq = loss.grad_wrt_expectations(q)
+    norm = SSMNaturalGradient.natgrad_norm(pl, nq, (gl, gd, gs))
+    # dense reference: P = blocktridiag(-2 theta_diag, -theta_sub), mu = P^{-1} theta_lin; direction v = g
+    th = [host(x)[0] for x in (pl.unpack(amd.VEC, nq["lin"]), pl.unpack(amd.SYM, nq["diag"]), pl.unpack(amd.FULL, nq["sub"], T - 1))]
+    v = [host(x)[0] for x in (pl.unpack(amd.VEC, gl), pl.unpack(amd.SYM, gd), pl.unpack(amd.FULL, gs, T - 1))]
+    def dense(diag, sub):
+        M = np.zeros((T * d, T * d))
+        for k in range(T):
+            M[k * d:(k + 1) * d, k * d:(k + 1) * d] = -2.0 * diag[k]
+        for k in range(T - 1):
+            M[(k + 1) * d:(k + 2) * d, k * d:(k + 1) * d] = -sub[k]
+            M[k * d:(k + 1) * d, (k + 1) * d:(k + 2) * d] = -sub[k].T
+        return M
+    P, dP = dense(th[1], th[2]), dense(v[1], v[2])
+    S = np.linalg.inv(P)
+    mu = S @ th[0].reshape(-1)
+    dmu = S @ (v[0].reshape(-1) - dP @ mu)
+    dE = -S @ dP @ S + np.outer(dmu, mu) + np.outer(mu, dmu)
+    ref = v[0].reshape(-1) @ dmu
+    for k in range(T):
+        ref += np.sum(v[1][k] * dE[k * d:(k + 1) * d, k * d:(k + 1) * d])
+    for k in range(T - 1):
+        ref += 2.0 * np.sum(v[2][k] * dE[(k + 1) * d:(k + 2) * d, k * d:(k + 1) * d])
+    assert ref > 0
+    np.testing.assert_allclose(norm, ref, rtol=1e-6)
+    # first step: m = (1-b1) g, v = (1-b2) norm, lr = gamma sqrt(1-b2)/(1-b1)
+    opt = SSMNaturalGradient(gamma=0.2, beta1=0.9, beta2=0.99, epsilon=1e-8)      # momentum is the default, as in the reference
+    e0 = float(loss.elbo(q))
+    opt.minimize(loss, q)
+    step = 0.2 * np.sqrt(1 - 0.99) / (1 - 0.9) / (np.sqrt((1 - 0.99) * ref) + 1e-8) * (1 - 0.9)
+    want = [a - step * b for a, b in zip(th, v)]
+    got = tr.ssm_to_naturals(q)
+    for a, b in zip(got, want):
+        assert_close(host(a), b, rtol=1e-5)
+    assert float(loss.elbo(q)) > e0
+    opt.minimize(loss, q)           # second step runs with the moving averages
+    assert np.isfinite(float(loss.elbo(q)))
 
 
 @pytest.mark.parametrize("kname", ["m12", "m32sum"])

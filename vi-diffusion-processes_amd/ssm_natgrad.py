@@ -7,8 +7,13 @@ The reference obtains dL/d eta from a persistent GradientTape through the loss a
 not built yet; instead the loss object supplies dL/d eta itself (`grad_wrt_expectations`), which is available in closed form
 for the losses on the path: the ELBO of a Gauss-Markov q is  sum_t VE_t(mu_t, Sigma_tt) - KL[q || p]  with
 d KL / d eta = theta_q - theta_p.  `GaussMarkovELBO` below is that loss (the `VariationalGaussianProcess.elbo` of the reference,
-models/variational.py:129-152).  The Adam-like momentum variant (ssm_natgrad.py:177-208) needs Fisher-vector products and is
-not implemented.
+models/variational.py:129-152).
+
+The Adam-like momentum variant (ssm_natgrad.py:36-58, 177-208; the reference's default) keeps moving averages m of the natural
+gradient g = dL/d eta and v of its squared norm in the Fisher metric, <g, dL/d theta> = g^T (d eta / d theta) g.  The reference
+gets dL/d theta from a second tape pass; here the Fisher-vector product is the directional derivative of the expectation
+parameters, (eta(theta + e g) - eta(theta - e g)) / 2e, from two extra factor + selected-inverse sweeps.  The reference has no
+test for this variant (parity unpinned); tests check the update against the same formulas on the oracle.
 """
 import torch
 
@@ -59,10 +64,12 @@ class GaussMarkovELBO:
 class SSMNaturalGradient:
     """ssm_natgrad.py:33-244."""
 
-    def __init__(self, gamma=0.1, momentum=False, beta1=0.9, beta2=0.99, epsilon=1e-8, name=None):
-        if momentum:
-            raise NotImplementedError("the momentum variant needs Fisher-vector products through the sweeps (not built yet)")
+    def __init__(self, gamma=0.1, momentum=True, beta1=0.9, beta2=0.99, epsilon=1e-8, name=None):
         self.gamma = float(gamma)
+        self._momentum = bool(momentum)
+        self._beta1, self._beta2, self._epsilon = float(beta1), float(beta2), float(epsilon)
+        self._ms, self._v, self._step_counter = None, 0.0, 1.0      # ssm_natgrad.py:88-93, 155-168
+        self._effective_lr = None
 
     def minimize(self, loss_fn, ssm: StateSpaceModel):
         """One natural-gradient step on `ssm` in place (ssm_natgrad.py:95-119)."""
@@ -76,11 +83,52 @@ class SSMNaturalGradient:
                 "sweeps (the reference's GradientTape through banded ops) are not implemented")
         pl = ssm.plan
         (gl, gd, gs), nq = loss_fn.grad_wrt_expectations(ssm)
-        tl = pl.lincomb(pl.empty(VEC), 1.0, nq["lin"], -self.gamma, gl)
-        td = pl.lincomb(pl.empty(SYM), 1.0, nq["diag"], -self.gamma, gd)
-        ts = pl.lincomb(pl.empty(FULL), 1.0, nq["sub"], -self.gamma, gs)
+        step, dl, dd, ds = self.gamma, gl, gd, gs
+        if self._momentum:
+            # ssm_natgrad.py:177-208
+            b1, b2 = self._beta1, self._beta2
+            lr = self.gamma * (1.0 - b2 ** self._step_counter) ** 0.5 / (1.0 - b1 ** self._step_counter)
+            if self._ms is None:
+                self._ms = [torch.zeros_like(g) for g in (gl, gd, gs)]
+            for m, g in zip(self._ms, (gl, gd, gs)):
+                pl.lincomb(m, b1, m, 1.0 - b1, g)
+            self._v = self._v * b2 + (1.0 - b2) * self.natgrad_norm(pl, nq, (gl, gd, gs))
+            self._step_counter += 1.0
+            step = lr / (self._v ** 0.5 + self._epsilon)
+            self._effective_lr = step
+            dl, dd, ds = self._ms
+        tl = pl.lincomb(pl.empty(VEC), 1.0, nq["lin"], -step, dl)
+        td = pl.lincomb(pl.empty(SYM), 1.0, nq["diag"], -step, dd)
+        ts = pl.lincomb(pl.empty(FULL), 1.0, nq["sub"], -step, ds)
         new = naturals_to_ssm_params_packed(pl, tl, td, ts)
         # assign in place (ssm_natgrad.py:213-218)
         keep_batch = ssm.batch_shape
         ssm.__dict__.update(new.__dict__)
         ssm.batch_shape = keep_batch
+
+    @staticmethod
+    def natgrad_norm(pl, nq, g, rel_step=1e-5):
+        """
+        <g, F g> with F = d eta / d theta the Fisher matrix of q in natural coordinates (the reference's
+        sum(dL/d eta * dL/d theta), sub-diagonal part counted twice, ssm_natgrad.py:189-192), summed over all chains.
+        Central difference of eta along g: two extra factor + selected-inverse passes.
+        """
+        gl, gd, gs = g
+        T = pl.T
+        tnorm = max(float(nq["diag"].abs().max()), 1e-300)
+        gnorm = max(float(gd.abs().max()), float(gs.abs().max()), float(gl.abs().max()), 1e-300)
+        e = rel_step * tnorm / gnorm
+        etas = []
+        for sgn in (1.0, -1.0):
+            tl = pl.lincomb(pl.empty(VEC), 1.0, nq["lin"], sgn * e, gl)
+            td = pl.lincomb(pl.empty(SYM), 1.0, nq["diag"], sgn * e, gd)
+            ts = pl.lincomb(pl.empty(FULL), 1.0, nq["sub"], sgn * e, gs)
+            f = pl.factor(td, ts, tl, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
+            s_ = pl.selinv(f["L"], f["G"], f["y"], want_sub=True)
+            pl.check_info()
+            mu, cov, sub = pl.unpack(VEC, s_["x"]), pl.unpack(SYM, s_["Sig"]), pl.unpack(FULL, s_["Sub"], T - 1)
+            etas.append((mu, cov + mu[..., :, None] * mu[..., None, :], sub + mu[:, 1:, :, None] * mu[:, :-1, None, :]))
+        (m1, d1, s1), (m0, d0, s0) = etas
+        vl, vd, vs = pl.unpack(VEC, gl), pl.unpack(SYM, gd), pl.unpack(FULL, gs, T - 1)
+        tot = (vl * (m1 - m0)).sum() + (vd * (d1 - d0)).sum() + 2.0 * (vs * (s1 - s0)).sum()
+        return float(tot) / (2.0 * e)
