@@ -27,8 +27,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def obs_chol(d, noise):
+    """Cholesky factor of the observation-noise covariance: correlated across the state dimensions, so that the data sites
+    are full d x d blocks and the posterior genuinely couples the dimensions (the drift and diffusion act per dimension)."""
+    return noise * (np.eye(d) + 0.3 * np.eye(d, k=-1))
+
+
 def synth_double_well(B, T, d, dt, obs_every, noise, seed):
     """Euler-Maruyama double-well trajectories f(x) = 4x(1-x^2), q = I and noisy observations."""
+    Lc = obs_chol(d, noise)
     rng = np.random.default_rng(seed)
     x = np.where(rng.random((B, d)) < 0.5, -1.0, 1.0)
     idx = np.arange(obs_every, T, obs_every)
@@ -38,7 +45,7 @@ def synth_double_well(B, T, d, dt, obs_every, noise, seed):
     for t in range(1, T):
         x = x + dt * 4.0 * x * (1.0 - x * x) + sq * rng.standard_normal((B, d))
         if k < len(idx) and t == idx[k]:
-            ys[:, k] = x + noise * rng.standard_normal((B, d))
+            ys[:, k] = x + rng.standard_normal((B, d)) @ Lc.T
             k += 1
     return idx, ys
 
@@ -57,8 +64,9 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
     chol = np.concatenate([np.eye(d)[None], np.broadcast_to(np.sqrt(dt) * np.eye(d), (T - 1, d, d))], axis=0)
     lin, diag, sub = c_ref.ssm_to_naturals(A, off, chol)
     rep = lambda a: np.broadcast_to(a, (Bs,) + a.shape).copy()
-    Rinv = np.eye(d) / noise ** 2
-    st = c_ref.CviDpStepState(rep(lin), rep(diag), rep(sub), idx, ys[:Bs], Rinv, 2 * d * np.log(noise), alpha, beta,
+    Lc = obs_chol(d, noise)
+    Rinv = np.linalg.inv(Lc @ Lc.T)
+    st = c_ref.CviDpStepState(rep(lin), rep(diag), rep(sub), idx, ys[:Bs], Rinv, 2 * np.sum(np.log(np.diag(Lc))), alpha, beta,
                               np.ones(d), dt, np.zeros(d), np.eye(d))
     st.step(args.lr_data, args.lr_girsanov)         # first step doubles as warm-up and as a parity probe
     first = st.elbo.copy()
@@ -129,7 +137,7 @@ def main():
     idx, ys = synth_double_well(B, T, d, dt, args.obs_every, noise, seed=71892305 + 3 + rank)
     plan = vidp_amd.Plan(B, T, d, device=device)
     grid = np.arange(T) * dt
-    lik = MultivariateGaussian(noise * torch.eye(d, dtype=torch.float64, device=device))
+    lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))
     sde = DoubleWellSDE(q=torch.eye(d, dtype=torch.float64))
     model = CVISitesSDE(sde, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik,
                         prior_initial_state=(np.zeros(d), np.eye(d)), plan=plan)
@@ -172,7 +180,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"CVI-DP site-update loop (CVISitesSDE: update_data_sites + update_girsanov_sites + classic_elbo) "
                                f"on double-well SDE trajectories, T={T}, d={d}, {B} trajectories per GPU, "
-                               f"observation every {args.obs_every} steps",
+                               f"observation every {args.obs_every} steps, correlated observation noise (full d x d data sites)",
                    "trajectories_per_gpu": B, "T": T, "d": d, "total_trajectories": B * world,
                    "partition": {"levels": plan.nlevels, "segment_len": plan.R, "lanes": plan.Lpad}},
         "elbo_last": elbo_vals[-1],
