@@ -48,4 +48,8 @@ int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, cons
 int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps,
                   double aD, double aS, const double* mup, double* trace, double* maha, double* ws, hipStream_t st);
 
+// mfgm_api_mfma.hip: which = 0 reduce, 1 forward, 2 backward
+struct WideArgs;
+int mfma_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st);
+
 }  // namespace mfgm
