@@ -57,13 +57,22 @@ MFGM_DEV Tile gram(const Tile& X, const Tile& Y) { return gram(X, Y, tile_zero()
 // direct: tile = M (identity padded when PAD_EYE);  transposed: tile = M^T
 template <bool TRANSPOSED, bool PAD_EYE>
 MFGM_DEV Tile ld_tile(const double* __restrict__ blk, int d, const LaneId& L, double scale) {
+    // branch-free: out-of-range lanes read element 0 and discard it, so that all four loads are in flight together
     Tile t;
+    double x[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = L.g + 4 * i;
-        double v = (PAD_EYE && r == L.c) ? 1.0 : 0.0;
-        if (r < d && L.c < d) v = scale * (TRANSPOSED ? blk[L.c * d + r] : blk[r * d + L.c]);
-        t.r[i] = v;
+        const bool ok = r < d && L.c < d;
+        x[i] = blk[ok ? (TRANSPOSED ? L.c * d + r : r * d + L.c) : 0];
+    }
+    // the loaded value is consumed unconditionally (times 0 where out of range) so that the compiler cannot sink the load
+    // back under a branch with a wait of its own
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = L.g + 4 * i;
+        const bool ok = r < d && L.c < d;
+        t.r[i] = __builtin_fma(x[i], ok ? scale : 0.0, (!ok && PAD_EYE && r == L.c) ? 1.0 : 0.0);
     }
     return t;
 }
@@ -81,10 +90,16 @@ MFGM_DEV void st_tile(double* __restrict__ blk, int d, const LaneId& L, const Ti
 // vectors live in column 0
 MFGM_DEV Tile ld_vec(const double* __restrict__ v, int d, const LaneId& L, double scale) {
     Tile t;
+    double x[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = L.g + 4 * i;
-        t.r[i] = (L.c == 0 && r < d) ? scale * v[r] : 0.0;
+        x[i] = v[r < d ? r : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = L.g + 4 * i;
+        t.r[i] = x[i] * ((L.c == 0 && r < d) ? scale : 0.0);
     }
     return t;
 }
@@ -109,19 +124,24 @@ MFGM_DEV Tile tile_transpose(const Tile& t, double* lds, const LaneId& L) {
 }
 
 // Gauss-Jordan row elimination on [A | Bm] (Bm = I on entry).
-//   CHOL: A symmetric positive definite  ->  A = L^T (upper triangular), Bm = L^{-1};  prod *= prod_j 1/L_jj
-//   else: A = L lower triangular         ->  A = I,                      Bm = L^{-1}
+//   CHOL: A symmetric positive definite  ->  A = L^T in its upper triangle (the strict lower triangle is left with rounding
+//         residue and must be masked by the caller), Bm = L^{-1};  prod *= prod_j 1/L_jj
+//   else: A = L lower triangular         ->  Bm = L^{-1}  (A is consumed)
+// Row j lives in lane row jr = j & 3, register ji = j >> 2: registers i < ji hold finished rows, registers i > ji only rows
+// below the pivot (no per-lane selects), register ji mixes finished rows, the pivot row and rows below.
 template <bool CHOL>
 MFGM_DEV void gj16(Tile& A, Tile& Bm, const LaneId& L, double& prod, int& bad) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int jr = j & 3, ji = j >> 2;                     // row j lives in lane row jr, register ji
+        const int jr = j & 3, ji = j >> 2;
         double rA = __shfl(A.r[ji], (jr << 4) | L.c, 64);       // row j of both tiles, per column
         double rB = __shfl(Bm.r[ji], (jr << 4) | L.c, 64);
         double p = bcast(rA, j);                                // pivot A[j][j]
         double s, s2;
         if (CHOL) {
-            if (!(p > 0.0)) { bad = 1; p = 1.0; }
+            const bool neg = !(p > 0.0);
+            bad |= neg ? 1 : 0;
+            p = neg ? 1.0 : p;
             s = rsqrt_nr(p);
             s2 = s;
             prod *= s;
@@ -131,17 +151,29 @@ MFGM_DEV void gj16(Tile& A, Tile& Bm, const LaneId& L, double& prod, int& bad) {
         }
         rA *= s;
         rB *= s;
+        const int colj = (L.lane & 0x30) | j;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i < ji) continue;                               // rows g + 4i <= 4i + 3 < j: untouched
-            const int row = L.g + 4 * i;
-            const double m = __shfl(A.r[i], (L.lane & 0x30) | j, 64) * s2;     // A[row][j] * s2
-            const bool below = row > j, isrow = row == j;
-            const double a_new = (L.c == j) ? 0.0 : __builtin_fma(-m, rA, A.r[i]);
-            A.r[i] = below ? a_new : (isrow ? rA : A.r[i]);
-            Bm.r[i] = below ? __builtin_fma(-m, rB, Bm.r[i]) : (isrow ? rB : Bm.r[i]);
+            if (i < ji) continue;
+            const double m = __shfl(A.r[i], colj, 64) * s2;    // A[row][j] * s2
+            if (i > ji) {
+                A.r[i] = __builtin_fma(-m, rA, A.r[i]);
+                Bm.r[i] = __builtin_fma(-m, rB, Bm.r[i]);
+            } else {
+                const bool below = L.g > jr, isrow = L.g == jr;
+                A.r[i] = below ? __builtin_fma(-m, rA, A.r[i]) : (isrow ? rA : A.r[i]);
+                Bm.r[i] = below ? __builtin_fma(-m, rB, Bm.r[i]) : (isrow ? rB : Bm.r[i]);
+            }
         }
     }
+}
+
+// keep the upper triangle (c >= r) of a tile
+MFGM_DEV Tile tile_upper(const Tile& t, const LaneId& L) {
+    Tile o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.r[i] = (L.c >= L.g + 4 * i) ? t.r[i] : 0.0;
+    return o;
 }
 
 // sum of squares of column 0 (uniform result)
@@ -246,7 +278,9 @@ static __global__ __launch_bounds__(64) void km_forward(WideArgs a) {
             cv = gram(Gat, gram(Xt, ha));
         }
     }
-    double logacc = 0.0, quad = 0.0;
+    double quad = 0.0;
+    LogAcc la;                                   // prod_j 1 / L_jj over this segment, mantissa / exponent form
+    la.init();
     for (int s = 0; s < len; ++s) {
         const int t = t0 + s;
         Tile F = ld_tile<false, true>(wblk(a.Dg, b, n, t, EF), d, L, a.aD);
@@ -263,8 +297,9 @@ static __global__ __launch_bounds__(64) void km_forward(WideArgs a) {
         Tile X = tile_eye(L);
         double prod = 1.0;
         gj16<true>(F, X, L, prod, bad);
-        logacc -= log(prod);
-        st_tile<true>(wblk(a.Lg, b, n, t, EF), d, L, F);            // F holds L^T
+        la.mul(prod);
+        la.renorm();
+        st_tile<true>(wblk(a.Lg, b, n, t, EF), d, L, tile_upper(F, L));            // F holds L^T
         const Tile Xt = tile_transpose(X, lds, L);
         const Tile Gt = gram(Xt, St);
         if (has_next) st_tile<true>(wblk(a.Gg, b, n, t, EF), d, L, Gt);
@@ -277,7 +312,7 @@ static __global__ __launch_bounds__(64) void km_forward(WideArgs a) {
         }
     }
     if (a.part && L.lane == 0) {
-        a.part[blockIdx.x] = logacc;
+        a.part[blockIdx.x] = -la.value();
         a.part[a.lv.Lpad + blockIdx.x] = quad;
     }
     if (bad && L.lane == 0) atomicMax(a.info, 1);
@@ -292,8 +327,7 @@ static __global__ __launch_bounds__(64) void km_backward(WideArgs a) {
     const int b = blockIdx.x / P, p = blockIdx.x - b * P;
     const int t0 = p * R, len = min(R, n - t0), te = t0 + len - 1;
     int bad = 0;
-    auto inv_L = [&](int t) {
-        Tile Lm = ld_tile<false, true>(wblk(a.Lg, b, n, t, EF), d, L, 1.0);
+    auto inv_L = [&](Tile Lm) {
         Tile X = tile_eye(L);
         double dummy = 1.0;
         gj16<false>(Lm, X, L, dummy, bad);
@@ -304,15 +338,23 @@ static __global__ __launch_bounds__(64) void km_backward(WideArgs a) {
         Sn = ld_tile<false, false>(wblk(a.uSig, b, a.up.n, p, EF), d, L, 1.0);
         if (HAS_RHS) xn = ld_vec(wblk(a.umu, b, a.up.n, p, d), d, L, 1.0);
     } else {
-        const Tile X = inv_L(te);
+        const Tile yv = HAS_RHS ? ld_vec(wblk(a.yg, b, n, te, d), d, L, 1.0) : tile_zero();
+        const Tile X = inv_L(ld_tile<false, true>(wblk(a.Lg, b, n, te, EF), d, L, 1.0));
         Sn = gram(X, X);
-        if (HAS_RHS) xn = gram(X, ld_vec(wblk(a.yg, b, n, te, d), d, L, 1.0));
+        if (HAS_RHS) xn = gram(X, yv);
     }
     st_tile<false>(wblk(a.Sigg, b, n, te, EF), d, L, Sn);
     if (HAS_RHS) st_vec(wblk(a.mug, b, n, te, d), d, L, xn);
     auto step = [&](int t, bool write_node) {
-        const Tile X = inv_L(t);
+        // every load of the step is issued before the elimination, whose latency then covers them
+        const Tile Lm = ld_tile<false, true>(wblk(a.Lg, b, n, t, EF), d, L, 1.0);
         const Tile Gt = ld_tile<true, false>(wblk(a.Gg, b, n, t, EF), d, L, 1.0);
+        Tile Gm = tile_zero(), yv = tile_zero();
+        if (HAS_RHS) {
+            Gm = ld_tile<false, false>(wblk(a.Gg, b, n, t, EF), d, L, 1.0);
+            yv = ld_vec(wblk(a.yg, b, n, t, d), d, L, 1.0);
+        }
+        const Tile X = inv_L(Lm);
         const Tile H = gram(Gt, X);                 // G L^{-1}
         const Tile SnH = gram(Sn, H);               // Sigma_n H
         if (WANT_SUB) st_tile<false>(wblk(a.Subg, b, n, t, EF), d, L, tile_neg(SnH));
@@ -320,8 +362,7 @@ static __global__ __launch_bounds__(64) void km_backward(WideArgs a) {
         const Tile Sig = gram(H, SnH, gram(X, X));
         st_tile<false>(wblk(a.Sigg, b, n, t, EF), d, L, Sig);
         if (HAS_RHS) {
-            const Tile Gm = ld_tile<false, false>(wblk(a.Gg, b, n, t, EF), d, L, 1.0);
-            const Tile v = gram(tile_neg(Gm), xn, ld_vec(wblk(a.yg, b, n, t, d), d, L, 1.0));      // y - G^T x_n
+            const Tile v = gram(tile_neg(Gm), xn, yv);      // y - G^T x_n
             xn = gram(X, v);
             st_vec(wblk(a.mug, b, n, t, d), d, L, xn);
         }

@@ -32,13 +32,18 @@ struct WideArgs {
 // row i of a d x d block (zero padded), column i of a block
 template <int DM>
 MFGM_DEV void ld_row(const double* __restrict__ blk, int d, int i, double scale, double (&out)[DM]) {
+    // branch-free (out-of-range elements read element 0 and are discarded): all DM loads are in flight together
 #pragma unroll
-    for (int k = 0; k < DM; ++k) out[k] = (i < d && k < d) ? scale * blk[i * d + k] : 0.0;
+    for (int k = 0; k < DM; ++k) out[k] = blk[(i < d && k < d) ? i * d + k : 0];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) out[k] = (i < d && k < d) ? scale * out[k] : 0.0;
 }
 template <int DM>
 MFGM_DEV void ld_col(const double* __restrict__ blk, int d, int i, double scale, double (&out)[DM]) {
 #pragma unroll
-    for (int k = 0; k < DM; ++k) out[k] = (i < d && k < d) ? scale * blk[k * d + i] : 0.0;
+    for (int k = 0; k < DM; ++k) out[k] = blk[(i < d && k < d) ? k * d + i : 0];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) out[k] = (i < d && k < d) ? scale * out[k] : 0.0;
 }
 template <int DM>
 MFGM_DEV void st_row(double* __restrict__ blk, int d, int i, const double (&v)[DM]) {
@@ -145,6 +150,12 @@ MFGM_DEV void inv_t_rows(const double (&L)[DM], double (&Xt)[DM], double* tile, 
     __syncthreads();
 }
 
+// element `lane` of a d-vector (0 beyond d), branch-free
+MFGM_DEV double ld_elem(const double* __restrict__ v, int lane, int d) {
+    const double x = v[lane < d ? lane : 0];
+    return lane < d ? x : 0.0;
+}
+
 MFGM_DEV const double* wblk(const double* base, int b, int n, int t, int E) { return base + ((size_t)b * n + t) * E; }
 MFGM_DEV double* wblk(double* base, int b, int n, int t, int E) { return base + ((size_t)b * n + t) * E; }
 
@@ -171,7 +182,7 @@ static __global__ __launch_bounds__(64) void kw_reduce(WideArgs a) {
         for (int k = 0; k < DM; ++k) Z[k] = 0.0;
     }
     if (HAS_RHS) {
-        h = (lane < d) ? a.aR * wblk(a.rg, b, n, t0, d)[lane] : 0.0;
+        h = a.aR * ld_elem(wblk(a.rg, b, n, t0, d), lane, d);
         if (HAS_CORR && lane < d) h -= wblk(a.rcorr, b, n, t0, d)[lane];
     }
 #pragma unroll
@@ -190,7 +201,7 @@ static __global__ __launch_bounds__(64) void kw_reduce(WideArgs a) {
         if (lane >= d && lane < DM) Fn[lane] = 1.0;
         double hn = 0.0;
         if (HAS_RHS) {
-            hn = (lane < d) ? a.aR * wblk(a.rg, b, n, t + 1, d)[lane] : 0.0;
+            hn = a.aR * ld_elem(wblk(a.rg, b, n, t + 1, d), lane, d);
             if (HAS_CORR && lane < d) hn -= wblk(a.rcorr, b, n, t + 1, d)[lane];
         }
         chol_rsolve<DM, true>(F, invd, G, Z, lane, bad);   // G <- S L^{-T},  Z <- Z L^{-T}  (Z^T = L^{-1} W)
@@ -251,8 +262,8 @@ static __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
         if (lane >= d && lane < DM) Fa[lane] = 1.0;
         double ha = 0.0;
         if (HAS_RHS) {
-            const double yt = (lane < d) ? wblk(a.uy, b, un, p - 1, d)[lane] : 0.0;
-            ha = mv<DM>(Lt, yt) + ((lane < d) ? wblk(a.urho, b, un, p - 1, d)[lane] : 0.0);
+            const double yt = ld_elem(wblk(a.uy, b, un, p - 1, d), lane, d);
+            ha = mv<DM>(Lt, yt) + (ld_elem(wblk(a.urho, b, un, p - 1, d), lane, d));
         }
         ld_row<DM>(wblk(a.Sg, b, n, t0 - 1, EF), d, lane, a.aS, Ga);
         chol_rsolve<DM, false>(Fa, invd, Ga, dummy, lane, bad);
@@ -275,7 +286,7 @@ static __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
         if (lane >= d && lane < DM) F[lane] = 1.0;
         double h = 0.0;
         if (HAS_RHS) {
-            h = (lane < d) ? a.aR * wblk(a.rg, b, n, t, d)[lane] : 0.0;
+            h = a.aR * ld_elem(wblk(a.rg, b, n, t, d), lane, d);
             if (HAS_CORR && lane < d) h -= wblk(a.rcorr, b, n, t, d)[lane];
             h -= c;
         }
@@ -334,7 +345,7 @@ static __global__ __launch_bounds__(64) void kw_backward(WideArgs a) {
     double Sn[DM], xn = 0.0;
     if (HAS_UP) {
         ld_row<DM>(wblk(a.uSig, b, a.up.n, p, EF), d, lane, 1.0, Sn);
-        if (HAS_RHS) xn = (lane < d) ? wblk(a.umu, b, a.up.n, p, d)[lane] : 0.0;
+        if (HAS_RHS) xn = ld_elem(wblk(a.umu, b, a.up.n, p, d), lane, d);
     } else {
         double Xt[DM];
         inv_t(te, Xt);
@@ -342,7 +353,7 @@ static __global__ __launch_bounds__(64) void kw_backward(WideArgs a) {
         for (int k = 0; k < DM; ++k) Sn[k] = 0.0;
         mm_abt<DM>(Xt, Xt, 1.0, Sn);
         if (HAS_RHS) {
-            const double y = (lane < d) ? wblk(a.yg, b, n, te, d)[lane] : 0.0;
+            const double y = ld_elem(wblk(a.yg, b, n, te, d), lane, d);
             xn = mv<DM>(Xt, y);
         }
     }
@@ -363,7 +374,7 @@ static __global__ __launch_bounds__(64) void kw_backward(WideArgs a) {
         mm_abt<DM>(T1, Ht, 1.0, Sig);        // Sigma_t = Xt Xt^T + Ht Sigma_n Ht^T
         st_row<DM>(wblk(a.Sigg, b, n, t, EF), d, lane, Sig);
         if (HAS_RHS) {
-            const double y = (lane < d) ? wblk(a.yg, b, n, t, d)[lane] : 0.0;
+            const double y = ld_elem(wblk(a.yg, b, n, t, d), lane, d);
             const double v = y - mv<DM>(Gt, xn);
             xn = mv<DM>(Xt, v);
             if (lane < d) wblk(a.mug, b, n, t, d)[lane] = xn;
@@ -397,7 +408,7 @@ static __global__ __launch_bounds__(64) void kw_ssm_to_naturals(int B, int T, in
     double Qi[DM];
     qinv(t, Qi);
     double lin = 0.0;
-    if (WANT_LIN) lin = mv<DM>(Qi, (lane < d) ? wblk(offg, b, T, t, d)[lane] : 0.0);
+    if (WANT_LIN) lin = mv<DM>(Qi, ld_elem(wblk(offg, b, T, t, d), lane, d));
     if (t + 1 < T) {
         double Q1[DM], A[DM], At[DM], M[DM];
         qinv(t + 1, Q1);
@@ -408,7 +419,7 @@ static __global__ __launch_bounds__(64) void kw_ssm_to_naturals(int B, int T, in
         mm_ab<DM>(Q1, A, 1.0, M);                     // Qi_{t+1} A
         mm_ab<DM>(At, M, 1.0, Qi);                    // + A^T Qi_{t+1} A
         if (WANT_LIN) {
-            const double z1 = mv<DM>(Q1, (lane < d) ? wblk(offg, b, T, t + 1, d)[lane] : 0.0);
+            const double z1 = mv<DM>(Q1, ld_elem(wblk(offg, b, T, t + 1, d), lane, d));
             lin -= mv<DM>(At, z1);
         }
 #pragma unroll
