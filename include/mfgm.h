@@ -234,6 +234,22 @@ int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, 
 
 const char* mfgm_version(void);
 
+/* ---- one long chain over several processes (wide plans, i.e. 8 < d <= 32) ---------------------------------
+ * The reference has no counterpart (it runs one chain on one device); this is the partitioned solver's own level structure used
+ * across GPUs.  Every process creates the SAME plan (same B, T, d, R0, Rup), owns a contiguous range [seg_lo, seg_hi) of the
+ * level-0 segments (nodes [seg_lo*R0, min(seg_hi*R0, T))), and holds the inputs of its own nodes plus the one sub-diagonal
+ * block to the left of its first node (arrays are addressed with global node indices).
+ *   factor:  mfgm_packed_factor_phase(phase 0)   zero the level-1 inputs, level-0 reduce of the owned segments
+ *            all-reduce(sum) of the workspace region given by mfgm_plan_exchange_region (every entry has one writer)
+ *            mfgm_packed_factor_phase(phase 1)   coarser levels (replicated on every process), level-0 forward of the owned
+ *                                                segments; logdet / quad are the partial sums over the owned segments
+ *   selected inverse: mfgm_packed_selinv as usual (coarser levels replicated, level 0 on the owned segments, no communication). */
+int mfgm_plan_set_shard(mfgm_plan* plan, int seg_lo, int seg_hi);
+int mfgm_plan_exchange_region(const mfgm_plan* plan, size_t* offset_doubles, size_t* count_doubles);
+int mfgm_packed_factor_phase(const mfgm_plan* plan, int phase, const double* D, const double* S, const double* r, double aD,
+                             double aS, double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws,
+                             int* info, void* stream);
+
 /* ---- batched small dense SPD algebra on natural-layout arrays -----------------------------------------------------------
  * The per-time-step algebra around the sweeps that has no fused kernel of its own: replaces the reference's
  * tf.linalg.cholesky / tf.linalg.cholesky_solve / tf.linalg.triangular_solve calls on [..., d, d] blocks

@@ -283,3 +283,101 @@ def test_sparse_cvi_d16(amd, rng):
     omu, ovar = npc.predict_f(o.dist_q, _sum16(np_kernels), z, tn)
     assert_close(host(mu), omu, rtol=1e-5)
     assert_close(host(var), ovar, rtol=1e-5)
+
+
+class _ThreadAllReduce:
+    """In-process stand-in for the all-reduce of a process group: one thread per rank, tensors summed at a barrier."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.bar, self.slots, self.total = world, threading.Barrier(world), [None] * world, None
+
+    def for_rank(self, rank):
+        import torch
+
+        def allreduce(t):
+            torch.cuda.synchronize()
+            self.slots[rank] = t
+            self.bar.wait()
+            if rank == 0:
+                self.total = torch.stack(self.slots).sum(0)
+            self.bar.wait()
+            t.copy_(self.total)
+            torch.cuda.synchronize()
+            self.bar.wait()
+            return t
+        return allreduce
+
+
+@pytest.mark.parametrize("d,T,R0,world", [(16, 400, 10, 4), (12, 333, 7, 3), (30, 200, 8, 2), (16, 64, 8, 8)])
+def test_one_chain_sharded_over_ranks(amd, rng, d, T, R0, world):
+    """SURVEY 8e, second row (config 5): one chain cut over `world` ranks (here threads sharing the GPU, each with its own plan,
+    workspace and a copy of the inputs that is NaN outside the nodes the rank is entitled to read).  Every rank's slice of the
+    factor, the marginals and the solve equals the single-process result; the log-determinant and |L^{-1} r|^2 are summed."""
+    import threading
+    import torch
+    from vidp_amd.distributed import ChainShard
+    B = 2
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    whole = amd.Plan(B, T, d, R0=R0)
+    Dp, Sp, rp = whole.pack(amd.SYM, dev(diag)), whole.pack(amd.FULL, dev(sub)), whole.pack(amd.VEC, dev(r))
+    f0 = whole.factor(Dp, Sp, rp, want_logdet=True, want_quad=True)
+    s0 = whole.selinv(f0["L"], f0["G"], f0["y"])
+    whole.check_info()
+    ref = {k: host(whole.unpack(kind, arr, n)) for k, kind, arr, n in (
+        ("L", amd.TRI, f0["L"], T), ("G", amd.FULL, f0["G"], T - 1), ("y", amd.VEC, f0["y"], T), ("Sig", amd.SYM, s0["Sig"], T),
+        ("Sub", amd.FULL, s0["Sub"], T - 1), ("x", amd.VEC, s0["x"], T))}
+    group = _ThreadAllReduce(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            plan = amd.Plan(B, T, d, R0=R0)
+            sh = ChainShard(plan, rank, world, allreduce=group.for_rank(rank))
+            lo, hi = sh.node_lo, sh.node_hi
+            Dn, Sn, rn = np.full_like(diag, np.nan), np.full((B, T, d, d), np.nan), np.full_like(r, np.nan)
+            Dn[:, lo:hi], rn[:, lo:hi] = diag[:, lo:hi], r[:, lo:hi]
+            slo, shi = max(lo - 1, 0), min(hi, T - 1)
+            Sn[:, slo:shi] = sub[:, slo:shi]
+            # the arrays of a wide plan are the natural ones: hand them over without the symmetrising pack
+            f = sh.factor(dev(Dn).reshape(-1), dev(Sn).reshape(-1), dev(rn).reshape(-1), want_logdet=True, want_quad=True)
+            s = sh.selinv(f["L"], f["G"], f["y"])
+            plan.check_info()
+            res = {k: host(plan.unpack(kind, arr, n)) for k, kind, arr, n in (
+                ("L", amd.TRI, f["L"], T), ("G", amd.FULL, f["G"], T - 1), ("y", amd.VEC, f["y"], T), ("Sig", amd.SYM, s["Sig"], T),
+                ("Sub", amd.FULL, s["Sub"], T - 1), ("x", amd.VEC, s["x"], T))}
+            out[rank] = (lo, hi, res, host(f["logdet"]), host(f["quad"]))
+        except Exception as e:      # surfaced in the main thread
+            errs.append((rank, repr(e)))
+            group.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+    covered = 0
+    for lo, hi, res, logdet, quad in out:
+        covered += hi - lo
+        for k in ("L", "y", "Sig", "x"):
+            assert_close(res[k][:, lo:hi], ref[k][:, lo:hi], rtol=1e-9)
+        assert_close(res["G"][:, lo:min(hi, T - 1)], ref["G"][:, lo:min(hi, T - 1)], rtol=1e-9)
+        # Sigma_{t+1,t} is produced together with Sigma_{t+1}: a rank owns the cross-covariances [lo - 1, hi - 1)
+        assert_close(res["Sub"][:, max(lo - 1, 0):hi - 1], ref["Sub"][:, max(lo - 1, 0):hi - 1], rtol=1e-9)
+        np.testing.assert_allclose(logdet, host(f0["logdet"]), rtol=1e-12)
+        np.testing.assert_allclose(quad, host(f0["quad"]), rtol=1e-12)
+    assert covered == T
+
+
+def test_one_chain_two_processes():
+    """The same sharded solve through a real process group: 2 ranks (gloo, rendezvous on 127.0.0.1) sharing the one GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(root, "tests", "mp_chain_shard.py")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "chain shard parity ok 2" in res.stdout

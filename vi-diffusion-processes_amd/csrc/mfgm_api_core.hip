@@ -58,6 +58,8 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
         ++l;
     }
     P.nlevels = l;
+    P.seg_lo = 0;
+    P.seg_hi = P.lv[0].P;
     size_t off = 0;
     auto take = [&](size_t nd) { size_t o = off; off += (nd + 63) / 64 * 64; return o; };
     // per-segment partial sums; the wide local kernels keep one partial per node
@@ -81,6 +83,24 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
 }
 
 void mfgm_plan_destroy(mfgm_plan* plan) { delete plan; }
+
+int mfgm_plan_set_shard(mfgm_plan* plan, int seg_lo, int seg_hi) {
+    if (!plan) return 1;
+    Plan& P = plan->p;
+    if (!P.wide || P.nlevels < 2 || seg_lo < 0 || seg_hi > P.lv[0].P || seg_lo >= seg_hi) return 1;
+    P.seg_lo = seg_lo;
+    P.seg_hi = seg_hi;
+    return 0;
+}
+
+int mfgm_plan_exchange_region(const mfgm_plan* plan, size_t* offset_doubles, size_t* count_doubles) {
+    if (!plan || !offset_doubles || !count_doubles) return 1;
+    const Plan& P = plan->p;
+    if (P.nlevels < 2) return 1;
+    *offset_doubles = P.off_Dhat[1];
+    *count_doubles = P.off_L[1] - P.off_Dhat[1];
+    return 0;
+}
 
 int mfgm_plan_describe(const mfgm_plan* plan, int* out6) {
     if (!plan || !out6) return 1;

@@ -5,7 +5,7 @@
 namespace mfgm {
 
 int mfma_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
-    dim3 grid(a.lv.L), block(64);
+    dim3 grid((a.lv.L / a.lv.P) * a.nseg), block(64);   // chains x covered segments
 #define KM(K) hipLaunchKernelGGL((K), grid, block, 0, st, a)
     if (which == 0) {
         if (has_rhs) { if (has_corr) KM((km_reduce<true, true>)); else KM((km_reduce<true, false>)); }

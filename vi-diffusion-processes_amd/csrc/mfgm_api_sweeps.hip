@@ -215,4 +215,15 @@ int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* 
     MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st, only_level, mom)));
 }
 
+
+int mfgm_packed_factor_phase(const mfgm_plan* plan, int phase, const double* D, const double* S, const double* r, double aD,
+                             double aS, double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws,
+                             int* info, void* stream) {
+    if (!plan || !D || !L || !G || !info || !ws || (phase != 0 && phase != 1)) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide || P.nlevels < 2 || !S) return 1;
+    if ((r != nullptr) != (y != nullptr)) return 1;
+    return wide_factor(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, phase);
+}
+
 }  // extern "C"

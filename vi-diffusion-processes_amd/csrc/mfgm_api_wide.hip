@@ -10,7 +10,7 @@ namespace {
 // ---- wide (8 < d <= 32) drivers: same level recursion, one wavefront per segment ------------------------------------
 template <int DM>
 int wide_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
-    dim3 grid(a.lv.L), block(64);
+    dim3 grid((a.lv.L / a.lv.P) * a.nseg), block(64);   // chains x covered segments
 #define KW(K) hipLaunchKernelGGL((K), grid, block, 0, st, a)
     if (which == 0) {
         if (has_rhs) { if (has_corr) KW((kw_reduce<DM, true, true>)); else KW((kw_reduce<DM, true, false>)); }
@@ -53,6 +53,8 @@ void wide_bind(const Plan& P, int l, double* ws, WideArgs& a) {
     const int K = P.nlevels - 1;
     a.lv = P.lv[l];
     a.d = P.d;
+    a.seg_lo = (l == 0) ? P.seg_lo : 0;
+    a.nseg = (l == 0) ? P.seg_hi - P.seg_lo : P.lv[l].P;
     if (l > 0) {
         a.Dg = ws + P.off_Dhat[l]; a.Dcorr = ws + P.off_Rsub[l]; a.Sg = ws + P.off_S[l];
         a.rg = ws + P.off_rhat[l]; a.rcorr = ws + P.off_rho[l];
@@ -72,10 +74,15 @@ void wide_bind(const Plan& P, int l, double* ws, WideArgs& a) {
 
 namespace mfgm {
 
+// phase -1: the whole factorisation (plans that own every segment);  phase 0: zero the level-1 inputs and run the level-0
+// reduce on the owned segments (a sharded chain then sums the level-1 inputs over the processes);  phase 1: everything after.
 int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
-                double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st) {
+                double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st,
+                int phase) {
     const bool has_rhs = (rg != nullptr);
     const int K = P.nlevels - 1;
+    const bool sharded = (P.seg_lo != 0 || P.seg_hi != P.lv[0].P);
+    if (sharded && (phase < 0 || K == 0)) return 1;
     auto make = [&](int l) {
         WideArgs a;
         memset(&a, 0, sizeof(a));
@@ -88,15 +95,29 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
         wide_bind(P, l, ws, a);
         return a;
     };
-    for (int l = 0; l < K; ++l) {
-        int rc = wide_dispatch(P.d, 0, make(l), has_rhs, l > 0, true, false, st);
+    if (phase <= 0) {
+        if (phase == 0 && K > 0) {
+            if (hipMemsetAsync(ws + P.off_Dhat[1], 0, (P.off_L[1] - P.off_Dhat[1]) * sizeof(double), st) != hipSuccess) return 3;
+        }
+        if (K > 0) {
+            int rc = wide_dispatch(P.d, 0, make(0), has_rhs, false, true, false, st);
+            if (rc) return rc;
+        }
+        if (phase == 0) return 0;
+    }
+    for (int l = 1; l < K; ++l) {
+        int rc = wide_dispatch(P.d, 0, make(l), has_rhs, true, true, false, st);
         if (rc) return rc;
+    }
+    if (sharded && (logdet || quad)) {
+        if (hipMemsetAsync(ws + P.off_part[0], 0, 2 * (size_t)P.lv[0].Lpad * sizeof(double), st) != hipSuccess) return 3;
     }
     for (int l = K; l >= 0; --l) {
         int rc = wide_dispatch(P.d, 1, make(l), has_rhs, l > 0, l < K, false, st);
         if (rc) return rc;
     }
     if (logdet || quad) {
+        // on a sharded plan these are the partial sums over the owned segments
         hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
         MFGM_CHECK_LAUNCH();
     }

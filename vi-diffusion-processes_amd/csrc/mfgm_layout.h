@@ -31,6 +31,7 @@ struct Plan {
     int B, T, d;
     int wide;      // d > 8: wavefront-per-segment kernels on natural-layout arrays (mfgm_wide.h)
     int nlevels;
+    int seg_lo, seg_hi;   // level-0 segments this process owns (wide plans; the whole range unless mfgm_plan_set_shard was called)
     LevelDesc lv[kMaxLevels];
     // per-level workspace offsets (in doubles) into the plan-owned level workspace, levels >= 1
     size_t off_Dhat[kMaxLevels], off_Rsub[kMaxLevels], off_S[kMaxLevels], off_rhat[kMaxLevels], off_rho[kMaxLevels];

@@ -192,7 +192,7 @@ static __global__ __launch_bounds__(64) void km_reduce(WideArgs a) {
     const LaneId L{(int)threadIdx.x, (int)threadIdx.x >> 4, (int)threadIdx.x & 15};
     const int d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int b = blockIdx.x / a.nseg, p = a.seg_lo + ((int)blockIdx.x - b * a.nseg);   // this launch covers segments [seg_lo, seg_lo + nseg)
     const int t0 = p * R, len = min(R, n - t0);
     int bad = 0;
     double prod = 1.0;
@@ -255,7 +255,7 @@ static __global__ __launch_bounds__(64) void km_forward(WideArgs a) {
     const LaneId L{(int)threadIdx.x, (int)threadIdx.x >> 4, (int)threadIdx.x & 15};
     const int d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int b = blockIdx.x / a.nseg, p = a.seg_lo + ((int)blockIdx.x - b * a.nseg);   // this launch covers segments [seg_lo, seg_lo + nseg)
     const int t0 = p * R, len = min(R, n - t0);
     int bad = 0;
     Tile C = tile_zero(), cv = tile_zero();
@@ -312,8 +312,8 @@ static __global__ __launch_bounds__(64) void km_forward(WideArgs a) {
         }
     }
     if (a.part && L.lane == 0) {
-        a.part[blockIdx.x] = -la.value();
-        a.part[a.lv.Lpad + blockIdx.x] = quad;
+        a.part[b * P + p] = -la.value();
+        a.part[a.lv.Lpad + b * P + p] = quad;
     }
     if (bad && L.lane == 0) atomicMax(a.info, 1);
 }
@@ -324,7 +324,7 @@ static __global__ __launch_bounds__(64) void km_backward(WideArgs a) {
     const LaneId L{(int)threadIdx.x, (int)threadIdx.x >> 4, (int)threadIdx.x & 15};
     const int d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int b = blockIdx.x / a.nseg, p = a.seg_lo + ((int)blockIdx.x - b * a.nseg);   // this launch covers segments [seg_lo, seg_lo + nseg)
     const int t0 = p * R, len = min(R, n - t0), te = t0 + len - 1;
     int bad = 0;
     auto inv_L = [&](Tile Lm) {

@@ -20,6 +20,7 @@ MFGM_DEV double bcast(double x, int src) {
 struct WideArgs {
     LevelDesc lv, up;
     int d;
+    int seg_lo, nseg;   // segments of this level covered by the launch (all of them except on a sharded level 0)
     const double* Dg; const double* Sg; const double* rg; const double* Dcorr; const double* rcorr;
     double aD, aS, aR;
     double* Lg; double* Gg; double* yg; double* part;
@@ -164,7 +165,7 @@ template <int DM, bool HAS_RHS, bool HAS_CORR>
 static __global__ __launch_bounds__(64) void kw_reduce(WideArgs a) {
     const int lane = threadIdx.x, d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int b = blockIdx.x / a.nseg, p = a.seg_lo + ((int)blockIdx.x - b * a.nseg);   // this launch covers segments [seg_lo, seg_lo + nseg)
     const int t0 = p * R, len = min(R, n - t0);
     int bad = 0;
     double F[DM], Z[DM], Racc[DM], h = 0.0, rho = 0.0;
@@ -246,7 +247,7 @@ template <int DM, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
 static __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
     const int lane = threadIdx.x, d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int b = blockIdx.x / a.nseg, p = a.seg_lo + ((int)blockIdx.x - b * a.nseg);   // this launch covers segments [seg_lo, seg_lo + nseg)
     const int t0 = p * R, len = min(R, n - t0);
     int bad = 0;
     double C[DM], c = 0.0;
@@ -319,8 +320,8 @@ static __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
         }
     }
     if (a.part && lane == 0) {
-        a.part[blockIdx.x] = logacc;
-        a.part[a.lv.Lpad + blockIdx.x] = quad;
+        a.part[b * P + p] = logacc;
+        a.part[a.lv.Lpad + b * P + p] = quad;
     }
     if (bad && lane == 0) atomicMax(a.info, 1);
 }
@@ -332,7 +333,7 @@ template <int DM, bool HAS_RHS, bool HAS_UP, bool WANT_SUB>
 static __global__ __launch_bounds__(64) void kw_backward(WideArgs a) {
     const int lane = threadIdx.x, d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int b = blockIdx.x / a.nseg, p = a.seg_lo + ((int)blockIdx.x - b * a.nseg);   // this launch covers segments [seg_lo, seg_lo + nseg)
     const int t0 = p * R, len = min(R, n - t0), te = t0 + len - 1;
     __shared__ double tile[DM * (DM + 1)];
     // Xt = L^{-T} held by rows

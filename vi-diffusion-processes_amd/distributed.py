@@ -46,3 +46,67 @@ def allreduce_max_(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
+
+
+class ChainShard:
+    """
+    One long chain over several GPUs (SURVEY 8e second row, config 5): the time axis is cut at level-0 segment boundaries, rank k
+    owns segments [seg_lo, seg_hi).  Per factorisation there is one real exchange: the level-1 separator system
+    (P x (3 d^2 + 2 d) doubles, every entry written by one rank) is summed over the ranks with one all-reduce (plus a 2 d^2 halo of
+    factor blocks per cut and the scalar log-determinant / quadratic-form sums); the coarser levels
+    are then solved redundantly on every rank and the level-0 forward / backward sweeps touch only the owned segments.
+    Wide plans (8 < d <= 32) only.  Arrays are addressed with global node indices: a rank needs the inputs of its own nodes
+    [node_lo, node_hi) and the sub-diagonal block at node_lo - 1; its outputs are valid on its own nodes (the cross-covariances
+    Sigma_{t+1,t} on [node_lo - 1, node_hi - 1): each is produced together with Sigma_{t+1}).
+
+    `allreduce` defaults to the in-place sum over the torch.distributed group; tests on a single GPU inject one that sums over
+    several shard objects living in the same process.
+    """
+
+    def __init__(self, plan, rank, world, allreduce=None):
+        import ctypes
+        from . import _lib
+        self.plan, self.rank, self.world = plan, int(rank), int(world)
+        if plan.P < self.world:
+            raise ValueError(f"{plan.P} level-0 segments cannot be shared by {world} ranks: use a smaller R0")
+        self.seg_lo, self.seg_hi = shard_bounds(plan.P, self.rank, self.world)
+        _lib.check(plan.lib.mfgm_plan_set_shard(plan.h, self.seg_lo, self.seg_hi), "mfgm_plan_set_shard (wide plans with >= 2 levels only)")
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(plan.lib.mfgm_plan_exchange_region(plan.h, ctypes.byref(off), ctypes.byref(cnt)), "mfgm_plan_exchange_region")
+        self.exchange = plan.ws[off.value:off.value + cnt.value]
+        self.node_lo, self.node_hi = self.seg_lo * plan.R, min(self.seg_hi * plan.R, plan.T)
+        self._allreduce = allreduce if allreduce is not None else allreduce_sum_
+
+    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False):
+        """Block Cholesky of the sharded chain.  Returns dict(L, G, y, logdet, quad) with logdet / quad already summed over ranks."""
+        from ._lib import FULL, TRI, VEC, check
+        from .packed import _ptr, _stream
+        pl = self.plan
+        L, G = pl.empty(TRI), pl.empty(FULL)
+        y = pl.empty(VEC) if r is not None else None
+        pl.epoch += 1
+        logdet = torch.empty(pl.B, dtype=torch.float64, device=pl.device) if want_logdet else None
+        quad = torch.empty(pl.B, dtype=torch.float64, device=pl.device) if want_quad else None
+        args = (_ptr(D), _ptr(S), _ptr(r), float(aD), float(aS), float(aR), _ptr(L), _ptr(G), _ptr(y), _ptr(logdet), _ptr(quad),
+                _ptr(pl.ws), _ptr(pl.info), _stream())
+        check(pl.lib.mfgm_packed_factor_phase(pl.h, 0, *args), "mfgm_packed_factor_phase(0)")
+        self._allreduce(self.exchange)
+        check(pl.lib.mfgm_packed_factor_phase(pl.h, 1, *args), "mfgm_packed_factor_phase(1)")
+        # halo: the factor blocks of the node to the left of the first owned node (needed for Sigma_{lo, lo-1}); 2 d^2 doubles per cut
+        B, T, d = pl.B, pl.T, pl.d
+        Lv, Gv = L.view(B, T, d, d), G.view(B, T, d, d)
+        halo = torch.zeros((self.world, 2, B, d, d), dtype=torch.float64, device=pl.device)
+        if self.node_hi < T:
+            halo[self.rank, 0], halo[self.rank, 1] = Lv[:, self.node_hi - 1], Gv[:, self.node_hi - 1]
+        self._allreduce(halo)
+        if self.node_lo > 0:
+            Lv[:, self.node_lo - 1], Gv[:, self.node_lo - 1] = halo[self.rank - 1, 0], halo[self.rank - 1, 1]
+        if logdet is not None:
+            self._allreduce(logdet)
+        if quad is not None:
+            self._allreduce(quad)
+        return dict(L=L, G=G, y=y, logdet=logdet, quad=quad)
+
+    def selinv(self, L, G, y=None, want_sub=True):
+        """Selected inverse on the owned nodes (no communication: the coarse levels are replicated)."""
+        return self.plan.selinv(L, G, y, want_sub=want_sub)
