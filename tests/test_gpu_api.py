@@ -596,3 +596,64 @@ def test_sparse_cvi_and_posterior(amd, rng, kname):
     omu, ovar = npc.predict_f(o2.dist_q, mk(np_kernels), z, tn)
     assert_close(host(mu), omu)
     assert_close(host(var), ovar)
+
+
+def test_exp_io_checkpoints(amd, rng, tmp_path):
+    """On-disk formats of the reference's experiments: data .npz schema (exp_dp_utils.py:108-125), cvi_model.npz /
+    posteriors.npz (cvi_dp.py:140-149), vi_gp_model.npz (vi_markov_gp.py:175-178) and the CVI-DP -> VDP warm start
+    (vi_markov_gp.py:89-115): key names and shapes as the reference writes them, and save -> load reproduces the model."""
+    import torch
+    from vidp_amd import exp_io, sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    T, dt, d = 70, 0.01, 2
+    grid = np.arange(T) * dt
+    idx = np.arange(4, T - 1, 6)
+    y = np.sign(rng.normal(size=(1, len(idx), d))) + 0.1 * rng.normal(size=(1, len(idx), d))
+    path = str(tmp_path / "data.npz")
+    exp_io.save_exp_data(path, Q=np.eye(d), x0=np.ones(d), sigma=0.3, latent_process=rng.normal(size=(T, d)), observation_grid=grid[idx],
+                         observations=y[0], test_grid=grid[[3, 9]], test_observations=y[0, :2], time_grid=grid)
+    Q, x0, noise, latent, obs, tg, test = exp_io.load_exp_data(path)
+    assert noise.shape == (1, 1) and tuple(obs[1].shape) == (len(idx), d) and obs[0].is_cuda and tuple(tg.shape) == (T,)
+    np.testing.assert_array_equal(host(obs[1]), y[0])
+    lik = MultivariateGaussian(dev(noise.item() * np.eye(d)))
+    init = (np.zeros(d), np.eye(d))
+    mk = lambda: CVISitesSDE(gsde.DoubleWellSDE(q=torch.eye(d, dtype=torch.float64)), grid, (obs[0], obs[1][None]), lik, prior_initial_state=init)
+    m = mk()
+    for _ in range(3):
+        m.update_data_sites(0.5)
+        m.update_girsanov_sites(0.2)
+    out = str(tmp_path / "run")
+    exp_io.save_cvi_model(out, m)
+    z = np.load(out + "/cvi_model.npz")
+    assert sorted(z.files) == sorted(["data_sites_nat1", "data_sites_nat2", "girsanov_sites_nat1", "girsanov_sites_nat2_diag",
+                                      "girsanov_sites_nat2_subdiag"])
+    assert z["data_sites_nat1"].shape == (len(idx), d) and z["girsanov_sites_nat2_subdiag"].shape == (T - 1, d, d)
+    post = np.load(out + "/posteriors.npz")
+    assert post["cvi_m"].shape == (T, d) and post["cvi_S"].shape == (T, d, d) and post["time_grid"].shape == (T,)
+    m2 = exp_io.load_cvi_model(out, mk())
+    np.testing.assert_allclose(host(m2.classic_elbo_per_trajectory()), host(m.classic_elbo_per_trajectory()), rtol=1e-10)
+    mu2, S2 = m2.dist_q.marginals
+    assert_close(host(mu2).reshape(T, d), post["cvi_m"], rtol=1e-9)
+    assert_close(host(S2).reshape(T, d, d), post["cvi_S"], rtol=1e-9)
+    # VDP: warm start from the CVI posterior, checkpoint round trip
+    mkv = lambda: VariationalMarkovGP((obs[0], obs[1][None]), gsde.DoubleWellSDE(q=torch.eye(d, dtype=torch.float64)), grid, lik,
+                                      prior_initial_state=init)
+    v = exp_io.warm_start_vdp_from_cvi(mkv(), m)
+    ssm = m.dist_q
+    A_ref = -(host(ssm.state_transitions).reshape(T - 1, d, d) - np.eye(d)) / dt
+    assert_close(host(v.plan.unpack(amd.FULL, v.A, T - 1))[0], A_ref, rtol=1e-12)
+    assert_close(host(v.plan.unpack(amd.VEC, v.b))[0, :T - 1], host(ssm.state_offsets).reshape(T - 1, d) / dt, rtol=1e-12)
+    mS = v._forward_packed()
+    v.update_lagrange(mS)
+    v.update_param(mS, lr=0.05)
+    exp_io.save_vi_gp_model(out, v)
+    zv = np.load(out + "/vi_gp_model.npz")
+    assert sorted(zv.files) == sorted(["A", "b", "lambda_lagrange", "psi_lagrange", "x0_m", "x0_S"])
+    assert zv["A"].shape == (T - 1, d, d) and zv["lambda_lagrange"].shape == (T - 1, d) and zv["x0_S"].shape == (d, d)
+    v2 = exp_io.load_vi_gp_model(out, mkv())
+    np.testing.assert_allclose(host(v2.elbo_per_trajectory()), host(v.elbo_per_trajectory()), rtol=1e-10)
+    with pytest.raises(ValueError):
+        exp_io.load_vi_gp_model(out, VariationalMarkovGP((obs[0][:3], obs[1][None, :3]), gsde.DoubleWellSDE(q=torch.eye(d, dtype=torch.float64)),
+                                                         grid[:40], lik, prior_initial_state=init))
