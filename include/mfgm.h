@@ -234,6 +234,10 @@ int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, 
 
 const char* mfgm_version(void);
 
+/* Natural [B, T, 3d] view (mu, diag Sigma_tt, diag Sigma_{t+1,t}) of the packed moment array written by
+ * mfgm_packed_selinv_mom; used by the prior-parameter gradients (variational_cvi_sde.py:495-506).  d <= 8 plans. */
+int mfgm_unpack_moments(const mfgm_plan* plan, const double* packed_mom, double* natural, void* stream);
+
 /* ---- one long chain over several processes (wide plans, i.e. 8 < d <= 32) ---------------------------------
  * The reference has no counterpart (it runs one chain on one device); this is the partitioned solver's own level structure used
  * across GPUs.  Every process creates the SAME plan (same B, T, d, R0, Rup), owns a contiguous range [seg_lo, seg_hi) of the

@@ -145,6 +145,21 @@ int mfgm_pack(const mfgm_plan* plan, int kind, const double* natural, int n_node
     return repack(plan, kind, natural, packed, n_nodes, true, stream);
 }
 
+int mfgm_unpack_moments(const mfgm_plan* plan, const double* packed_mom, double* natural, void* stream) {
+    // the moment array is a per-node vector of 3d doubles: same re-layout as a vector of a chain with state dimension 3d
+    if (!plan || !packed_mom || !natural) return 1;
+    const Plan& P = plan->p;
+    if (P.wide) return 1;
+    const LevelDesc& lv = P.lv[0];
+    const int En = 3 * P.d;
+    int CH = std::min(std::max(1, 64 / En), lv.R);
+    dim3 grid(lv.Lpad / 64, ceil_div(lv.R, CH)), block(256);
+    size_t shmem = (size_t)64 * (CH * En + 1) * sizeof(double);
+    hipLaunchKernelGGL((k_repack<false>), grid, block, shmem, (hipStream_t)stream, packed_mom, natural, lv, En, (int)PK_VEC, P.T, CH);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 int mfgm_unpack(const mfgm_plan* plan, int kind, const double* packed, double* natural, int n_nodes, void* stream) {
     return repack(plan, kind, packed, natural, n_nodes, false, stream);
 }

@@ -205,6 +205,12 @@ class Plan:
                                                    _ptr(self.ws), _stream()), "mfgm_packed_selinv_mom")
         return dict(Sig=Sig, Sub=Sub, x=x, mom=mom)
 
+    def unpack_moments(self, mom):
+        """Natural [B, T, 3d] view (mu, diag Sigma_tt, diag Sigma_{t+1,t}) of a packed moment array."""
+        out = torch.empty((self.B, self.T, 3 * self.d), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_unpack_moments(self.h, _ptr(mom), _ptr(out), _stream()), "mfgm_unpack_moments")
+        return out
+
     def sde_lean(self, prm, mom, Sig=None, mode=0, theta_q=None):
         """Moment-array CVI-DP kernel: mode 0 -> per-chain KL partial (add log|L_q| - T d / 2), mode 3 -> theta_q update."""
         q = theta_q if theta_q is not None else (None, None, None)

@@ -40,6 +40,24 @@ class SDE:
         """(alpha, beta) of the Euler map u(x) = x + dt f(x) = alpha x - beta x^3."""
         raise NotImplementedError
 
+    # -- trainable drift parameters (tf.Variable(trainable=...) in the reference, sde.py:150, 197-198) ---------------------
+    _param_names = ()
+
+    @property
+    def trainable_variables(self):
+        """Names of the drift parameters being learnt, in the reference's variable order."""
+        return [n for n in self._param_names if getattr(self, "_trainable", {}).get(n, False)]
+
+    def get(self, name):
+        return float(getattr(self, name))
+
+    def assign(self, name, value):
+        setattr(self, name, float(value))
+
+    def cubic_jacobian(self, dt):
+        """{parameter: (d alpha / d parameter, d beta / d parameter)}."""
+        raise NotImplementedError
+
     def params(self, dt, init_mu, init_cov, lr=0.0, clip=None):
         """Fill the C parameter block (mfgm_sde_params)."""
         d = self.state_dim
@@ -69,9 +87,15 @@ class SDE:
 class OrnsteinUhlenbeckSDE(SDE):
     """dx = -decay x dt + dB, spectral density q (sde.py:134-176)."""
 
-    def __init__(self, decay=1.0, q=None):
+    _param_names = ("decay",)
+
+    def __init__(self, decay=1.0, q=None, trainable=False):
         super().__init__(torch.ones((1, 1), dtype=torch.float64) if q is None else q)
         self.decay = float(decay)
+        self._trainable = {"decay": bool(trainable)}
+
+    def cubic_jacobian(self, dt):
+        return {"decay": (-dt, 0.0)}
 
     def drift(self, x, t=None):
         return -self.decay * x
@@ -90,9 +114,15 @@ class OrnsteinUhlenbeckSDE(SDE):
 class DoubleWellSDE(SDE):
     """dx = scale x (c - x^2) dt + dB (sde.py:179-224)."""
 
-    def __init__(self, q=None, scale=4.0, c=1.0):
+    _param_names = ("scale", "c")
+
+    def __init__(self, q=None, scale_trainable=False, c_trainable=False, scale=4.0, c=1.0):
         super().__init__(torch.ones((1, 1), dtype=torch.float64) if q is None else q)
         self.scale, self.c = float(scale), float(c)
+        self._trainable = {"scale": bool(scale_trainable), "c": bool(c_trainable)}
+
+    def cubic_jacobian(self, dt):
+        return {"scale": (dt * self.c, dt), "c": (dt * self.scale, 0.0)}
 
     def drift(self, x, t=None):
         return self.scale * x * (self.c - x * x)

@@ -2,8 +2,9 @@
 Host-side mirror of the experiment trainers that drive the hot path: `CVISitesTrainer`
 (docs/diffusion_processes/cvi_dp_trainer.py:19-200) and `VIMarkovGPTrainer`
 (docs/diffusion_processes/vi_markov_gp_trainer.py:17-135): the inference loops with their learning-rate decay and
-convergence rules, NLPD / RMSE on held-out grid points (exp_dp_utils.py:189-224).  Prior-parameter learning and the
-wandb / hydra plumbing are out of scope.  One host synchronisation per iteration remains (the ELBO scalar decides
+convergence rules, NLPD / RMSE on held-out grid points (exp_dp_utils.py:189-224), and for CVI-DP the prior-parameter
+learning loop (cvi_dp_trainer.py:138-250: Adam on the drift parameters with the KL + VE gradients).  The wandb / hydra
+plumbing is out of scope.  One host synchronisation per iteration remains (the ELBO scalar decides
 the learning-rate decay), everything else stays on the device.
 """
 import logging
@@ -50,15 +51,80 @@ class _Metrics:
         return nlpd, rmse
 
 
+class _Adam:
+    """tf.optimizers.Adam defaults (beta_1 0.9, beta_2 0.999, epsilon 1e-7) on a short list of scalars."""
+
+    def __init__(self, lr, n):
+        self.lr, self.m, self.v, self.t = float(lr), [0.0] * n, [0.0] * n, 0
+
+    def step(self, values, grads):
+        self.t += 1
+        out = []
+        for i, (x, g) in enumerate(zip(values, grads)):
+            self.m[i] = 0.9 * self.m[i] + 0.1 * g
+            self.v[i] = 0.999 * self.v[i] + 0.001 * g * g
+            a = self.lr * math.sqrt(1.0 - 0.999 ** self.t) / (1.0 - 0.9 ** self.t)
+            out.append(x - a * self.m[i] / (math.sqrt(self.v[i]) + 1e-7))
+        return out
+
+
 class CVISitesTrainer:
-    """cvi_dp_trainer.py:19-200 (inference part)."""
+    """cvi_dp_trainer.py:19-250."""
 
     def __init__(self, model, test_data=None, prior_sde=None, max_itr=100, optim_tol=1e-2, max_itr_sites_optim=20,
-                 girsanov_sites_lr=0.1, data_sites_lr=0.1):
+                 girsanov_sites_lr=0.1, data_sites_lr=0.1, learn_prior_sde=False, prior_sde_lr=1e-2, learning_max_itr=100,
+                 learning_tol=1e-2):
         self.model, self.prior_sde = model, prior_sde
         self.max_itr, self.optim_tol, self.max_itr_sites_optim = max_itr, optim_tol, max_itr_sites_optim
         self.girsanov_sites_lr, self.data_sites_lr = girsanov_sites_lr, data_sites_lr
         self._metrics = _Metrics(model, test_data, model.time_grid)
+        self.learn_prior_sde, self.prior_sde_lr = bool(learn_prior_sde), float(prior_sde_lr)
+        self.learning_max_itr, self.learning_tol = int(learning_max_itr), float(learning_tol)
+        self.prior_params = {}
+        if self.learn_prior_sde:
+            names = model.prior_sde.trainable_variables
+            if not names:
+                raise ValueError("learn_prior_sde needs a prior SDE with trainable parameters")
+            self.prior_sde_optim = _Adam(self.prior_sde_lr, len(names))
+            self.store_prior_param_vals()
+
+    def store_prior_param_vals(self):
+        """cvi_dp_trainer.py:52-61: history of the trainable drift parameters, keyed by their index."""
+        sde = self.model.prior_sde
+        for i, n in enumerate(sde.trainable_variables):
+            self.prior_params.setdefault(i, []).append(sde.get(n))
+
+    def optimize_prior_sde(self):
+        """cvi_dp_trainer.py:207-250: Adam steps on the drift parameters with d(KL - VE)/d params until the ELBO settles."""
+        from .sde import OrnsteinUhlenbeckSDE
+        model, sde = self.model, self.model.prior_sde
+        elbo_vals, nlpd_vals, rmse_vals = [float(model.classic_elbo())], [], []
+        for _ in range(self.learning_max_itr):
+            grads_kl = model.grad_KL_wrt_prior_params()
+            grads_ve = model.grad_VE_wrt_prior_params()
+            names = sde.trainable_variables
+            new = self.prior_sde_optim.step([sde.get(n) for n in names], [a + b for a, b in zip(grads_kl, grads_ve)])
+            for n, v in zip(names, new):
+                sde.assign(n, v)
+            if isinstance(sde, OrnsteinUhlenbeckSDE):
+                # stationary initial state q / (2 decay) (cvi_dp_trainer.py:231-235)
+                d = model.state_dim
+                cov = torch.diag(torch.tensor(sde.q_diag, dtype=torch.float64)) / (2.0 * sde.decay)
+                model.set_prior_initial_state(torch.zeros(d, dtype=torch.float64).numpy(), cov.numpy())
+            else:
+                model._refresh_sde_params()
+            elbo_vals.append(float(model.classic_elbo()))
+            nl, rm = self._nlpd_rmse()
+            nlpd_vals.append(nl)
+            rmse_vals.append(rm)
+            self.store_prior_param_vals()
+            if elbo_vals[-1] < elbo_vals[-2]:
+                logger.info("Decaying the LR!!!")
+                self.prior_sde_optim.lr /= 2
+            if abs(elbo_vals[-2] - elbo_vals[-1]) < self.learning_tol:
+                logger.info("Prior parameter optimized successfully!!!")
+                break
+        return elbo_vals[1:], nlpd_vals, rmse_vals
 
     def _nlpd_rmse(self):
         q = self.model._refresh()
@@ -105,11 +171,27 @@ class CVISitesTrainer:
         return elbo_vals[1:], nlpd_vals, rmse_vals
 
     def optimize(self):
-        """cvi_dp_trainer.py:138-176 without prior learning."""
-        e0 = float(self.model.classic_elbo())
+        """cvi_dp_trainer.py:138-187: inference, then (optionally) alternate with prior-parameter learning."""
+        elbo_vals = [float(self.model.classic_elbo())]
         n0, r0 = self._nlpd_rmse()
-        e, n, r = self.perform_inference()
-        return [e0] + e, [n0] + n, [r0] + r, {}
+        nlpd_vals, rmse_vals = [n0], [r0]
+        previous = []
+        for _ in range(self.max_itr):
+            e, n, r = self.perform_inference()
+            elbo_vals, nlpd_vals, rmse_vals = elbo_vals + e, nlpd_vals + n, rmse_vals + r
+            if not self.learn_prior_sde:
+                break
+            pe, pn, pr = self.optimize_prior_sde()
+            done = abs(elbo_vals[-1] - pe[-1]) < self.optim_tol
+            elbo_vals, nlpd_vals, rmse_vals = elbo_vals + pe, nlpd_vals + pn, rmse_vals + pr
+            if done:
+                logger.info("Model successfully optimized!!!")
+                break
+            if len(previous) > 4 and (abs(previous[-1] - previous[-3]) < 1e-4 or abs(previous[-2] - previous[-4]) < 1e-4):
+                logger.info("The objective is most probably jumping between two values!!!")
+                break
+            previous.append(elbo_vals[-1])
+        return elbo_vals, nlpd_vals, rmse_vals, self.prior_params
 
 
 class VIMarkovGPTrainer:

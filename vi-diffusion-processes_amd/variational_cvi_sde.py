@@ -350,6 +350,76 @@ class CVISitesSDE(CVISitesSSM):
         kl = pl.sde_kl(self._sde_prm, q["mu"], q["Sig"], q["Sub"], mode=1, grads=grads)
         return kl, grads
 
+    # -- prior-parameter learning (variational_cvi_sde.py:495-518) ------------------------------------------------------------
+    def _refresh_sde_params(self):
+        self._sde_prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1])
+
+    def set_prior_initial_state(self, mean, cov):
+        """Replace p(x0) (the trainer re-sets it to the stationary OU covariance after every decay update)."""
+        self.prior_initial_state = (mean, cov)
+        self._refresh_sde_params()
+
+    def grad_KL_wrt_cubic(self):
+        """
+        (d KL / d alpha, d KL / d beta) of the Euler map u(x) = alpha x - beta x^3, summed over trajectories, time and the
+        state dimensions: KL = sum_t 1/2 w E_q[(x' - u(x))^2] + terms free of the drift, with Gaussian moments of
+        (x, x') up to order six from the moment array (mu, diag Sigma, diag Sigma_{t+1,t}).
+        """
+        q = self._refresh()
+        d, T = self.state_dim, self.T
+        mom = self.plan.unpack_moments(q["mom"])
+        m, s, c = mom[:, :-1, :d], mom[:, :-1, d:2 * d], mom[:, :-1, 2 * d:]
+        mn = mom[:, 1:, :d]
+        al, be = self.prior_sde.cubic(self.dt)
+        w = torch.tensor([1.0 / (self.dt * v) for v in self.prior_sde.q_diag], dtype=torch.float64, device=mom.device)
+        m2, s2 = m * m, s * s
+        Ex2 = m2 + s
+        Ex3 = m * (m2 + 3.0 * s)
+        Ex4 = m2 * m2 + 6.0 * m2 * s + 3.0 * s2
+        Ex6 = m2 * m2 * m2 + 15.0 * m2 * m2 * s + 45.0 * m2 * s2 + 15.0 * s2 * s
+        Exxn = m * mn + c                                # E[x x']
+        Ex3xn = mn * Ex3 + 3.0 * c * Ex2                 # E[x^3 x'] (Stein)
+        dal = -(w * (Exxn - al * Ex2 + be * Ex4)).sum()
+        dbe = (w * (Ex3xn - al * Ex4 + be * Ex6)).sum()
+        return float(dal), float(dbe)
+
+    def grad_KL_wrt_prior_params(self):
+        """d KL[q || p_SDE] / d (trainable drift parameters), in `prior_sde.trainable_variables` order (variational_cvi_sde.py:495-506)."""
+        dal, dbe = self.grad_KL_wrt_cubic()
+        jac = self.prior_sde.cubic_jacobian(self.dt)
+        return [dal * jac[n][0] + dbe * jac[n][1] for n in self.prior_sde.trainable_variables]
+
+    def grad_VE_wrt_prior_params(self, rel_step=1e-6):
+        """
+        d(-E_q log p(Y | X)) / d (trainable drift parameters) with q = linearised prior + sites (variational_cvi_sde.py:508-518).
+        The reference differentiates through set_linearized_prior and dist_q with a tape; here each parameter gets a central
+        difference of two re-linearised posterior refreshes on the same path.  Like the reference's, the call leaves the prior
+        re-linearised at the current posterior.
+        """
+        sde = self.prior_sde
+        q = self._refresh()
+        path = (q["mu"].clone(), q["Sig"].clone())
+
+        def neg_ve():
+            self._path, self._q = path, None
+            self._refresh_sde_params()
+            self.set_linearized_prior()
+            self._path, self._q = path, None
+            return -float(self.variational_expectation().sum())
+
+        grads = []
+        for n in sde.trainable_variables:
+            v0 = sde.get(n)
+            h = rel_step * max(abs(v0), 1.0)
+            sde.assign(n, v0 + h)
+            up = neg_ve()
+            sde.assign(n, v0 - h)
+            dn = neg_ve()
+            sde.assign(n, v0)
+            grads.append((up - dn) / (2.0 * h))
+        neg_ve()
+        return grads
+
     def update_girsanov_sites(self, lr: float):
         """Fused: g <- g + lr (scatter(data) - dKL/d eta), theta_q moves by the same increment (variational_cvi_sde.py:279-299)."""
         q = self._refresh()
