@@ -282,7 +282,9 @@ int mfgm_batched_cholesky(int N, int d, const double* A, double* L, int* info, v
     if (N < 0 || d < 1 || d > 32 || !info) return 1;
     if (N == 0) return 0;
     if (!A || !L || A == L) return 1;
-    hipLaunchKernelGGL(k_batched_chol, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, d, A, L, info);
+    if (d > 8 && d <= 16) hipLaunchKernelGGL((k_batched_chol_wave<16>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, d, A, L, info);
+    else if (d > 16) hipLaunchKernelGGL((k_batched_chol_wave<32>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, d, A, L, info);
+    else hipLaunchKernelGGL(k_batched_chol, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, d, A, L, info);
     MFGM_CHECK_LAUNCH();
     return 0;
 }

@@ -15,7 +15,7 @@ int s2n_impl(const Plan& P, const double* A, const double* off, const double* ch
     else hipLaunchKernelGGL((k_ssm_to_naturals<D, false>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, A, off, chol, cD, cS, lin, diag, sub, part);
     MFGM_CHECK_LAUNCH();
     if (sumlogchol) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, sumlogchol, (double*)nullptr);
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, sumlogchol, (double*)nullptr);
         MFGM_CHECK_LAUNCH();
     }
     return 0;
@@ -27,7 +27,7 @@ int kl_impl(const Plan& P, const double* Sig, const double* Sub, const double* m
     double* part = ws + P.off_part[0];
     hipLaunchKernelGGL((k_kl_terms<D>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, Sig, Sub, mu, Pd, Ps, aD, aS, mup, part);
     MFGM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, lv.Lpad, trace, maha);
+    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, lv.Lpad, trace, maha);
     MFGM_CHECK_LAUNCH();
     return 0;
 }

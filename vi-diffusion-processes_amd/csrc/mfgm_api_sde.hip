@@ -20,7 +20,7 @@ int sde_kl_impl(const Plan& P, int mode, const SdeParams& pr, const double* mu, 
     else hipLaunchKernelGGL((k_sde_kl<D, 3>), grid, block, 0, st, lv, pr, mu, Sig, Sub, part, o1, od, os, q1, qd, qs, info);
     MFGM_CHECK_LAUNCH();
     if (kl) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, kl, (double*)nullptr);
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, kl, (double*)nullptr);
         MFGM_CHECK_LAUNCH();
     }
     return 0;
@@ -73,7 +73,7 @@ int sde_lean_impl(const Plan& P, int mode, const SdeParams& pr, const double* mo
         double* part = ws + P.off_part[0];
         hipLaunchKernelGGL((k_sde_lean<D, 0>), grid, block, 0, st, lv, pr, mom, Sig, part, q1, qd, qs);
         MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, out, (double*)nullptr);
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, out, (double*)nullptr);
     } else {
         hipLaunchKernelGGL((k_sde_lean<D, 3>), grid, block, 0, st, lv, pr, mom, Sig, (double*)nullptr, q1, qd, qs);
     }

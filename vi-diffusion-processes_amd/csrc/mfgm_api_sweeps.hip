@@ -123,7 +123,7 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
         if (rc) return rc;
     }
     if (only_stage < 0 && (logdet || quad)) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad,
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad,
                            logdet, quad);
         MFGM_CHECK_LAUNCH();
     }

@@ -20,7 +20,7 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         if (o1) hipLaunchKernelGGL((k_vdp_esde<D, true>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, part, o1, o2);
         else hipLaunchKernelGGL((k_vdp_esde<D, false>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, part, o1, o2);
         MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, lv.P, 0, o0, (double*)nullptr);
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, o0, (double*)nullptr);
     } else if (what == 2) {
         hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
         MFGM_CHECK_LAUNCH();

@@ -118,7 +118,7 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
     }
     if (logdet || quad) {
         // on a sharded plan these are the partial sums over the owned segments
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
         MFGM_CHECK_LAUNCH();
     }
     return 0;
@@ -153,7 +153,7 @@ int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, cons
 #undef S2N
     MFGM_CHECK_LAUNCH();
     if (sumlogchol) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, P.T, 0, sumlogchol, (double*)nullptr);
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, P.T, 0, sumlogchol, (double*)nullptr);
         MFGM_CHECK_LAUNCH();
     }
     return 0;
@@ -164,7 +164,7 @@ int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const dou
     double* part = ws + P.off_part[0];
     hipLaunchKernelGGL(kw_kl_terms, dim3(P.B * P.T), dim3(64), 0, st, P.B, P.T, P.d, Sig, Sub, mu, Pd, Ps, aD, aS, mup, part);
     MFGM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(64), 0, st, part, P.T, P.B * P.T, trace, maha);
+    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, P.T, P.B * P.T, trace, maha);
     MFGM_CHECK_LAUNCH();
     return 0;
 }

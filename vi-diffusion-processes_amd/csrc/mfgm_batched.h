@@ -5,6 +5,7 @@
 // no part of the path depends on a vendor batched-LAPACK; sqrt and division are IEEE here (accuracy over speed).
 #pragma once
 #include "mfgm_math.h"
+#include "mfgm_wide.h"   // row-per-lane primitives (ld_row, chol_rsolve) for the wavefront-per-matrix variant
 
 namespace mfgm {
 
@@ -30,6 +31,32 @@ static __global__ __launch_bounds__(128) void k_batched_chol(int N, int d, const
         }
     }
     if (bad) atomicMax(info, 1);
+}
+
+// Wavefront-per-matrix Cholesky for 8 < d <= 32: lane i holds row i (coalesced row loads / stores), pivots are broadcast with
+// v_readlane; 4 matrices per 256-thread block.
+template <int DM>
+static __global__ __launch_bounds__(256) void k_batched_chol_wave(int N, int d, const double* __restrict__ A, double* __restrict__ L,
+                                                                  int* info) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;                       // whole wavefronts leave together
+    double F[DM];
+    ld_row<DM>(A + (size_t)n * d * d, d, lane, 1.0, F);
+    if (lane >= d && lane < DM) F[lane] = 1.0;
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < DM; ++j) {                  // row Cholesky-Crout, IEEE sqrt / division as in k_batched_chol
+        double acc = F[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) acc = __builtin_fma(-F[k], bcast(F[k], j), acc);
+        double piv = bcast(acc, j);
+        if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+        const double ljj = sqrt(piv);
+        F[j] = (lane > j) ? acc / ljj : ((lane == j) ? ljj : 0.0);
+    }
+    st_row<DM>(L + (size_t)n * d * d, d, lane, F);
+    if (bad && lane == 0) atomicMax(info, 1);
 }
 
 // X = op(L) B for B [N, d, m]:  mode 1: L^{-1} B,  2: L^{-T} B,  3: (L L^T)^{-1} B.  lbatch = 1 shares one L.

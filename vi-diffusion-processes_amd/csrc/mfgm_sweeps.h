@@ -450,11 +450,13 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 
 // ---- per-chain sum of the per-lane partials ---------------------------------------------------------
 // part: [2*Lpad]; out_logdet[b] = sum_p part[b*P+p]; out_quad[b] likewise.  One wave per chain.
-static __global__ __launch_bounds__(64) void k_sum_partials(const double* part, int P, int Lpad, double* out_logdet,
-                                                    double* out_quad) {
+static __global__ __launch_bounds__(256) void k_sum_partials(const double* part, int P, int Lpad, double* out_logdet,
+                                                            double* out_quad) {
+    // one block per chain; fixed summation order (deterministic)
+    __shared__ double sh0[4], sh1[4];
     const int b = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int p = threadIdx.x; p < P; p += 64) {
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
         s0 += part[(size_t)b * P + p];
         s1 += part[(size_t)Lpad + (size_t)b * P + p];
     }
@@ -463,9 +465,14 @@ static __global__ __launch_bounds__(64) void k_sum_partials(const double* part, 
         s0 += __shfl_down(s0, off, 64);
         s1 += __shfl_down(s1, off, 64);
     }
+    if ((threadIdx.x & 63) == 0) { sh0[threadIdx.x >> 6] = s0; sh1[threadIdx.x >> 6] = s1; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        if (out_logdet) out_logdet[b] = s0;
-        if (out_quad) out_quad[b] = s1;
+        const int nw = (blockDim.x + 63) >> 6;
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < nw; ++w) { t0 += sh0[w]; t1 += sh1[w]; }
+        if (out_logdet) out_logdet[b] = t0;
+        if (out_quad) out_quad[b] = t1;
     }
 }
 
