@@ -293,6 +293,18 @@ int mfgm_batched_trsm(int N, int d, int m, int lbatch, const double* L, const do
     if (N < 0 || d < 1 || d > 32 || m < 1 || mode < 1 || mode > 3 || (lbatch != 1 && lbatch != N)) return 1;
     if (N == 0) return 0;
     if (!L || !B || !X) return 1;
+    if (m >= 8) {
+        hipStream_t st = (hipStream_t)stream;
+#define TRSM_COLS(DM_, CP_) hipLaunchKernelGGL((k_batched_trsm_cols<DM_, CP_>), dim3((N + 64 / CP_ - 1) / (64 / CP_)), dim3(64), 0, st, N, d, m, lbatch, L, B, X, mode)
+#define TRSM_DM(DM_) do { if (m <= 16) TRSM_COLS(DM_, 16); else if (m <= 32) TRSM_COLS(DM_, 32); else TRSM_COLS(DM_, 64); } while (0)
+        if (d <= 8) TRSM_DM(8);
+        else if (d <= 16) TRSM_DM(16);
+        else TRSM_DM(32);
+#undef TRSM_DM
+#undef TRSM_COLS
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
     const long long total = (long long)N * m;
     hipLaunchKernelGGL(k_batched_trsm, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, N, d, m, lbatch, L, B,
                        X, mode);

@@ -85,4 +85,57 @@ static __global__ __launch_bounds__(128) void k_batched_trsm(int N, int d, int m
     }
 }
 
+
+// Triangular solves for wide right-hand sides (m >= 8): L staged in LDS, one right-hand-side column per thread held in
+// registers; loads and stores of B / X are coalesced across the columns.  A 64-thread block serves 64 / CP matrices with CP
+// column slots each (CP = 16, 32 or 64, the smallest that covers m, or 64 with a column loop).
+template <int DM, int CP>
+static __global__ __launch_bounds__(64) void k_batched_trsm_cols(int N, int d, int m, int lbatch, const double* __restrict__ L,
+                                                                 const double* __restrict__ B, double* __restrict__ X, int mode) {
+    constexpr int MPB = 64 / CP;                                 // matrices per block
+    __shared__ double sl_all[MPB * DM * (DM + 1)];
+    const int sub = threadIdx.x / CP, c0 = threadIdx.x - sub * CP;
+    const int n = blockIdx.x * MPB + sub;
+    double* sl = sl_all + sub * DM * (DM + 1);
+    if (n < N) {
+        const double* l = L + (lbatch == 1 ? 0 : (size_t)n * d * d);
+        for (int e = c0; e < d * d; e += CP) sl[(e / d) * (DM + 1) + (e % d)] = l[e];
+    }
+    __syncthreads();
+    if (n >= N) return;
+    for (int c = c0; c < m; c += CP) {
+        const double* b = B + (size_t)n * d * m + c;
+        double* x = X + (size_t)n * d * m + c;
+        double v[DM];
+#pragma unroll
+        for (int i = 0; i < DM; ++i) v[i] = (i < d) ? b[(size_t)i * m] : 0.0;
+        if (mode & 1) {
+#pragma unroll
+            for (int i = 0; i < DM; ++i) {
+                if (i < d) {
+                    double t = v[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t = __builtin_fma(-sl[i * (DM + 1) + k], v[k], t);
+                    v[i] = t / sl[i * (DM + 1) + i];
+                }
+            }
+        }
+        if (mode & 2) {
+#pragma unroll
+            for (int i = DM - 1; i >= 0; --i) {
+                if (i < d) {
+                    double t = v[i];
+#pragma unroll
+                    for (int k = i + 1; k < DM; ++k)
+                        if (k < d) t = __builtin_fma(-sl[k * (DM + 1) + i], v[k], t);
+                    v[i] = t / sl[i * (DM + 1) + i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+            if (i < d) x[(size_t)i * m] = v[i];
+    }
+}
+
 }  // namespace mfgm

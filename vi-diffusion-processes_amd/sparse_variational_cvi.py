@@ -43,7 +43,9 @@ class SparseCVIGaussianProcess:
         """Prior naturals + overlap-added site naturals (sparse_variational_cvi.py:140-174)."""
         p = self.dist_p
         pl, sd = p.plan, self._kernel.state_dim
-        nat = pl.ssm_to_naturals(p.packed.A, p.packed.off, p.packed.chol)
+        if getattr(self, "_p_nat", None) is None:      # the prior does not change between site updates
+            self._p_nat = pl.ssm_to_naturals(p.packed.A, p.packed.off, p.packed.chol)
+        nat = self._p_nat
         lin = self.nat1[1:, :sd] + self.nat1[:-1, sd:]
         diag = self.nat2[1:, :sd, :sd] + self.nat2[:-1, sd:, sd:]
         sub = 2.0 * self.nat2[1:-1, sd:, :sd]
