@@ -741,3 +741,63 @@ def test_prior_parameter_gradients_and_learning(amd, rng):
     assert len(params[0]) > 3 and params[0][0] == 0.3
     assert params[0][-1] > 0.6                    # moved towards the data-generating decay
     assert elbos[-1] > elbos[1]
+
+
+def test_vdp_prior_gradient_and_learning(amd, rng):
+    """VariationalMarkovGP.grad_prior_sde_params (vi_sde.py:457-470) against finite differences of the oracle's E_sde (closed
+    form; at d = 1 also the reference's quadrature) on the same (m[1:], S[1:]) path, and the trainer's prior-learning loop
+    (vi_markov_gp_trainer.py:163-201) raising the bound for a mis-specified OU decay."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.trainers import VIMarkovGPTrainer
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    for d in (1, 2):
+        T, dt = 50, 0.01
+        grid = np.arange(T) * dt
+        idx = np.arange(4, T - 1, 6)
+        y = np.sign(rng.normal(size=(1, len(idx), d))) + 0.1 * rng.normal(size=(1, len(idx), d))
+        sde = gsde.DoubleWellSDE(q=torch.eye(d, dtype=torch.float64), scale_trainable=True, c_trainable=True, scale=3.0, c=0.8)
+        v = VariationalMarkovGP((grid[idx], dev(y)), sde, grid, MultivariateGaussian(dev(0.4 * np.eye(d))),
+                                prior_initial_state=(np.zeros(d), 0.5 * np.eye(d)))
+        for _ in range(4):
+            mS = v._forward_packed()
+            v.update_lagrange(mS)
+            v.update_param(mS, lr=0.05)
+        g = v.grad_prior_sde_params()
+        m, S = [host(x)[0][1:] for x in v.forward_pass]
+        A = host(v.plan.unpack(amd.FULL, v.A, T - 1))[0]
+        b = host(v.plan.unpack(amd.VEC, v.b))[0, :T - 1]
+
+        def e_closed(scale, c):
+            return np_sde.e_sde_closed_form(scale * c, scale, np.ones(d), -A, b, m, S, dt, want_grads=False)
+        fns = [e_closed]
+        if d == 1:
+            def e_quad(scale, c):
+                o = np_sde.DoubleWellSDE(np.eye(d), scale, c)
+                return np_sde.squared_drift_difference_along_gaussian_path(o, -A, b, m, S, dt)
+            fns.append(e_quad)
+        for fn in fns:
+            h = 1e-5
+            fd = [(fn(3.0 + h, 0.8) - fn(3.0 - h, 0.8)) / (2 * h), (fn(3.0, 0.8 + h) - fn(3.0, 0.8 - h)) / (2 * h)]
+            np.testing.assert_allclose(g, fd, rtol=2e-5, atol=1e-7)
+    # learning: OU data with decay 2, prior initialised at 0.3 (gentle VDP step sizes: the fixed-point iteration diverges otherwise)
+    T, dt = 120, 0.01
+    grid = np.arange(T) * dt
+    x = np.zeros(T)
+    for k in range(1, T):
+        x[k] = x[k - 1] - dt * 2.0 * x[k - 1] + np.sqrt(dt) * rng.normal()
+    il = np.arange(2, T - 1, 4)
+    yl = (x[il] + 0.3 * rng.normal(size=len(il))).reshape(1, -1, 1)
+    ou = gsde.OrnsteinUhlenbeckSDE(0.3, torch.eye(1, dtype=torch.float64), trainable=True)
+    vm = VariationalMarkovGP((grid[il], dev(yl)), ou, grid, MultivariateGaussian(dev(0.3 * np.eye(1))),
+                             prior_initial_state=(np.zeros(1), np.eye(1) / 0.6))
+    tr = VIMarkovGPTrainer(vm, q_lr=0.05, x0_lr=0.05, max_itr=15, warmup_itr=2, learn_prior_sde=True, prior_sde_lr=0.05,
+                           learning_max_itr=8, learning_tol=1e-5, optimize_prior_initial_state=True)
+    e_inf, _, _ = tr.perform_inference()
+    assert np.isfinite(e_inf[-1]) and e_inf[-1] > e_inf[0]
+    e_learn, _, _ = tr.optimize_prior_sde()
+    assert np.all(np.isfinite(e_learn))
+    assert tr.prior_params[0][0] == 0.3 and tr.prior_params[0][-1] > 0.3 + 0.2      # Adam moved the decay up, towards 2
+    assert e_learn[-1] > e_inf[-1]                                                   # and the bound with it

@@ -58,6 +58,10 @@ class SDE:
         """{parameter: (d alpha / d parameter, d beta / d parameter)}."""
         raise NotImplementedError
 
+    def drift_cubic_jacobian(self):
+        """{parameter: (d af / d parameter, d bf / d parameter)} of f(x) = af x - bf x^3."""
+        raise NotImplementedError
+
     def params(self, dt, init_mu, init_cov, lr=0.0, clip=None):
         """Fill the C parameter block (mfgm_sde_params)."""
         d = self.state_dim
@@ -97,6 +101,9 @@ class OrnsteinUhlenbeckSDE(SDE):
     def cubic_jacobian(self, dt):
         return {"decay": (-dt, 0.0)}
 
+    def drift_cubic_jacobian(self):
+        return {"decay": (-1.0, 0.0)}
+
     def drift(self, x, t=None):
         return -self.decay * x
 
@@ -123,6 +130,9 @@ class DoubleWellSDE(SDE):
 
     def cubic_jacobian(self, dt):
         return {"scale": (dt * self.c, dt), "c": (dt * self.scale, 0.0)}
+
+    def drift_cubic_jacobian(self):
+        return {"scale": (self.c, 1.0), "c": (self.scale, 0.0)}
 
     def drift(self, x, t=None):
         return self.scale * x * (self.c - x * x)

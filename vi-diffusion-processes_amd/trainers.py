@@ -2,8 +2,8 @@
 Host-side mirror of the experiment trainers that drive the hot path: `CVISitesTrainer`
 (docs/diffusion_processes/cvi_dp_trainer.py:19-200) and `VIMarkovGPTrainer`
 (docs/diffusion_processes/vi_markov_gp_trainer.py:17-135): the inference loops with their learning-rate decay and
-convergence rules, NLPD / RMSE on held-out grid points (exp_dp_utils.py:189-224), and for CVI-DP the prior-parameter
-learning loop (cvi_dp_trainer.py:138-250: Adam on the drift parameters with the KL + VE gradients).  The wandb / hydra
+convergence rules, NLPD / RMSE on held-out grid points (exp_dp_utils.py:189-224), and the prior-parameter learning loops
+(cvi_dp_trainer.py:138-250, vi_markov_gp_trainer.py:163-215: Adam on the drift parameters).  The wandb / hydra
 plumbing is out of scope.  One host synchronisation per iteration remains (the ELBO scalar decides
 the learning-rate decay), everything else stays on the device.
 """
@@ -195,14 +195,30 @@ class CVISitesTrainer:
 
 
 class VIMarkovGPTrainer:
-    """vi_markov_gp_trainer.py:17-135 (inference part)."""
+    """vi_markov_gp_trainer.py:17-215."""
 
     def __init__(self, model, test_data=None, q_lr=0.1, x0_lr=0.1, max_itr=1000, lr_tol=1e-2, optim_tol=1e-4, warmup_x0_itr=10,
-                 warmup_itr=20):
+                 warmup_itr=20, learn_prior_sde=False, prior_sde_lr=1e-2, learning_max_itr=100, learning_tol=1e-2,
+                 optimize_prior_initial_state=False):
         self.model = model
         self.q_lr, self.x0_lr, self.max_itr = q_lr, x0_lr, max_itr
         self.lr_tol, self.optim_tol, self.warmup_x0_itr, self.warmup_itr = lr_tol, optim_tol, warmup_x0_itr, warmup_itr
         self._metrics = _Metrics(model, test_data, model.grid)
+        self.learn_prior_sde, self.prior_sde_lr = bool(learn_prior_sde), float(prior_sde_lr)
+        self.learning_max_itr, self.learning_tol = int(learning_max_itr), float(learning_tol)
+        self.optimize_prior_initial_state = bool(optimize_prior_initial_state)
+        self.prior_params = {}
+        if self.learn_prior_sde:
+            names = model.prior_sde.trainable_variables
+            if not names:
+                raise ValueError("learn_prior_sde needs a prior SDE with trainable parameters")
+            self.prior_sde_optim = _Adam(self.prior_sde_lr, len(names))
+            self.store_prior_param_vals()
+
+    def store_prior_param_vals(self):
+        sde = self.model.prior_sde
+        for i, n in enumerate(sde.trainable_variables):
+            self.prior_params.setdefault(i, []).append(sde.get(n))
 
     def perform_inference(self):
         """vi_markov_gp_trainer.py:50-92."""
@@ -227,15 +243,57 @@ class VIMarkovGPTrainer:
                 break
         return elbos[1:], nlpds, rmses
 
+    def optimize_prior_x0(self):
+        """vi_markov_gp_trainer.py:203-215: for an OU prior the initial state follows the stationary covariance q / (2 decay)."""
+        from .sde import OrnsteinUhlenbeckSDE
+        mdl, sde = self.model, self.model.prior_sde
+        if not isinstance(sde, OrnsteinUhlenbeckSDE):
+            raise NotImplementedError("gradient steps on p(x0) (grad_initial_state, vi_sde.py:472-482) are built for the OU prior only")
+        cov = torch.diag(torch.tensor(sde.q_diag, dtype=torch.float64)) / (2.0 * sde.decay)
+        mdl.set_prior_initial_state(mdl.p0_mu, cov.numpy())
+
+    def optimize_prior_sde(self):
+        """vi_markov_gp_trainer.py:163-201: Adam on the drift parameters with dE_sde/d params at the current (m, S)."""
+        mdl, sde = self.model, self.model.prior_sde
+        elbo_vals, nlpd_vals, rmse_vals = [float(mdl.elbo())], [], []
+        for _ in range(self.learning_max_itr):
+            grads = mdl.grad_prior_sde_params()
+            names = sde.trainable_variables
+            for n, v in zip(names, self.prior_sde_optim.step([sde.get(n) for n in names], grads)):
+                sde.assign(n, v)
+            mdl._refresh_drift_params()
+            if self.optimize_prior_initial_state:
+                self.optimize_prior_x0()
+            mS = mdl._forward_packed()
+            elbo_vals.append(float(mdl.elbo(mS)))
+            nl, rm = self._metrics(*mS)
+            nlpd_vals.append(nl)
+            rmse_vals.append(rm)
+            self.store_prior_param_vals()
+            if abs(elbo_vals[-2] - elbo_vals[-1]) < self.learning_tol:
+                logger.info("Prior parameter optimized successfully!!!")
+                break
+        return elbo_vals[1:], nlpd_vals, rmse_vals
+
     def optimize(self):
-        """vi_markov_gp_trainer.py:94-135 without prior learning: 20 warm-up iterations at lr = 1e-6, then inference."""
+        """vi_markov_gp_trainer.py:94-135: warm-up iterations at lr = 1e-6, then inference alternating with prior learning."""
         mdl = self.model
         for _ in range(self.warmup_itr):
             mS = mdl._forward_packed()
             mdl.update_lagrange(mS)
             mdl.update_param(mS, lr=1e-6)
         mS = mdl._forward_packed()
-        e0 = float(mdl.elbo(mS))
+        elbo_vals = [float(mdl.elbo(mS))]
         n0, r0 = self._metrics(*mS)
-        e, n, r = self.perform_inference()
-        return [e0] + e, [n0] + n, [r0] + r, {}
+        nlpd_vals, rmse_vals = [n0], [r0]
+        for _ in range(self.max_itr):
+            e, n, r = self.perform_inference()
+            elbo_vals, nlpd_vals, rmse_vals = elbo_vals + e, nlpd_vals + n, rmse_vals + r
+            if not self.learn_prior_sde:
+                break
+            pe, pn, pr = self.optimize_prior_sde()
+            elbo_vals, nlpd_vals, rmse_vals = elbo_vals + pe, nlpd_vals + pn, rmse_vals + pr
+            if len(pe) > 2 and abs(pe[-2] - pe[-1]) < self.optim_tol:
+                logger.info("Model successfully optimized!!!")
+                break
+        return elbo_vals, nlpd_vals, rmse_vals, self.prior_params

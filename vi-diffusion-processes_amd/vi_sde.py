@@ -127,6 +127,44 @@ class VariationalMarkovGP:
                                                  _ptr(out), _ptr(gm), _ptr(gS), _ptr(pl.ws), _stream()), "mfgm_packed_vdp_esde")
         return pl.unpack(VEC, gm, self.num_transitions), pl.unpack(SYM, gS, self.num_transitions)
 
+    # -- prior-parameter learning (vi_sde.py:457-470) ------------------------------------------------------------------------
+    def _refresh_drift_params(self):
+        af, bf = self.prior_sde.drift_cubic()
+        for i in range(self.state_dim):
+            self._prm.af[i], self._prm.bf[i] = af, bf
+
+    def set_prior_initial_state(self, mean, cov):
+        self.p0_mu = np.asarray(mean, dtype=np.float64).reshape(self.state_dim)
+        self.p0_cov = np.asarray(cov, dtype=np.float64).reshape(self.state_dim, self.state_dim)
+
+    def grad_prior_sde_params(self):
+        """
+        d E_sde / d (trainable drift parameters) at fixed (m, S), in `prior_sde.trainable_variables` order.  As in the reference,
+        the path handed to E_sde here is states 1..N (`m[1:]`, vi_sde.py:462-466) against the N transitions' (A, b).
+        With r = f_p - f_q = af x - bf x^3 + A x - b per dimension:  dE/daf = dt sum w E[r x],  dE/dbf = -dt sum w E[r x^3],
+        Gaussian moments to order six (E[x_j x_i^3] = m_j E[x_i^3] + 3 S_ji E[x_i^2]).
+        """
+        pl, N, d = self.plan, self.num_transitions, self.state_dim
+        mp, Sp = self._forward_packed()
+        m, S = pl.unpack(VEC, mp)[:, 1:], pl.unpack(SYM, Sp)[:, 1:]
+        A, b = pl.unpack(FULL, self.A, N), pl.unpack(VEC, self.b)[:, :N]
+        af, bf = self.prior_sde.drift_cubic()
+        w = torch.tensor([1.0 / v for v in self.prior_sde.q_diag], dtype=torch.float64, device=self.device)
+        s = torch.diagonal(S, dim1=-2, dim2=-1)
+        m2, s2 = m * m, s * s
+        Ex2 = m2 + s
+        Ex3 = m * (m2 + 3.0 * s)
+        Ex4 = m2 * m2 + 6.0 * m2 * s + 3.0 * s2
+        Ex6 = m2 * m2 * m2 + 15.0 * m2 * m2 * s + 45.0 * m2 * s2 + 15.0 * s2 * s
+        Am = (A @ m[..., None])[..., 0]
+        ASii = (A * S.transpose(-1, -2)).sum(-1)                       # sum_j A_ij S_ji
+        Erx = af * Ex2 - bf * Ex4 + ASii + Am * m - b * m
+        Erx3 = af * Ex4 - bf * Ex6 + Am * Ex3 + 3.0 * ASii * Ex2 - b * Ex3
+        daf = float(self.dt * (w * Erx).sum())
+        dbf = float(-self.dt * (w * Erx3).sum())
+        jac = self.prior_sde.drift_cubic_jacobian()
+        return [daf * jac[n][0] + dbf * jac[n][1] for n in self.prior_sde.trainable_variables]
+
     # -- updates -----------------------------------------------------------------------------------------------
     def update_lagrange(self, mS=None):
         """Backward sweep with jump conditions for (psi, lambda) (vi_sde.py:289-347)."""
