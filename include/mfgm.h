@@ -122,6 +122,12 @@ typedef struct mfgm_sde_params {
     double clip_lo, clip_hi; /* clipping of the linearised A, b; lo >= hi disables (variational_cvi_sde.py:417-430) */
     double sq_dtq[8];     /* sqrt(dt q_ii) */
     double cholP0[36];    /* Cholesky of the prior initial covariance */
+    double theta[8];      /* parameter of the non-polynomial drifts (kind >= 1) */
+    double dt;            /* Euler step, u(x) = x + dt f(x) (kind >= 1) */
+    int kind;             /* 0: cubic (closed-form moments); 1: f = theta tanh x (BenesSDE, sde.py:227-268); 2: f = sin(x - theta)
+                           * (SineDiffusionSDE, :271-312); 3: f = sqrt(theta |x|) (SqrtDiffusionSDE, :315-356).  Kinds >= 1 use the
+                           * reference's Gauss-Hermite rules (10 points for the linearisation, 20 for the KL) per dimension; d <= 4 */
+    int pad_;
 } mfgm_sde_params;
 
 /* KL[q || p_SDE] of the Gaussian chain q (marginal blocks mu, Sig, Sub packed) from the Euler-discretised SDE prior,

@@ -148,6 +148,12 @@ class CVISitesSDE(CVISitesSSM):
     def grad_kl_wrt_exp_param(self):
         q = self.dist_q
         mu, cov = q.marginals
+        if not hasattr(self.sde, "cubic"):
+            # non-polynomial drifts: central differences of the reference's quadrature KL stand in for its GradientTape
+            sub = q.subsequent_covariances(cov)
+            eta_d = cov + mu[..., :, None] * mu[..., None, :]
+            eta_s = sub + mu[1:, :, None] * mu[:-1, None, :]
+            return self._np_sde.sde_ssm_kl_grads_fd(mu, eta_d, eta_s, self.sde, self.dt, self.init_mu, self.init_cov)
         alpha, beta = self.sde.cubic(self.dt)
         _, grads = self._np_sde.sde_ssm_kl_closed_form(mu, cov, q.subsequent_covariances(cov), alpha, beta, np.diag(self.sde.q),
                                                        self.dt, self.init_mu, self.init_cov)

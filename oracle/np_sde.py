@@ -107,6 +107,48 @@ class DoubleWellSDE(SDE):
         return 1.0 + dt * self.scale * self.c, dt * self.scale
 
 
+class BenesSDE(SDE):
+    """sde.py:227-268: f(x) = theta tanh(x)."""
+
+    def __init__(self, theta=1.0, q=np.ones((1, 1))):
+        super().__init__(q)
+        self.theta = float(theta)
+
+    def drift(self, x, t=None):
+        return self.theta * np.tanh(x)
+
+    def gradient_drift(self, x, t=None):
+        return self.theta * (1.0 - np.tanh(x) ** 2)
+
+
+class SineDiffusionSDE(SDE):
+    """sde.py:271-312: f(x) = sin(x - theta)."""
+
+    def __init__(self, theta=0.0, q=np.ones((1, 1))):
+        super().__init__(q)
+        self.theta = float(theta)
+
+    def drift(self, x, t=None):
+        return np.sin(x - self.theta)
+
+    def gradient_drift(self, x, t=None):
+        return np.cos(x - self.theta)
+
+
+class SqrtDiffusionSDE(SDE):
+    """sde.py:315-356: f(x) = sqrt(theta |x|)."""
+
+    def __init__(self, theta=1.0, q=np.ones((1, 1))):
+        super().__init__(q)
+        self.theta = float(theta)
+
+    def drift(self, x, t=None):
+        return np.sqrt(self.theta * np.abs(x))
+
+    def gradient_drift(self, x, t=None):
+        return 0.5 * np.sign(x) * np.sqrt(self.theta / np.abs(x))
+
+
 def linear_drift_to_ssm(A, b, q, transition_times, initial_mean, initial_chol_covariance):
     """LinearDrift.to_ssm (drift.py:66-117): A_k = A dt + I, b_k = b dt, Q_k = q dt.  A [N,D,D], b [N,D], q [N,D,D]."""
     dts = (transition_times[1:] - transition_times[:-1])

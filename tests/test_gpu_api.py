@@ -801,3 +801,93 @@ def test_vdp_prior_gradient_and_learning(amd, rng):
     assert np.all(np.isfinite(e_learn))
     assert tr.prior_params[0][0] == 0.3 and tr.prior_params[0][-1] > 0.3 + 0.2      # Adam moved the decay up, towards 2
     assert e_learn[-1] > e_inf[-1]                                                   # and the bound with it
+
+
+def _theta_sdes(kind, d, qd):
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    q_np, q_t = np.diag(qd), torch.from_numpy(np.diag(qd))
+    if kind == "benes":
+        return np_sde.BenesSDE(1.3, q_np), gsde.BenesSDE(1.3, q_t)
+    if kind == "sine":
+        return np_sde.SineDiffusionSDE(0.4, q_np), gsde.SineDiffusionSDE(0.4, q_t)
+    return np_sde.SqrtDiffusionSDE(1.5, q_np), gsde.SqrtDiffusionSDE(1.5, q_t)
+
+
+@pytest.mark.parametrize("d,kind", [(1, "benes"), (1, "sine"), (2, "benes"), (2, "sine"), (1, "sqrt")])
+def test_sde_kl_kernel_quadrature_drifts(amd, rng, d, kind):
+    """Non-polynomial drifts (BenesSDE, SineDiffusionSDE, SqrtDiffusionSDE; sde.py:227-356): KL[q || p_SDE] (full-block and
+    moment-array kernels), its gradient with respect to the expectation parameters and the linearisation, with the
+    reference's Gauss-Hermite rules inside the kernels, against the oracle's restatement of the reference quadrature
+    (sde_utils.py:262-359, 119-179; central differences stand in for the GradientTape)."""
+    from oracle import np_sde
+    B, T, dt = 2, 6, 0.05
+    qd = 0.5 + rng.random(d)
+    osde, gs = _theta_sdes(kind, d, qd)
+    prm = random_ssm_params(rng, (B,), T, d, scale_A=0.8)
+    # marginal standard deviations around 0.4: there the 20-point rule integrates tanh to ~1e-12, so the per-dimension
+    # (Stein) form used by the kernels and the reference's quadrature of the squared residual are the same number
+    prm = (prm[0], 0.4 * prm[1], prm[2], prm[3], 0.4 * prm[4])
+    if kind == "sqrt":      # keep the path away from the kink at 0 (f' is singular there, in the reference too)
+        prm = (prm[0] + 4.0, 0.5 * prm[1], 0.02 * prm[2] + 0.99 * np.eye(d), 0.02 * prm[3] + 0.05, 0.5 * prm[4])
+    init_mu, init_cov = 0.1 * rng.normal(size=d), 0.7 * np.eye(d) + 0.1 * np.ones((d, d))
+    plan = amd.Plan(B, T, d, R0=3, Rup=2)
+    mus, covs, subs = [], [], []
+    for b in range(B):
+        q = np_ssm.StateSpaceModel(*[p[b] for p in prm])
+        mu, cov = q.marginals
+        mus.append(mu); covs.append(cov); subs.append(q.subsequent_covariances(cov))
+    mu, cov, sub = np.stack(mus), np.stack(covs), np.stack(subs)
+    pm, pc, ps = plan.pack(amd.VEC, dev(mu)), plan.pack(amd.SYM, dev(cov)), plan.pack(amd.FULL, dev(sub))
+    cprm = gs.params(dt, init_mu, init_cov)
+    grads = (plan.empty(amd.VEC), plan.empty(amd.SYM), plan.empty(amd.FULL))
+    kl0 = host(plan.sde_kl(cprm, pm, pc, ps, mode=0))
+    kl1 = host(plan.sde_kl(cprm, pm, pc, ps, mode=1, grads=grads))
+    plan.check_info()
+    g1, gd, gsub = host(plan.unpack(amd.VEC, grads[0])), host(plan.unpack(amd.SYM, grads[1])), host(plan.unpack(amd.FULL, grads[2], T - 1))
+    A, off, chol = plan.linearize_cubic(gs.params(dt, init_mu, init_cov, clip=None), pm, pc)
+    Ag, offg = host(plan.unpack(amd.FULL, A, T - 1)), host(plan.unpack(amd.VEC, off))
+    for b in range(B):
+        eta_d = cov[b] + mu[b][:, :, None] * mu[b][:, None, :]
+        eta_s = sub[b] + mu[b][1:, :, None] * mu[b][:-1, None, :]
+        kl = np_sde.sde_ssm_kl_from_expectations(mu[b], eta_d, eta_s, osde, dt, init_mu, init_cov)
+        np.testing.assert_allclose(kl0[b], kl, rtol=1e-8)
+        np.testing.assert_allclose(kl1[b], kl, rtol=1e-8)
+        o1, od, os_ = np_sde.sde_ssm_kl_grads_fd(mu[b], eta_d, eta_s, osde, dt, init_mu, init_cov)
+        assert_close(g1[b], o1, rtol=2e-5, scale_atol=1e-7)
+        assert_close(gd[b], od, rtol=2e-5, scale_atol=1e-7)
+        assert_close(gsub[b], os_, rtol=2e-5, scale_atol=1e-7)
+        # the model linearises transition k around the posterior marginal of state k + 1 (variational_cvi_sde.py:408-432)
+        lin = np_sde.linearize_sde(osde, np.arange(T) * dt, mu[b][1:], cov[b][1:], init_mu, init_cov)
+        # d > 1: the reference's tensor-product 10-point rule and the per-dimension rule differ by the rule's own error
+        assert_close(Ag[b], lin.A, rtol=1e-9 if d == 1 else 2e-6)
+        assert_close(offg[b][1:], lin.b, rtol=1e-9 if d == 1 else 2e-6, scale_atol=1e-8 if d == 1 else 1e-6)
+
+
+@pytest.mark.parametrize("kind", ["benes", "sine"])
+def test_cvi_sites_sde_quadrature_drifts(amd, rng, kind):
+    """CVI-DP with a non-polynomial prior drift (the lean moment-array path with Gauss-Hermite expectations) against the
+    oracle model whose Girsanov gradient is the finite-differenced reference quadrature."""
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    d, B, T, dt = 1, 1, 12, 0.05
+    osde, gs = _theta_sdes(kind, d, np.ones(d))
+    grid = np.arange(T) * dt
+    idx = np.array([3, 7, 10])
+    y = np.sign(rng.normal(size=(B, 3, d))) + 0.2 * rng.normal(size=(B, 3, d))
+    cholR = 0.3 * np.eye(d)
+    init = (np.zeros(d), 0.5 * np.eye(d))
+    g = CVISitesSDE(gs, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)), prior_initial_state=init)
+    o = np_models.CVISitesSDE(osde, grid, idx, y[0], np_models.MultivariateGaussianLik(cholR), *init)
+    assert_close(host(g.dist_p.state_transitions)[0], o.dist_p.A)
+    for lr_d, lr_g in ((0.5, 0.2), (0.3, 0.1)):
+        g.update_data_sites(lr_d)
+        g.update_girsanov_sites(lr_g)
+        o.update_data_sites(lr_d)
+        o.update_girsanov_sites(lr_g)
+        np.testing.assert_allclose(host(g.classic_elbo_per_trajectory())[0], o.classic_elbo(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(host(g.KL_q_p()), host(g.KL_q_p_full()), rtol=1e-9)
+    g.relinearize()
+    o.relinearize()
+    np.testing.assert_allclose(host(g.classic_elbo_per_trajectory())[0], o.classic_elbo(), rtol=2e-6, atol=2e-6)

@@ -65,7 +65,8 @@ class SdeParams(ctypes.Structure):
     _fields_ = [("alpha", ctypes.c_double * 8), ("beta", ctypes.c_double * 8), ("W", ctypes.c_double * 8),
                 ("P0inv", ctypes.c_double * 36), ("mu0", ctypes.c_double * 8), ("logdetQp", ctypes.c_double),
                 ("logdetP0", ctypes.c_double), ("lr", ctypes.c_double), ("clip_lo", ctypes.c_double),
-                ("clip_hi", ctypes.c_double), ("sq_dtq", ctypes.c_double * 8), ("cholP0", ctypes.c_double * 36)]
+                ("clip_hi", ctypes.c_double), ("sq_dtq", ctypes.c_double * 8), ("cholP0", ctypes.c_double * 36),
+                ("theta", ctypes.c_double * 8), ("dt", ctypes.c_double), ("kind", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
 class KernelSpec(ctypes.Structure):

@@ -38,6 +38,16 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
         default: return 1;                   \
     }
 
+// the quadrature (non-polynomial drift) kernels are instantiated for d <= 4 only
+#define MFGM_DISPATCH_D4(d, CALL)            \
+    switch (d) {                             \
+        case 1: { constexpr int DD = 1; return CALL; } \
+        case 2: { constexpr int DD = 2; return CALL; } \
+        case 3: { constexpr int DD = 3; return CALL; } \
+        case 4: { constexpr int DD = 4; return CALL; } \
+        default: return 1;                   \
+    }
+
 // mfgm_api_wide.hip
 int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st,

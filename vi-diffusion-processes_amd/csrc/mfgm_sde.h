@@ -25,38 +25,99 @@ struct SdeParams {
     double clip_lo, clip_hi;    // clipping of the linearised A, b (linearise kernel); lo >= hi disables
     double sq_dtq[8];           // sqrt(dt q_ii): Cholesky of the prior process noise
     double cholP0[36];          // Cholesky of the prior initial covariance, packed lower triangle
+    double theta[8];            // parameter of the non-polynomial per-dimension drifts (kind >= 1)
+    double dt;                  // Euler step: u(x) = x + dt f(x)                        (kind >= 1)
+    int kind;                   // 0: cubic alpha x - beta x^3 (closed form); 1: theta tanh x; 2: sin(x - theta); 3: sqrt(theta |x|)
+    int pad_;
 };
 
-template <int D>
+// Drifts that are not polynomials (markovflow/sde/sde.py:227-330: BenesSDE, SineDiffusionSDE, SqrtDiffusionSDE): f, f', f''.
+MFGM_DEV void drift_eval(int kind, double th, double x, double& f, double& f1, double& f2) {
+    if (kind == 1) {
+        const double t = tanh(x), c = 1.0 - t * t;
+        f = th * t; f1 = th * c; f2 = -2.0 * th * t * c;
+    } else if (kind == 2) {
+        f = sin(x - th); f1 = cos(x - th); f2 = -f;
+    } else {
+        const double a = fabs(x), r = sqrt(th * a);
+        f = r; f1 = (x < 0.0 ? -0.5 : 0.5) * r / a; f2 = -0.25 * r / (a * a);
+    }
+}
+
+// E u, E u', Var u under N(m, v) and their partials with respect to (m, v), for one state dimension.
+//   KIND 0: the cubic's polynomial moments in closed form.
+//   KIND 1: H-point Gauss-Hermite quadrature x_k = m + sqrt(2 v) xi_k, differentiated as a formula (what the reference's
+//           GradientTape does to gpflow's mvnquad: d x_k / d m = 1, d x_k / d v = xi_k / sqrt(2 v)); the reference uses
+//           H = 10 for the linearisation (sde.py:92-131) and H = 20 for the KL (sde_utils.py:262-359).
+template <int KIND, int H>
+MFGM_DEV void drift_mom(const SdeParams& pr, int i, double mi, double v, double& ubar, double& J, double& V, double& ub_v,
+                        double& J_m, double& J_v, double& V_m, double& V_v) {
+    if (KIND == 0) {
+        const double al = pr.alpha[i], be = pr.beta[i];
+        const double m2 = mi * mi, a = m2 + v;
+        ubar = al * mi - be * mi * (m2 + 3.0 * v);
+        J = al - 3.0 * be * a;
+        V = al * al * v - 6.0 * al * be * v * a + be * be * v * (9.0 * m2 * m2 + 36.0 * m2 * v + 15.0 * v * v);
+        ub_v = -3.0 * be * mi;
+        J_m = -6.0 * be * mi;
+        J_v = -3.0 * be;
+        V_m = -12.0 * al * be * mi * v + be * be * mi * v * (36.0 * m2 + 72.0 * v);
+        V_v = al * al - 6.0 * al * be * (m2 + 2.0 * v) + be * be * (9.0 * m2 * m2 + 72.0 * m2 * v + 45.0 * v * v);
+    } else {
+        static_assert(H == 10 || H == 20, "Gauss-Hermite tables exist for 10 and 20 points");
+        // positive nodes / weights (w / sqrt(pi)) of numpy.polynomial.hermite.hermgauss(H); the rule is symmetric
+        constexpr double x10[5] = {0.3429013272237046, 1.0366108297895136, 1.7566836492998816, 2.5327316742327897, 3.4361591188377374};
+        constexpr double w10[5] = {0.34464233493201907, 0.13548370298026777, 0.01911158050077031, 0.0007580709343122176,
+                                   4.310652630718299e-06};
+        constexpr double x20[10] = {0.24534070830090124, 0.7374737285453944, 1.234076215395323, 1.7385377121165861, 2.2549740020892757,
+                                    2.7888060584281305, 3.3478545673832163, 3.944764040115625, 4.603682449550744, 5.387480890011233};
+        constexpr double w20[10] = {0.2607930634495549, 0.16173933398399998, 0.0615063720639769, 0.013997837447101022,
+                                    0.00183010313108049, 0.00012882627996192928, 4.402121090230851e-06, 6.127490259982928e-08,
+                                    2.4820623623151755e-10, 1.2578006724379234e-13};
+        const double s2 = sqrt(2.0 * v), inv = 1.0 / s2, th = pr.theta[i], dt = pr.dt;
+        double Eu = 0.0, Eu1 = 0.0, Eu2 = 0.0, Eu1x = 0.0, Eu2x = 0.0, Euu = 0.0, Euu1 = 0.0, Euu1x = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < H; ++k) {
+            const int kk = (k < H / 2) ? (H / 2 - 1 - k) : (k - H / 2);
+            const double xa = (H == 10) ? x10[kk % 5] : x20[kk % 10], w = (H == 10) ? w10[kk % 5] : w20[kk % 10];
+            const double xi = (k < H / 2) ? -xa : xa;
+            const double x = mi + s2 * xi;
+            double f, f1, f2;
+            drift_eval(pr.kind, th, x, f, f1, f2);
+            const double u = x + dt * f, u1 = 1.0 + dt * f1, u2 = dt * f2;
+            Eu += w * u; Eu1 += w * u1; Eu2 += w * u2;
+            Eu1x += w * u1 * xi; Eu2x += w * u2 * xi;
+            Euu += w * u * u; Euu1 += w * u * u1; Euu1x += w * u * u1 * xi;
+        }
+        ubar = Eu; J = Eu1;
+        ub_v = Eu1x * inv;
+        J_m = Eu2; J_v = Eu2x * inv;
+        V = Euu - Eu * Eu;
+        V_m = 2.0 * Euu1 - 2.0 * Eu * Eu1;
+        V_v = 2.0 * Euu1x * inv - 2.0 * Eu * ub_v;
+    }
+}
+
+template <int D, int KIND, int H>
 MFGM_DEV void cubic_moments(const SdeParams& pr, const double (&m)[D], const double (&S)[MFGM_NTRI(D)], double (&ubar)[D],
                             double (&J)[D], double (&V)[D], double (&ub_v)[D], double (&J_m)[D], double (&J_v)[D],
                             double (&V_m)[D], double (&V_v)[D]) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const double al = pr.alpha[i], be = pr.beta[i], mi = m[i], v = S[tix(i, i)];
-        const double m2 = mi * mi, a = m2 + v;
-        ubar[i] = al * mi - be * mi * (m2 + 3.0 * v);
-        J[i] = al - 3.0 * be * a;
-        V[i] = al * al * v - 6.0 * al * be * v * a + be * be * v * (9.0 * m2 * m2 + 36.0 * m2 * v + 15.0 * v * v);
-        ub_v[i] = -3.0 * be * mi;
-        J_m[i] = -6.0 * be * mi;
-        J_v[i] = -3.0 * be;
-        V_m[i] = -12.0 * al * be * mi * v + be * be * mi * v * (36.0 * m2 + 72.0 * v);
-        V_v[i] = al * al - 6.0 * al * be * (m2 + 2.0 * v) + be * be * (9.0 * m2 * m2 + 72.0 * m2 * v + 45.0 * v * v);
-    }
+    for (int i = 0; i < D; ++i)
+        drift_mom<KIND, H>(pr, i, m[i], S[tix(i, i)], ubar[i], J[i], V[i], ub_v[i], J_m[i], J_v[i], V_m[i], V_v[i]);
 }
 
 // One transition: returns its KL value; when GRAD, also the gradient pieces
 //   own node:   Gm[D], GS (sym, only the part added by this transition), GC (full)
 //   next node:  om[D] = -W e - GC m   (already includes the -GC_t m_t term of d/d eta1_{t+1}),  oS = 1/2 (W - P)
-template <int D, bool GRAD>
+template <int D, bool GRAD, int KIND>
 MFGM_DEV double sde_transition(const SdeParams& pr, const double (&m)[D], const double (&S)[MFGM_NTRI(D)],
                                const double (&C)[D * D], const double (&mn)[D], const double (&Sn)[MFGM_NTRI(D)],
                                double (&Gm)[D], double (&GS)[MFGM_NTRI(D)], double (&GC)[D * D], double (&om)[D],
                                double (&oS)[MFGM_NTRI(D)], int& bad) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     double ubar[D], J[D], V[D], ub_v[D], J_m[D], J_v[D], V_m[D], V_v[D];
-    cubic_moments<D>(pr, m, S, ubar, J, V, ub_v, J_m, J_v, V_m, V_v);
+    cubic_moments<D, KIND, 20>(pr, m, S, ubar, J, V, ub_v, J_m, J_v, V_m, V_v);
     // A = C S^{-1}
     double Ls[ET], invs[D], A[EF];
 #pragma unroll
@@ -119,7 +180,7 @@ MFGM_DEV double sde_transition(const SdeParams& pr, const double (&m)[D], const 
 
 // MODE 0: KL value only (per-lane partials).  MODE 1: also write d KL / d eta to (o1, od, os).
 // MODE 2: fused Girsanov update  g <- g - lr dKL/deta,  theta_q <- theta_q - lr dKL/deta  (o* = g arrays, q* = theta_q)
-template <int D, int MODE>
+template <int D, int MODE, int KIND>
 __global__ __launch_bounds__(64) void k_sde_kl(LevelDesc lv, SdeParams pr, const double* __restrict__ mug,
                                               const double* __restrict__ Sigg, const double* __restrict__ Subg,
                                               double* __restrict__ part, double* o1, double* od, double* os, double* q1,
@@ -172,7 +233,7 @@ __global__ __launch_bounds__(64) void k_sde_kl(LevelDesc lv, SdeParams pr, const
         ld_node<D>(mug, R, R - 1, left, mp);
         ld_node<ET>(Sigg, R, R - 1, left, Sp);
         ld_node<EF>(Subg, R, R - 1, left, Cp);
-        sde_transition<D, true>(pr, mp, Sp, Cp, m, S, Gm, GS, GC, cm, cS, bad);
+        sde_transition<D, true, KIND>(pr, mp, Sp, Cp, m, S, Gm, GS, GC, cm, cS, bad);
     }
     for (int s = 0; s < R; ++s) {
         if (s < len) {
@@ -184,7 +245,7 @@ __global__ __launch_bounds__(64) void k_sde_kl(LevelDesc lv, SdeParams pr, const
                 ld_node<EF>(Subg, R, s, me, C);
                 ld_next<D>(mug, R, s, len, lane, me, mn);
                 ld_next<ET>(Sigg, R, s, len, lane, me, Sn);
-                kl += sde_transition<D, GRAD>(pr, m, S, C, mn, Sn, Gm, GS, gs, om, oS, bad);
+                kl += sde_transition<D, GRAD, KIND>(pr, m, S, C, mn, Sn, Gm, GS, gs, om, oS, bad);
                 if (GRAD) {
 #pragma unroll
                     for (int e = 0; e < ET; ++e) gd[e] = cS[e] + GS[e];
@@ -273,7 +334,7 @@ __global__ __launch_bounds__(64) void k_sde_kl(LevelDesc lv, SdeParams pr, const
 // parameters.  Transition t -> t+1 is linearised on the marginal of node t+1 (the reference passes fx_mus[1:]):
 //     A_t = diag(J(m_{t+1}, v_{t+1})),   b_t = ubar - J m   at node t+1,   Q_t = dt q,
 // both clipped to [clip_lo, clip_hi] when stabilising.  Node 0 carries the prior initial state.
-template <int D>
+template <int D, int KIND>
 __global__ __launch_bounds__(64) void k_linearize_cubic(LevelDesc lv, SdeParams pr, const double* __restrict__ mug,
                                                        const double* __restrict__ Sigg,
                                                        double* __restrict__ Ag, double* __restrict__ offg,
@@ -302,7 +363,7 @@ __global__ __launch_bounds__(64) void k_linearize_cubic(LevelDesc lv, SdeParams 
             } else {
                 ld_node<D>(mug, R, s, me, m);
                 ld_node<ET>(Sigg, R, s, me, S);
-                cubic_moments<D>(pr, m, S, ubar, J, V, t0, t1, t2, t3, t4);
+                cubic_moments<D, KIND, 10>(pr, m, S, ubar, J, V, t0, t1, t2, t3, t4);
 #pragma unroll
                 for (int i = 0; i < D; ++i) off[i] = clipf(ubar[i] - J[i] * m[i]);
 #pragma unroll
@@ -318,7 +379,7 @@ __global__ __launch_bounds__(64) void k_linearize_cubic(LevelDesc lv, SdeParams 
             if (t + 1 < n) {
                 ld_next<D>(mug, R, s, len, lane, me, m);
                 ld_next<ET>(Sigg, R, s, len, lane, me, S);
-                cubic_moments<D>(pr, m, S, ubar, J, V, t0, t1, t2, t3, t4);
+                cubic_moments<D, KIND, 10>(pr, m, S, ubar, J, V, t0, t1, t2, t3, t4);
 #pragma unroll
                 for (int e = 0; e < EF; ++e) A[e] = clipf(0.0);
 #pragma unroll
@@ -346,7 +407,7 @@ namespace mfgm {
 // (variational_cvi_sde.py:279-299).  No d x d factorisation is needed.  mom: [3D per node] = (mu, diag Sigma, diag Sigma_{t+1,t}).
 // MODE 0: per-lane partial of  sum_t 1/2 [ sum_i W_i T_i + logdet Qp ] + node-0 term  (host adds log|L_q| - N/2);
 // MODE 3: theta_q update (data-site part added by the caller).
-template <int D, int MODE>
+template <int D, int MODE, int KIND>
 __global__ __launch_bounds__(64) void k_sde_lean(LevelDesc lv, SdeParams pr, const double* __restrict__ momg,
                                                 const double* __restrict__ Sigg, double* __restrict__ part, double* q1,
                                                 double* qd, double* qs) {
@@ -370,8 +431,9 @@ __global__ __launch_bounds__(64) void k_sde_lean(LevelDesc lv, SdeParams pr, con
         ld_node<3 * D>(momg, R, R - 1, LaneRef::of(lane - 1), prv);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const double al = pr.alpha[i], be = pr.beta[i], mi = prv[i], v = prv[D + i], m2 = mi * mi;
-            const double ub = al * mi - be * mi * (m2 + 3.0 * v), J = al - 3.0 * be * (m2 + v);
+            const double mi = prv[i];
+            double ub, J, V_, ub_v_, J_m_, J_v_, V_m_, V_v_;
+            drift_mom<KIND, 20>(pr, i, mi, prv[D + i], ub, J, V_, ub_v_, J_m_, J_v_, V_m_, V_v_);
             pWe[i] = pr.W[i] * (ub - cur[i]);
             pWJm[i] = pr.W[i] * J * mi;
         }
@@ -388,15 +450,12 @@ __global__ __launch_bounds__(64) void k_sde_lean(LevelDesc lv, SdeParams pr, con
             double t1[D], tdg[D], tsb[D], nWe[D], nWJm[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                const double al = pr.alpha[i], be = pr.beta[i], W = pr.W[i];
-                const double mi = cur[i], v = cur[D + i], c = cur[2 * D + i], m2 = mi * mi, a = m2 + v;
+                const double W = pr.W[i];
+                const double mi = cur[i], v = cur[D + i], c = cur[2 * D + i];
                 double Fm = pWe[i], dg = (t >= 1) ? -0.5 * W : 0.0, sb = 0.0, we = 0.0, wjm = 0.0, corr = pWJm[i];
                 if (has_next) {
-                    const double ub = al * mi - be * mi * (m2 + 3.0 * v), J = al - 3.0 * be * a;
-                    const double V = al * al * v - 6.0 * al * be * v * a + be * be * v * (9.0 * m2 * m2 + 36.0 * m2 * v + 15.0 * v * v);
-                    const double ub_v = -3.0 * be * mi, J_m = -6.0 * be * mi, J_v = -3.0 * be;
-                    const double V_m = -12.0 * al * be * mi * v + be * be * mi * v * (36.0 * m2 + 72.0 * v);
-                    const double V_v = al * al - 6.0 * al * be * (m2 + 2.0 * v) + be * be * (9.0 * m2 * m2 + 72.0 * m2 * v + 45.0 * v * v);
+                    double ub, J, V, ub_v, J_m, J_v, V_m, V_v;
+                    drift_mom<KIND, 20>(pr, i, mi, v, ub, J, V, ub_v, J_m, J_v, V_m, V_v);
                     const double mn = nxt[i], vn = nxt[D + i];
                     const double k = W * c;
                     we = W * (ub - mn);

@@ -15,6 +15,8 @@ from . import _lib
 class SDE:
     """sde.py:24-131."""
 
+    kind = 0        # drift family understood by the HIP kernels (mfgm_sde_params.kind): 0 = per-dimension cubic
+
     def __init__(self, q):
         q = torch.as_tensor(q, dtype=torch.float64)
         if q.dim() == 0:
@@ -65,8 +67,11 @@ class SDE:
     def params(self, dt, init_mu, init_cov, lr=0.0, clip=None):
         """Fill the C parameter block (mfgm_sde_params)."""
         d = self.state_dim
-        al, be = self.cubic(dt)
+        al, be = self.cubic(dt) if self.kind == 0 else (1.0, 0.0)
         prm = _lib.SdeParams()
+        prm.kind, prm.dt = int(self.kind), float(dt)
+        for i in range(d):
+            prm.theta[i] = float(getattr(self, "theta", 0.0))
         P0 = np.asarray(init_cov, dtype=np.float64).reshape(d, d)
         P0inv = np.linalg.inv(P0)
         cP0 = np.linalg.cholesky(P0)
@@ -145,3 +150,64 @@ class DoubleWellSDE(SDE):
 
     def drift_cubic(self):
         return self.scale * self.c, self.scale
+
+
+class _ThetaSDE(SDE):
+    """Per-dimension non-polynomial drifts with one parameter theta (sde.py:227-356): Gaussian expectations by the reference's
+    Gauss-Hermite rules inside the kernels (state_dim <= 4); no VDP / prior-learning support (those kernels are cubic-only)."""
+
+    _param_names = ("theta",)
+
+    def __init__(self, theta, q=None, trainable=False):
+        super().__init__(torch.ones((1, 1), dtype=torch.float64) if q is None else q)
+        if self.state_dim > 4:
+            raise ValueError("the quadrature drifts are built for state_dim <= 4")
+        self.theta = float(theta)
+        self._trainable = {"theta": bool(trainable)}
+
+    def cubic(self, dt):
+        raise NotImplementedError(f"{type(self).__name__} is not a cubic drift")
+
+    drift_cubic = cubic
+
+
+class BenesSDE(_ThetaSDE):
+    """dx = theta tanh(x) dt + dB (sde.py:227-268)."""
+    kind = 1
+
+    def __init__(self, theta=1.0, q=None, trainable=False):
+        super().__init__(theta, q, trainable)
+
+    def drift(self, x, t=None):
+        return self.theta * torch.tanh(x)
+
+    def gradient_drift(self, x, t=None):
+        return self.theta * (1.0 - torch.tanh(x) ** 2)
+
+
+class SineDiffusionSDE(_ThetaSDE):
+    """dx = sin(x - theta) dt + dB (sde.py:271-312)."""
+    kind = 2
+
+    def __init__(self, theta=0.0, q=None, trainable=False):
+        super().__init__(theta, q, trainable)
+
+    def drift(self, x, t=None):
+        return torch.sin(x - self.theta)
+
+    def gradient_drift(self, x, t=None):
+        return torch.cos(x - self.theta)
+
+
+class SqrtDiffusionSDE(_ThetaSDE):
+    """dx = sqrt(theta |x|) dt + dB (sde.py:315-356)."""
+    kind = 3
+
+    def __init__(self, theta=1.0, q=None, trainable=False):
+        super().__init__(theta, q, trainable)
+
+    def drift(self, x, t=None):
+        return torch.sqrt(self.theta * torch.abs(x))
+
+    def gradient_drift(self, x, t=None):
+        return 0.5 * torch.sign(x) * torch.sqrt(self.theta / torch.abs(x))
