@@ -120,7 +120,8 @@ def main():
 
     import vidp_amd
     from vidp_amd import distributed as vdist
-    rank, world = vdist.init_from_env(backend="nccl")      # "nccl" is RCCL on ROCm
+    # "nccl" is RCCL on ROCm; VIDP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path only)
+    rank, world = vdist.init_from_env(backend=os.environ.get("VIDP_DIST_BACKEND", "nccl"))
     if world > 1:
         import torch.distributed as dist
     else:
