@@ -138,11 +138,12 @@ def test_partition_invariance_large(amd, rng):
     np.testing.assert_allclose(np_btd.dense_mult(diag, sub, x, symmetric=True), r, rtol=1e-7, atol=1e-8)
 
 
-def test_natural_layout_entry_points(amd, rng):
-    """mfgm_btd_cholesky / mfgm_btd_posterior: the natural-layout C entry points a TF custom-op kernel would call."""
+@pytest.mark.parametrize("B,T,d", [(3, 57, 3), (2, 41, 12), (1, 30, 20)])
+def test_natural_layout_entry_points(amd, rng, B, T, d):
+    """mfgm_btd_cholesky / mfgm_btd_posterior: the natural-layout C entry points a TF custom-op kernel would call
+    (lane-per-segment, MFMA and row-per-lane kernel families)."""
     import torch
     from vidp_amd.packed import _ptr, _stream
-    B, T, d = 3, 57, 3
     diag, sub = random_dominant_btd(rng, (B,), T, d)
     r = rng.normal(size=(B, T, d))
     plan = amd.Plan(B, T, d, R0=8, Rup=4)
