@@ -372,12 +372,16 @@ def test_one_chain_sharded_over_ranks(amd, rng, d, T, R0, world):
 def test_one_chain_two_processes():
     """The same sharded solve through a real process group: 2 ranks (gloo, rendezvous on 127.0.0.1) sharing the one GPU."""
     import os
+    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:          # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", os.path.join(root, "tests", "mp_chain_shard.py")]
+           "--master-port", str(port), os.path.join(root, "tests", "mp_chain_shard.py")]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "chain shard parity ok 2" in res.stdout
