@@ -90,3 +90,17 @@ def test_e_sde_closed_form(rng, d, kind):
         e = np.zeros_like(S); e[t, i, j] = eps; e[t, j, i] = eps
         fd = (f(m, S + e) - f(m, S - e)) / (2 * eps)
         np.testing.assert_allclose(dS[t, i, j] * (1.0 if i == j else 2.0), fd, rtol=1e-5, atol=1e-7)
+
+
+def test_non_polynomial_drifts_against_adaptive_quadrature(rng):
+    """BenesSDE / SineDiffusionSDE / SqrtDiffusionSDE (sde.py:227-356): the 10-point rule of expected_drift and
+    expected_gradient_drift (sde.py:92-131) against scipy's adaptive quadrature of the same Gaussian integrals."""
+    from scipy import integrate
+    for sde, m, v in ((np_sde.BenesSDE(1.3), 0.4, 0.3), (np_sde.SineDiffusionSDE(0.4), -0.7, 0.5), (np_sde.SqrtDiffusionSDE(1.5), 4.0, 0.2)):
+        pdf = lambda x: np.exp(-0.5 * (x - m) ** 2 / v) / np.sqrt(2 * np.pi * v)
+        Ef = integrate.quad(lambda x: float(sde.drift(np.array([x]))[0]) * pdf(x), m - 12 * np.sqrt(v), m + 12 * np.sqrt(v))[0]
+        Eg = integrate.quad(lambda x: float(sde.gradient_drift(np.array([x]))[0]) * pdf(x), m - 12 * np.sqrt(v), m + 12 * np.sqrt(v))[0]
+        mm, vv = np.full((1, 1, 1), m), np.full((1, 1, 1, 1), v)
+        # tolerance = accuracy of the reference's own 10-point rule on these integrands
+        np.testing.assert_allclose(sde.expected_drift(mm, vv)[0, 0, 0], Ef, rtol=5e-6)
+        np.testing.assert_allclose(sde.expected_gradient_drift(mm, vv)[0, 0, 0], Eg, rtol=5e-5)
