@@ -169,3 +169,46 @@ def test_natural_layout_entry_points(amd, rng, B, T, d):
     assert_close(Sd.cpu().numpy(), oSd)
     assert_close(Ss.cpu().numpy(), oSs)
     assert_close(x.cpu().numpy(), np_btd.solve(oLd, oLs, np_btd.solve(oLd, oLs, r), transpose_left=True))
+
+
+@pytest.mark.parametrize("name,B,T,d", [("C2", 1, 100000, 3), ("C3", 64, 50000, 6), ("headline", 64, 100000, 6), ("C5", 1, 200000, 16)])
+def test_full_size_properties(amd, name, B, T, d):
+    """BASELINE.json's full sizes, through size-independent properties (inputs generated on the device):
+    K (K^{-1} r) = r,  tr(K Sigma) = sum_t <D_t, Sigma_tt> + 2 <S_t, Sigma_{t+1,t}> = T d  (only the selected-inverse blocks enter),
+    log det and the solve independent of the time partition, and L L^T reproducing the diagonal blocks."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(71892305)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda", dtype=torch.float64)
+    D = 0.1 * rnd(B, T, d, d)
+    D = D + D.transpose(-1, -2) + (4.0 + d ** 0.5) * torch.eye(d, device="cuda", dtype=torch.float64)
+    S = (0.3 / d ** 0.5) * rnd(B, T - 1, d, d)
+    r = rnd(B, T, d)
+    plan = amd.Plan(B, T, d)
+    Dp, Sp, rp = plan.pack(amd.SYM, D), plan.pack(amd.FULL, S), plan.pack(amd.VEC, r)
+    f = plan.factor(Dp, Sp, rp, want_logdet=True, want_quad=True)
+    s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True)
+    plan.check_info()
+    x, Sig, Sub = plan.unpack(amd.VEC, s["x"]), plan.unpack(amd.SYM, s["Sig"]), plan.unpack(amd.FULL, s["Sub"], T - 1)
+    # K x = r
+    Kx = (D @ x[..., None])[..., 0]
+    Kx[:, 1:] += (S @ x[:, :-1, :, None])[..., 0]
+    Kx[:, :-1] += (S.transpose(-1, -2) @ x[:, 1:, :, None])[..., 0]
+    assert float((Kx - r).abs().max()) < 1e-10 * float(r.abs().max()) * 100
+    # tr(K Sigma) = T d per chain
+    tr = (D * Sig).sum(dim=(1, 2, 3)) + 2.0 * (S * Sub).sum(dim=(1, 2, 3))
+    np.testing.assert_allclose(tr.cpu().numpy(), T * d, rtol=1e-10)
+    # r^T K^{-1} r = |L^{-1} r|^2
+    np.testing.assert_allclose((r * x).sum(dim=(1, 2)).cpu().numpy(), f["quad"].cpu().numpy(), rtol=1e-10)
+    # the factor reproduces the diagonal blocks: L_tt L_tt^T + L_{t,t-1} L_{t,t-1}^T = D_t
+    L, G = plan.unpack(amd.TRI, f["L"]), plan.unpack(amd.FULL, f["G"], T - 1)
+    rec = L @ L.transpose(-1, -2)
+    rec[:, 1:] += G @ G.transpose(-1, -2)
+    assert float((rec - D).abs().max()) < 1e-12 * float(D.abs().max()) * 100
+    del rec, L, G, Kx
+    # another time partition gives the same log-determinant and solve
+    plan2 = amd.Plan(B, T, d, R0=max(8, plan.R * 3 + 1), Rup=5)
+    f2 = plan2.factor(plan2.pack(amd.SYM, D), plan2.pack(amd.FULL, S), plan2.pack(amd.VEC, r), want_logdet=True)
+    s2 = plan2.selinv(f2["L"], f2["G"], f2["y"], want_sub=False)
+    plan2.check_info()
+    np.testing.assert_allclose(f2["logdet"].cpu().numpy(), f["logdet"].cpu().numpy(), rtol=1e-12)
+    assert float((plan2.unpack(amd.VEC, s2["x"]) - x).abs().max()) < 1e-11

@@ -183,8 +183,8 @@ int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed
     if (!node_ids || !values) return 1;
     const Plan& P = plan->p;
     const size_t total = (size_t)n * kind_enat(kind, P.d);
-    if (total >= (1ull << 32)) return 1;
-    int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    if (total >= (1ull << 32) || (size_t)P.B * P.T >= (1ull << 32)) return 1;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 16384);
     if (P.wide) {
         hipLaunchKernelGGL(kw_node_io, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.d, kind, packed, packed2, node_ids, n,
                            values, mode, scale);

@@ -47,8 +47,9 @@ static __global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int
     const unsigned total = (unsigned)n * En;
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const unsigned i = idx / En, ne = idx - i * En;
-        const long long id = node_ids[i];
-        const unsigned b = (unsigned)(id / T), t = (unsigned)(id - (long long)b * T);
+        // the host guarantees B * T < 2^32: 32-bit division (a 64-bit one costs more than the memory access it addresses)
+        const unsigned id = (unsigned)node_ids[i];
+        const unsigned b = id / (unsigned)T, t = id - b * (unsigned)T;
         const unsigned p = t / lv.R, s = t - p * lv.R, lane = b * lv.P + p;
         unsigned Ep = En, e = ne;
         bool skip = false, zero = false;
