@@ -18,7 +18,7 @@ import os
 import numpy as np
 import torch
 
-from ._lib import FULL, SYM, TRI, VEC
+from ._lib import FULL, SYM, VEC
 
 
 def load_exp_data(data_path, device="cuda"):

@@ -10,8 +10,8 @@ import math
 import torch
 
 from . import linalg
-from ._lib import FULL, SYM, TRI, VEC
-from .state_space_model import StateSpaceModel, _flat
+from ._lib import FULL, SYM, VEC
+from .state_space_model import StateSpaceModel
 
 
 class GaussianSitesNat:

@@ -2,7 +2,6 @@
 Host-side mirror of markovflow/posterior.py `ConditionalProcess` (posterior.py:166-260): the posterior process
 q(s(.)) = int p(s(.) | s(Z)) q(s(Z)) ds(Z) evaluated at arbitrary sorted time points.
 """
-import torch
 
 from .conditionals import conditional_predict, pairwise_marginals
 

@@ -8,7 +8,7 @@ step is independent d x d algebra on the selected-inverse blocks.
 import torch
 
 from . import linalg
-from ._lib import FULL, SYM, TRI, VEC
+from ._lib import FULL, SYM, VEC
 from .packed import Plan
 from .state_space_model import StateSpaceModel, _flat
 

@@ -17,7 +17,7 @@ test for this variant (parity unpinned); tests check the update against the same
 """
 import torch
 
-from ._lib import FULL, SYM, TRI, VEC
+from ._lib import FULL, SYM, VEC
 from .ssm_gaussian_transformations import naturals_to_ssm_params_packed
 from .state_space_model import StateSpaceModel
 from .variational_cvi import back_project_nats

@@ -7,7 +7,7 @@ sites, refreshed by the HIP sweeps.
 """
 import torch
 
-from ._lib import FULL, SYM, TRI, VEC
+from ._lib import SYM, VEC
 from .kalman_filter import GaussianSitesNat, KalmanFilter, KalmanFilterWithSites
 from .ssm_gaussian_transformations import naturals_to_ssm_params_packed
 

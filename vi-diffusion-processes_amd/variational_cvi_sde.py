@@ -10,11 +10,9 @@ Same method names as the reference (`full_sites`, `dist_q`, `update_data_sites`,
   * all per-time-step state (prior naturals, Girsanov sites, posterior naturals, marginals) lives in the
     packed device layout and is refreshed once per site update, not once per property access.
 """
-import math
-
 import torch
 
-from ._lib import FULL, SYM, TRI, VEC
+from ._lib import FULL, SYM, VEC
 from .packed import Plan
 from .state_space_model import StateSpaceModel
 

@@ -8,7 +8,6 @@ update_lagrange (with an O(T) tensor copy per step) is a partitioned affine recu
 Prior / initial distributions are (mean [d], covariance [d, d]) pairs.
 """
 import ctypes
-import math
 
 import numpy as np
 import torch
