@@ -123,6 +123,13 @@ MFGM_DEV Tile tile_transpose(const Tile& t, double* lds, const LaneId& L) {
     return o;
 }
 
+// ds_bpermute of a double with a precomputed byte address (source lane * 4)
+MFGM_DEV double bperm(double x, int addr) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
 // Gauss-Jordan row elimination on [A | Bm] (Bm = I on entry).
 //   CHOL: A symmetric positive definite  ->  A = L^T in its upper triangle (the strict lower triangle is left with rounding
 //         residue and must be masked by the caller), Bm = L^{-1};  prod *= prod_j 1/L_jj
@@ -131,12 +138,18 @@ MFGM_DEV Tile tile_transpose(const Tile& t, double* lds, const LaneId& L) {
 // below the pivot (no per-lane selects), register ji mixes finished rows, the pivot row and rows below.
 template <bool CHOL>
 MFGM_DEV void gj16(Tile& A, Tile& Bm, const LaneId& L, double& prod, int& bad) {
+    const int rowaddr[4] = {L.c << 2, (16 | L.c) << 2, (32 | L.c) << 2, (48 | L.c) << 2};   // lane (jr, c), as byte addresses
+    const int colbase = (L.lane & 0x30) << 2;                                               // lane (g, 0)
+    // Finished (pivot) rows stay unscaled in the registers during the loop; their scale factors are collected per row in
+    // `srow` and applied once at the end, which keeps per-lane selects out of the pivot loop.
+    Tile srow = {{1.0, 1.0, 1.0, 1.0}};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int jr = j & 3, ji = j >> 2;
-        double rA = __shfl(A.r[ji], (jr << 4) | L.c, 64);       // row j of both tiles, per column
-        double rB = __shfl(Bm.r[ji], (jr << 4) | L.c, 64);
-        double p = bcast(rA, j);                                // pivot A[j][j]
+        double rA = bperm(A.r[ji], rowaddr[jr]);                // row j of both tiles (unscaled), per column
+        double rB = bperm(Bm.r[ji], rowaddr[jr]);
+        double p = bcast(A.r[ji], (jr << 4) | j);               // pivot A[j][j], read at its home lane: the row broadcast
+                                                                 // above is then off the critical path (it overlaps the rsqrt)
         double s, s2;
         if (CHOL) {
             const bool neg = !(p > 0.0);
@@ -151,20 +164,21 @@ MFGM_DEV void gj16(Tile& A, Tile& Bm, const LaneId& L, double& prod, int& bad) {
         }
         rA *= s;
         rB *= s;
-        const int colj = (L.lane & 0x30) | j;
+        srow.r[ji] = (L.g == jr) ? s : srow.r[ji];
+        const int colj = colbase + 4 * j;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < ji) continue;
-            const double m = __shfl(A.r[i], colj, 64) * s2;    // A[row][j] * s2
-            if (i > ji) {
-                A.r[i] = __builtin_fma(-m, rA, A.r[i]);
-                Bm.r[i] = __builtin_fma(-m, rB, Bm.r[i]);
-            } else {
-                const bool below = L.g > jr, isrow = L.g == jr;
-                A.r[i] = below ? __builtin_fma(-m, rA, A.r[i]) : (isrow ? rA : A.r[i]);
-                Bm.r[i] = below ? __builtin_fma(-m, rB, Bm.r[i]) : (isrow ? rB : Bm.r[i]);
-            }
+            double m = bperm(A.r[i], colj) * s2;               // A[row][j] * s2
+            if (i == ji) m = (L.g > jr) ? m : 0.0;             // rows of this register at or above the pivot are left alone
+            A.r[i] = __builtin_fma(-m, rA, A.r[i]);
+            Bm.r[i] = __builtin_fma(-m, rB, Bm.r[i]);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        A.r[i] *= srow.r[i];
+        Bm.r[i] *= srow.r[i];
     }
 }
 
