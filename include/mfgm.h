@@ -193,6 +193,8 @@ typedef struct mfgm_vdp_params {
     double chol0[36];
     double dt;
     double lr;
+    double clip;          /* > 0: stabilize_system (vi_sde.py:312-323): NaN -> 1e-8 and clipping to [-clip, clip] of dE/dm, dE/dS and
+                           * the jump conditions inside the Lagrange sweep (CLIP_MAX = 5000 in the reference); 0: off */
 } mfgm_vdp_params;
 
 /* forward_pass (vi_sde.py:171-204; LinearDrift(-A, b).to_ssm, drift.py:66-117): variational parameters Am (FULL), bm (VEC),

@@ -235,9 +235,12 @@ class VariationalMarkovGP:
     PARITY UNPINNED: the reference has no test for this class.
     """
 
-    def __init__(self, obs_index, observations, sde, grid, likelihood, init_mu, init_cov):
+    CLIP_MIN, CLIP_MAX = -5000.0, 5000.0          # vi_sde.py:59-60
+
+    def __init__(self, obs_index, observations, sde, grid, likelihood, init_mu, init_cov, stabilize_system=False):
         from . import np_sde
         self._np_sde = np_sde
+        self.stabilize_system = stabilize_system
         self.obs_index, self.y = np.asarray(obs_index), np.asarray(observations, dtype=np.float64)
         self.sde, self.grid, self.lik = sde, np.asarray(grid, dtype=np.float64), likelihood
         self.d = sde.state_dim
@@ -254,6 +257,10 @@ class VariationalMarkovGP:
         """vi_sde.py:171-204: marginals of the SSM of the linear drift -A x + b."""
         q = np.broadcast_to(self.sde.q, (self.N, self.d, self.d))
         ssm = self._np_sde.linear_drift_to_ssm(-self.A, self.b, q, self.grid, self.q0_mu, self.q0_chol)
+        if self.stabilize_system:       # vi_sde.py:186-200
+            A = np.clip(np.where(np.isnan(ssm.A), 1e-8, ssm.A), -1.0, 1.0)
+            b = np.clip(np.where(np.isnan(ssm.b), 1e-8, ssm.b), -1.0, 1.0)
+            ssm = StateSpaceModel(ssm.mu0, ssm.cholP0, A, b, ssm.cholQ)
         return ssm.marginals
 
     def E_sde(self, m=None, S=None):
@@ -280,6 +287,9 @@ class VariationalMarkovGP:
     def update_lagrange(self, m, S):
         dEdm, dEdS = self._grad_E_sde(m, S)
         d_obs_m, d_obs_S = self._jump_conditions(m, S)
+        if self.stabilize_system:       # vi_sde.py:312-323
+            fix = lambda x: np.clip(np.where(np.isnan(x), 1e-8, x), self.CLIP_MIN, self.CLIP_MAX)
+            dEdm, dEdS, d_obs_m, d_obs_S = fix(dEdm), fix(dEdS), fix(d_obs_m), fix(d_obs_S)
         self.lam = np.zeros_like(self.lam)
         self.psi = 1e-10 * np.broadcast_to(np.eye(self.d), (self.N, self.d, self.d)).copy()
         for t in range(self.N - 1, 0, -1):
@@ -290,6 +300,9 @@ class VariationalMarkovGP:
 
     def update_param(self, m, S, lr):
         m, S = m[:-1], S[:-1]
+        if self.stabilize_system:       # vi_sde.py:393-397
+            self.psi = np.clip(np.where(np.isnan(self.psi), 1e-8, self.psi), self.CLIP_MIN, self.CLIP_MAX)
+            self.lam = np.clip(np.where(np.isnan(self.lam), 1e-8, self.lam), self.CLIP_MIN, self.CLIP_MAX)
         q = self.sde.q
         Egrad = -self.sde.expected_gradient_drift(m[None], S[None])[0]
         Ef = self.sde.expected_drift(m[None], S[None])[0]

@@ -891,3 +891,43 @@ def test_cvi_sites_sde_quadrature_drifts(amd, rng, kind):
     g.relinearize()
     o.relinearize()
     np.testing.assert_allclose(host(g.classic_elbo_per_trajectory())[0], o.classic_elbo(), rtol=2e-6, atol=2e-6)
+
+
+def test_variational_markov_gp_stabilized(amd, rng):
+    """stabilize_system (vi_sde.py:186-200, 312-323, 393-397): with a step size and observation precision at which the plain
+    fixed-point iteration leaves the clipping ranges, the clipped / NaN-scrubbed iteration follows the oracle's."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    d, B, T, dt = 1, 1, 40, 0.01
+    grid = np.arange(T) * dt
+    idx = np.arange(3, T - 1, 4)
+    y = 3.0 * np.sign(rng.normal(size=(B, len(idx), d)))
+    cholR = 0.01 * np.eye(d)                     # R^{-1} = 1e4: the jump conditions exceed CLIP_MAX = 5000
+    init = (np.zeros(d), 0.5 * np.eye(d))
+    g = VariationalMarkovGP((grid[idx], dev(y)), gsde.DoubleWellSDE(torch.eye(d, dtype=torch.float64)), grid, MultivariateGaussian(dev(cholR)),
+                            prior_initial_state=init, stabilize_system=True)
+    o = np_models.VariationalMarkovGP(idx, y[0], np_sde.DoubleWellSDE(np.eye(d)), grid, np_models.MultivariateGaussianLik(cholR), *init,
+                                      stabilize_system=True)
+    plan = g.plan
+    clipped = False
+    for it in range(4):
+        mS = g._forward_packed()
+        m, S = o.forward_pass()
+        assert_close(host(plan.unpack(amd.VEC, mS[0]))[0], m)
+        assert_close(host(plan.unpack(amd.SYM, mS[1]))[0], S)
+        g.update_lagrange(mS)
+        o.update_lagrange(m, S)
+        clipped = clipped or np.abs(o.psi).max() > 5000.0 or np.abs(o.lam).max() > 5000.0
+        assert_close(host(plan.unpack(amd.FULL, g.psi_lagrange, T - 1))[0], o.psi)
+        assert_close(host(plan.unpack(amd.VEC, g.lambda_lagrange, T - 1))[0], o.lam)
+        g.update_param(mS, lr=0.5)                   # clips the multipliers in place before using them
+        o.update_param(m, S, 0.5)
+        assert_close(host(plan.unpack(amd.FULL, g.psi_lagrange, T - 1))[0], o.psi)
+        assert_close(host(plan.unpack(amd.FULL, g.A, T - 1))[0], o.A)
+        assert_close(host(plan.unpack(amd.VEC, g.b, T - 1))[0], o.b)
+    assert clipped                                   # the scenario does exercise the clipping
+    ssm_A = np.abs(host(plan.unpack(amd.FULL, g._ssm_bufs[0], T - 1))).max()
+    assert ssm_A <= 1.0 + 1e-12                   # the clipped transitions

@@ -78,7 +78,7 @@ class KernelSpec(ctypes.Structure):
 class VdpParams(ctypes.Structure):
     """mfgm_vdp_params (include/mfgm.h)."""
     _fields_ = [("af", ctypes.c_double * 8), ("bf", ctypes.c_double * 8), ("q", ctypes.c_double * 8), ("mu0", ctypes.c_double * 8),
-                ("chol0", ctypes.c_double * 36), ("dt", ctypes.c_double), ("lr", ctypes.c_double)]
+                ("chol0", ctypes.c_double * 36), ("dt", ctypes.c_double), ("lr", ctypes.c_double), ("clip", ctypes.c_double)]
 
 
 class MfgmError(RuntimeError):

@@ -19,7 +19,13 @@ struct VdpParams {
     double chol0[36];      // q(x0) Cholesky factor (packed lower triangle)
     double dt;
     double lr;
+    double clip;           // > 0: NaN scrubbing and clipping of the Lagrange sweep's inputs (stabilize_system)
 };
+
+MFGM_DEV double vdp_stab(double x, double c) {
+    x = (x != x) ? 1e-8 : x;
+    return fmin(fmax(x, -c), c);
+}
 
 // Gaussian moments of the cubic drift: E f, E f', Var f and partials (same algebra as cubic_moments of mfgm_sde.h)
 template <int D>
@@ -230,6 +236,12 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                     ld_node<D>(yR, R, s, me, yr);
                     ld_node<ET>(dobsS, R, s, me, dob);
                     vdp_energy<D, true>(pr, m, S, A, bb, dm, dS);
+                    if (pr.clip > 0.0) {        // vi_sde.py:312-323
+#pragma unroll
+                        for (int i = 0; i < D; ++i) dm[i] = vdp_stab(dm[i], pr.clip);
+#pragma unroll
+                        for (int e = 0; e < ET; ++e) { dS[e] = vdp_stab(dS[e], pr.clip); dob[e] = vdp_stab(dob[e], pr.clip); }
+                    }
                     // psi <- psi - dt (psi A + psi A - dEdS) - d_obs_S ;  lam <- lam - dt (A lam - dEdm) - d_obs_m
                     double pa[EF], al[D];
                     gemm<D>(psi, A, pa);
@@ -239,6 +251,7 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                         double dom = yr[i];
 #pragma unroll
                         for (int k = 0; k < D; ++k) dom = __builtin_fma(2.0 * dob[six(i, k)], m[k], dom);
+                        if (pr.clip > 0.0) dom = vdp_stab(dom, pr.clip);
                         lam[i] = lam[i] - pr.dt * (al[i] - dm[i]) - dom;
 #pragma unroll
                         for (int j = 0; j < D; ++j)

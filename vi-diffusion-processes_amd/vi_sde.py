@@ -22,8 +22,7 @@ class VariationalMarkovGP:
     """vi_sde.py:63-482."""
 
     def __init__(self, input_data, prior_sde, grid, likelihood, prior_initial_state=None, stabilize_system=False, plan=None):
-        if stabilize_system:
-            raise NotImplementedError("stabilize_system (NaN scrubbing / clipping, vi_sde.py:186-192) is not on the HIP path")
+        self.stabilize_system = bool(stabilize_system)
         obs_times, observations = input_data
         if observations.dim() == 2:
             observations = observations[None]
@@ -65,6 +64,7 @@ class VariationalMarkovGP:
         for i in range(d):
             self._prm.af[i], self._prm.bf[i], self._prm.q[i] = af, bf, prior_sde.q_diag[i]
         self._prm.dt = self.dt
+        self._prm.clip = 5000.0 if self.stabilize_system else 0.0        # CLIP_MAX, vi_sde.py:59-60
         self._ssm_bufs = None
         self.dist_q_ssm = None
 
@@ -96,6 +96,11 @@ class VariationalMarkovGP:
         prm = self._params()
         _lib.check(self.lib.mfgm_packed_vdp_to_ssm(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(A), _ptr(off), _ptr(chol),
                                                    _stream()), "mfgm_packed_vdp_to_ssm")
+        if self.stabilize_system:
+            # vi_sde.py:186-200: NaN -> 1e-8 and clipping of the state transitions and offsets to [-1, 1] (node 0 of `off`, the
+            # initial mean, is rewritten just below)
+            torch.nan_to_num(A, nan=1e-8, out=A).clamp_(-1.0, 1.0)
+            torch.nan_to_num(off, nan=1e-8, out=off).clamp_(-1.0, 1.0)
         # node 0 carries q(x0), which is per trajectory
         node0 = pl.node_ids(torch.zeros(1, dtype=torch.int64))
         pl.scatter_nodes(VEC, off, node0, self.q0_mu)
@@ -178,6 +183,9 @@ class VariationalMarkovGP:
         """A <- (1-lr) A + lr A~, b <- (1-lr) b + lr b~ (vi_sde.py:377-414)."""
         pl = self.plan
         m, S = mS if mS is not None else self._mS
+        if self.stabilize_system:       # vi_sde.py:393-397
+            for arr in (self.psi_lagrange, self.lambda_lagrange):
+                torch.nan_to_num(arr, nan=1e-8, out=arr).clamp_(-5000.0, 5000.0)
         _lib.check(self.lib.mfgm_packed_vdp_update_param(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S),
                                                          _ptr(self.psi_lagrange), _ptr(self.lambda_lagrange), _ptr(self.A),
                                                          _ptr(self.b), _stream()), "mfgm_packed_vdp_update_param")
