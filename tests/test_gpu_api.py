@@ -782,6 +782,18 @@ def test_vdp_prior_gradient_and_learning(amd, rng):
             h = 1e-5
             fd = [(fn(3.0 + h, 0.8) - fn(3.0 - h, 0.8)) / (2 * h), (fn(3.0, 0.8 + h) - fn(3.0, 0.8 - h)) / (2 * h)]
             np.testing.assert_allclose(g, fd, rtol=2e-5, atol=1e-7)
+    # gradient of KL[q(x0) || p(x0)] with respect to the prior's (loc, scale): finite differences of the oracle's Gaussian KL
+    g_loc, g_scale = v.grad_initial_state()
+    q0m, q0S = host(v.q0_mu)[0], host(v.q0_chol @ v.q0_chol.transpose(-1, -2))[0]
+    Lp = np.linalg.cholesky(v.p0_cov)
+    kl0 = lambda loc, L: np_sde.gauss_kl(q0m, q0S, loc, L @ L.T)
+    h = 1e-6
+    for i in range(d):
+        e = np.zeros(d); e[i] = h
+        np.testing.assert_allclose(host(g_loc)[i], (kl0(v.p0_mu + e, Lp) - kl0(v.p0_mu - e, Lp)) / (2 * h), rtol=1e-5, atol=1e-8)
+        for j in range(i + 1):
+            E = np.zeros((d, d)); E[i, j] = h
+            np.testing.assert_allclose(host(g_scale)[i, j], (kl0(v.p0_mu, Lp + E) - kl0(v.p0_mu, Lp - E)) / (2 * h), rtol=1e-5, atol=1e-8)
     # learning: OU data with decay 2, prior initialised at 0.3 (gentle VDP step sizes: the fixed-point iteration diverges otherwise)
     T, dt = 120, 0.01
     grid = np.arange(T) * dt

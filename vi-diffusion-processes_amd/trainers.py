@@ -199,7 +199,7 @@ class VIMarkovGPTrainer:
 
     def __init__(self, model, test_data=None, q_lr=0.1, x0_lr=0.1, max_itr=1000, lr_tol=1e-2, optim_tol=1e-4, warmup_x0_itr=10,
                  warmup_itr=20, learn_prior_sde=False, prior_sde_lr=1e-2, learning_max_itr=100, learning_tol=1e-2,
-                 optimize_prior_initial_state=False):
+                 optimize_prior_initial_state=False, prior_initial_state_lr=0.1):
         self.model = model
         self.q_lr, self.x0_lr, self.max_itr = q_lr, x0_lr, max_itr
         self.lr_tol, self.optim_tol, self.warmup_x0_itr, self.warmup_itr = lr_tol, optim_tol, warmup_x0_itr, warmup_itr
@@ -207,6 +207,7 @@ class VIMarkovGPTrainer:
         self.learn_prior_sde, self.prior_sde_lr = bool(learn_prior_sde), float(prior_sde_lr)
         self.learning_max_itr, self.learning_tol = int(learning_max_itr), float(learning_tol)
         self.optimize_prior_initial_state = bool(optimize_prior_initial_state)
+        self.prior_initial_state_lr = float(prior_initial_state_lr)
         self.prior_params = {}
         if self.learn_prior_sde:
             names = model.prior_sde.trainable_variables
@@ -244,13 +245,23 @@ class VIMarkovGPTrainer:
         return elbos[1:], nlpds, rmses
 
     def optimize_prior_x0(self):
-        """vi_markov_gp_trainer.py:203-215: for an OU prior the initial state follows the stationary covariance q / (2 decay)."""
+        """
+        vi_markov_gp_trainer.py:203-215, as written there: the new "Cholesky factor" M is q / (2 decay) for an OU prior and
+        scale - lr * d KL / d scale otherwise, and the covariance handed to the model is M @ M (no transpose, and for the OU
+        prior the square of the stationary variance) -- mirrored, not corrected.
+        """
+        from . import linalg
         from .sde import OrnsteinUhlenbeckSDE
         mdl, sde = self.model, self.model.prior_sde
-        if not isinstance(sde, OrnsteinUhlenbeckSDE):
-            raise NotImplementedError("gradient steps on p(x0) (grad_initial_state, vi_sde.py:472-482) are built for the OU prior only")
-        cov = torch.diag(torch.tensor(sde.q_diag, dtype=torch.float64)) / (2.0 * sde.decay)
-        mdl.set_prior_initial_state(mdl.p0_mu, cov.numpy())
+        if isinstance(sde, OrnsteinUhlenbeckSDE):
+            mean = mdl.p0_mu
+            M = (torch.diag(torch.tensor(sde.q_diag, dtype=torch.float64)) / (2.0 * sde.decay)).numpy()
+        else:
+            g_loc, g_scale = mdl.grad_initial_state()
+            P0 = torch.from_numpy(mdl.p0_cov).to(mdl.device)
+            mean = mdl.p0_mu - self.prior_initial_state_lr * g_loc.cpu().numpy()
+            M = (linalg.cholesky(P0) - self.prior_initial_state_lr * g_scale).cpu().numpy()
+        mdl.set_prior_initial_state(mean, M @ M)
 
     def optimize_prior_sde(self):
         """vi_markov_gp_trainer.py:163-201: Adam on the drift parameters with dE_sde/d params at the current (m, S)."""

@@ -169,6 +169,24 @@ class VariationalMarkovGP:
         jac = self.prior_sde.drift_cubic_jacobian()
         return [daf * jac[n][0] + dbf * jac[n][1] for n in self.prior_sde.trainable_variables]
 
+    def grad_initial_state(self):
+        """
+        (d KL[q(x0) || p(x0)] / d loc, d / d scale) of the prior initial state N(loc, scale scale^T), summed over trajectories
+        (vi_sde.py:472-482): P^{-1}(loc - m_q) and tril(2 G scale) with G = 1/2 (P^{-1} - P^{-1}(S_q + dd^T) P^{-1}).
+        """
+        d = self.state_dim
+        P0 = torch.from_numpy(self.p0_cov).to(self.device)
+        mu0 = torch.from_numpy(self.p0_mu).to(self.device)
+        Lp = linalg.cholesky(P0)
+        Pinv = linalg.spd_inverse(chol=Lp)
+        delta = mu0 - self.q0_mu                                            # [B, d]
+        S0 = self.q0_chol @ self.q0_chol.transpose(-1, -2)
+        M = S0 + delta[:, :, None] * delta[:, None, :]
+        G = 0.5 * (Pinv[None] - Pinv[None] @ M @ Pinv[None]).sum(0)
+        g_loc = (delta @ Pinv).sum(0)
+        g_scale = torch.tril(2.0 * G @ Lp)
+        return g_loc, g_scale
+
     # -- updates -----------------------------------------------------------------------------------------------
     def update_lagrange(self, mS=None):
         """Backward sweep with jump conditions for (psi, lambda) (vi_sde.py:289-347)."""
