@@ -212,3 +212,39 @@ def test_full_size_properties(amd, name, B, T, d):
     plan2.check_info()
     np.testing.assert_allclose(f2["logdet"].cpu().numpy(), f["logdet"].cpu().numpy(), rtol=1e-12)
     assert float((plan2.unpack(amd.VEC, s2["x"]) - x).abs().max()) < 1e-11
+
+
+def test_random_partitions(amd):
+    """Randomised shapes and partitions (all three kernel families): chains shorter than a segment, one segment per chain,
+    ragged last segments on several levels, Rup = 2, more chains than lanes in a wavefront -- against the oracle."""
+    rs = np.random.default_rng(71892305 + 17)
+    cases = []
+    for _ in range(40):
+        d = int(rs.integers(1, 9))
+        cases.append((int(rs.integers(1, 6)), int(rs.integers(1, 90)), d, int(rs.integers(0, 20)), int(rs.integers(0, 7))))
+    for _ in range(14):
+        d = int(rs.integers(9, 33))
+        cases.append((int(rs.integers(1, 4)), int(rs.integers(1, 50)), d, int(rs.integers(0, 12)), int(rs.integers(0, 5))))
+    cases += [(130, 3, 2, 2, 2), (1, 2, 8, 1, 2), (1, 49, 3, 0, 0), (2, 97, 16, 2, 2)]
+    for B, T, d, R0, Rup in cases:
+        diag, sub = random_dominant_btd(rs, (B,), T, d)
+        r = rs.normal(size=(B, T, d))
+        plan = amd.Plan(B, T, d, R0=R0, Rup=Rup)
+        Sp = plan.pack(amd.FULL, _dev(sub)) if T > 1 else plan.zeros(amd.FULL)
+        f = plan.factor(plan.pack(amd.SYM, _dev(diag)), Sp, plan.pack(amd.VEC, _dev(r)), want_logdet=True, want_quad=True)
+        s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True)
+        plan.check_info()
+        Ld, Ls = np_btd.cholesky(diag, sub)
+        Sd, Ss = np_btd.inverse_blocks(Ld, Ls)
+        ctx = f"B={B} T={T} d={d} R0={R0} Rup={Rup} levels={plan.nlevels}"
+        try:
+            assert_close(plan.unpack(amd.TRI, f["L"]).cpu().numpy(), Ld)
+            np.testing.assert_allclose(f["logdet"].cpu().numpy(), np_btd.abs_log_det(Ld), rtol=1e-9, atol=1e-9)
+            assert_close(plan.unpack(amd.SYM, s["Sig"]).cpu().numpy(), Sd)
+            if T > 1:
+                assert_close(plan.unpack(amd.FULL, f["G"], T - 1).cpu().numpy(), Ls)
+                assert_close(plan.unpack(amd.FULL, s["Sub"], T - 1).cpu().numpy(), Ss)
+            x = np_btd.solve(Ld, Ls, np_btd.solve(Ld, Ls, r), transpose_left=True)
+            assert_close(plan.unpack(amd.VEC, s["x"]).cpu().numpy(), x)
+        except AssertionError as e:
+            raise AssertionError(ctx + "\n" + str(e)) from None
