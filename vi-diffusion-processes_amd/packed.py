@@ -112,11 +112,13 @@ class Plan:
                    "mfgm_lincomb")
         return out
 
-    def gather_nodes(self, kind, packed, node_ids):
-        """node_ids: int64 device tensor of b*T + t.  Returns natural [n, d] or [n, d, d]."""
+    def gather_nodes(self, kind, packed, node_ids, out=None):
+        """node_ids: int64 device tensor of b*T + t.  Returns natural [n, d] or [n, d, d] (written into `out` when given)."""
         n = node_ids.numel()
         shape = (n, self.d) if kind == VEC else (n, self.d, self.d)
-        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        assert tuple(out.shape) == shape and out.is_contiguous()
         _lib.check(self.lib.mfgm_node_io(self.h, kind, _ptr(packed), None, _ptr(node_ids), n, _ptr(out), 0, 1.0, _stream()),
                    "mfgm_node_io(gather)")
         return out

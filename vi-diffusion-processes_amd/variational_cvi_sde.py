@@ -173,8 +173,10 @@ class CVISitesSSM:
 
     def _gather_obs(self):
         q = self._refresh()
-        self.fx_mus_obs = self.plan.gather_nodes(VEC, q["mu"], self.obs_node_ids)
-        self.fx_covs_obs = self.plan.gather_nodes(SYM, q["Sig"], self.obs_node_ids)
+        # persistent buffers, updated in place: the state that crosses iterations keeps its addresses (a captured HIP graph
+        # of one iteration can then be replayed)
+        self.plan.gather_nodes(VEC, q["mu"], self.obs_node_ids, out=self.fx_mus_obs)
+        self.plan.gather_nodes(SYM, q["Sig"], self.obs_node_ids, out=self.fx_covs_obs)
         self._obs_fresh = True
 
     @property
@@ -205,7 +207,8 @@ class CVISitesSSM:
         tq = self.full_sites()
         self.plan.scatter_nodes(VEC, tq.lin, self.obs_node_ids, new1 - self.data_nat1, accumulate=True)
         self.plan.scatter_nodes(SYM, tq.diag, self.obs_node_ids, new2 - self.data_nat2, accumulate=True)
-        self.data_nat1, self.data_nat2 = new1, new2
+        self.data_nat1.copy_(new1)
+        self.data_nat2.copy_(new2)
         self._q = None
         self._obs_fresh = False   # marginals at the observation times are gathered lazily, when next needed
 
