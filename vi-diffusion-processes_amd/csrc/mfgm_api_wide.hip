@@ -37,14 +37,14 @@ int wide_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool 
     return 0;
 }
 
-// d <= 16: MFMA tiles (mfgm_mfma.h) unless MFGM_WIDE_NO_MFMA=1 asks for the row-per-lane kernels (cross-checks)
+// MFMA tiles (mfgm_mfma.h) unless MFGM_WIDE_NO_MFMA=1 asks for the row-per-lane kernels (cross-checks)
 bool use_mfma() {
     static const bool on = [] { const char* e = getenv("MFGM_WIDE_NO_MFMA"); return !(e && atoi(e) != 0); }();
     return on;
 }
 
 int wide_dispatch(int d, int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
-    if (d <= 16 && use_mfma()) return mfma_launch(which, a, has_rhs, has_corr, has_up, want_sub, st);
+    if (use_mfma()) return mfma_launch(which, a, has_rhs, has_corr, has_up, want_sub, st);
     if (d <= 16) return wide_launch<16>(which, a, has_rhs, has_corr, has_up, want_sub, st);
     return wide_launch<32>(which, a, has_rhs, has_corr, has_up, want_sub, st);
 }
