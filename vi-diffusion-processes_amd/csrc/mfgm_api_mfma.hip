@@ -35,6 +35,17 @@ int mfma_launch_nt(int which, const WideArgs& a, bool has_rhs, bool has_corr, bo
 }
 }  // namespace
 
+int mfma_ssm_to_naturals(int B, int T, int d, const double* A, const double* off, const double* chol, double cD, double cS,
+                         double* lin, double* diag, double* sub, double* part, hipStream_t st) {
+    dim3 grid(B * T), block(64);
+#define S2N(NT_, LIN_) hipLaunchKernelGGL((km_ssm_to_naturals<NT_, LIN_>), grid, block, 0, st, B, T, d, A, off, chol, cD, cS, lin, diag, sub, part)
+    if (d <= 16) { if (lin) S2N(1, true); else S2N(1, false); }
+    else { if (lin) S2N(2, true); else S2N(2, false); }
+#undef S2N
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 int mfma_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
     if (a.d <= 16) return mfma_launch_nt<1>(which, a, has_rhs, has_corr, has_up, want_sub, st);
     return mfma_launch_nt<2>(which, a, has_rhs, has_corr, has_up, want_sub, st);

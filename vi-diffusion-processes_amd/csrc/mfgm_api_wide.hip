@@ -146,12 +146,17 @@ int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double*
 int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
                          double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st) {
     double* part = sumlogchol ? ws + P.off_part[0] : nullptr;
-    dim3 grid(P.B * P.T), block(64);
+    if (use_mfma()) {
+        int rc = mfma_ssm_to_naturals(P.B, P.T, P.d, A, off, chol, cD, cS, lin, diag, sub, part, st);
+        if (rc) return rc;
+    } else {
+        dim3 grid(P.B * P.T), block(64);
 #define S2N(DM_, LIN_) hipLaunchKernelGGL((kw_ssm_to_naturals<DM_, LIN_>), grid, block, 0, st, P.B, P.T, P.d, A, off, chol, cD, cS, lin, diag, sub, part)
-    if (P.d <= 16) { if (lin) S2N(16, true); else S2N(16, false); }
-    else { if (lin) S2N(32, true); else S2N(32, false); }
+        if (P.d <= 16) { if (lin) S2N(16, true); else S2N(16, false); }
+        else { if (lin) S2N(32, true); else S2N(32, false); }
 #undef S2N
-    MFGM_CHECK_LAUNCH();
+        MFGM_CHECK_LAUNCH();
+    }
     if (sumlogchol) {
         hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, P.T, 0, sumlogchol, (double*)nullptr);
         MFGM_CHECK_LAUNCH();

@@ -62,5 +62,7 @@ int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const dou
 // mfgm_api_mfma.hip: which = 0 reduce, 1 forward, 2 backward
 struct WideArgs;
 int mfma_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st);
+int mfma_ssm_to_naturals(int B, int T, int d, const double* A, const double* off, const double* chol, double cD, double cS,
+                         double* lin, double* diag, double* sub, double* part, hipStream_t st);
 
 }  // namespace mfgm

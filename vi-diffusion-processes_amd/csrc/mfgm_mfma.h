@@ -244,8 +244,9 @@ MFGM_DEV double bperm(double x, int addr) {
 
 // Gauss-Jordan row elimination on [A | Bm] (Bm = I on entry).
 //   CHOL: A symmetric positive definite  ->  A = L^T in its upper triangle (the strict lower triangle is left with rounding
-//         residue and must be masked by the caller), Bm = L^{-1};  prod *= prod_j 1/L_jj
+//         residue and must be masked by the caller), Bm = L^{-1}
 //   else: A = L lower triangular         ->  Bm = L^{-1}  (A is consumed)
+// In both modes prod *= prod_j 1 / L_jj.
 // Row j = 16 J + jj lives in tile row J, lane row jr = jj & 3, register ji = jj >> 2.  Registers holding only rows below the
 // pivot need no per-lane selects; the register of the pivot row masks its multiplier.  Finished (pivot) rows stay unscaled in the
 // registers during the loop; their scale factors are collected per row in `srow` and applied once at the end.
@@ -277,6 +278,7 @@ MFGM_DEV void gj(Mat<NT>& A, Mat<NT>& Bm, const LaneId& L, double& prod, int& ba
         } else {
             s = rcp_nr(p);
             s2 = 1.0;
+            prod *= s;
         }
 #pragma unroll
         for (int Jc = 0; Jc < NT; ++Jc) { rA[Jc] *= s; rB[Jc] *= s; }
@@ -523,6 +525,60 @@ static __global__ __launch_bounds__(64) void km_backward(WideArgs a) {
     for (int s = len - 2; s >= 0; --s) step(t0 + s, true);
     if (WANT_SUB && p > 0) step(t0 - 1, false);
     if (bad && L.lane == 0) atomicMax(a.info, 1);
+}
+
+// ---- SSM parameters -> naturals / precision blocks, one wavefront per node (same outputs as k_ssm_to_naturals) ------------------------
+// With X = chol^{-1}:  Qi = gram(X, X);  M = Qi_{t+1} A = gram(Qi_{t+1}, A);  diag = cD (Qi_t + gram(A, M));  sub = cS M;
+// lin = gram(Qi_t, off_t) - gram(A, gram(Qi_{t+1}, off_{t+1})) -- Gram products only, no transposes.
+template <int NT, bool WANT_LIN>
+static __global__ __launch_bounds__(64) void km_ssm_to_naturals(int B, int T, int d, const double* __restrict__ Ag,
+                                                               const double* __restrict__ offg, const double* __restrict__ cholg,
+                                                               double cD, double cS, double* __restrict__ ling,
+                                                               double* __restrict__ diagg, double* __restrict__ subg,
+                                                               double* __restrict__ part_logdet) {
+    const LaneId L{(int)threadIdx.x, (int)threadIdx.x >> 4, (int)threadIdx.x & 15};
+    const int EF = d * d;
+    const int b = blockIdx.x / T, t = blockIdx.x - b * T;
+    (void)B;
+    int bad = 0;
+    const bool has_next = (t + 1 < T);
+    // all loads first
+    const Mat<NT> C0 = ld_mat<NT, false, true>(wblk(cholg, b, T, t, EF), d, L, 1.0);
+    const Mat<NT> C1 = has_next ? ld_mat<NT, false, true>(wblk(cholg, b, T, t + 1, EF), d, L, 1.0) : mat_eye<NT>(L);
+    const Mat<NT> A = has_next ? ld_mat<NT, false, false>(wblk(Ag, b, T, t, EF), d, L, 1.0) : mat_zero<NT>();
+    Vec<NT> o0 = vec_zero<NT>(), o1 = vec_zero<NT>();
+    if (WANT_LIN) {
+        o0 = ld_vec<NT>(wblk(offg, b, T, t, d), d, L, 1.0);
+        if (has_next) o1 = ld_vec<NT>(wblk(offg, b, T, t + 1, d), d, L, 1.0);
+    }
+    double prod = 1.0, dummy = 1.0;
+    Mat<NT> X = mat_eye<NT>(L), Lm = C0;
+    gj<NT, false>(Lm, X, L, prod, bad);
+    Mat<NT> Qi = gram<NT>(X, X);
+    Vec<NT> lin = WANT_LIN ? gram<NT>(Qi, o0) : vec_zero<NT>();
+    Mat<NT> M = mat_zero<NT>();
+    if (has_next) {
+        Mat<NT> X1 = mat_eye<NT>(L);
+        Lm = C1;
+        gj<NT, false>(Lm, X1, L, dummy, bad);
+        const Mat<NT> Q1 = gram<NT>(X1, X1);
+        M = gram<NT>(Q1, A);
+        Qi = gram<NT>(A, M, Qi);
+        if (WANT_LIN) lin = gram<NT>(mat_neg<NT>(A), gram<NT>(Q1, o1), lin);
+    }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Qi.t[I][J].r[i] *= cD;
+                M.t[I][J].r[i] *= cS;
+            }
+    st_mat<NT, false>(wblk(diagg, b, T, t, EF), d, L, Qi);
+    st_mat<NT, false>(wblk(subg, b, T, t, EF), d, L, M);
+    if (WANT_LIN) st_vec<NT>(wblk(ling, b, T, t, d), d, L, lin);
+    if (part_logdet && L.lane == 0) part_logdet[blockIdx.x] = -log(prod);      // sum log diag(chol_t)
 }
 
 }  // namespace mfgm
