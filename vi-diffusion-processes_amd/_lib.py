@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmfgm.so")
+# MFGM_LIB selects another build of the same library (A/B timing of kernel variants); the default is the in-tree one
+LIB_PATH = os.environ.get("MFGM_LIB") or os.path.join(_HERE, "csrc", "libmfgm.so")
 
 VEC, FULL, SYM, TRI = 0, 1, 2, 3
 
