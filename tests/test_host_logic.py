@@ -1,0 +1,94 @@
+"""
+Host-side logic that needs no GPU: parameter blocks handed to the C ABI, kernel specifications, the experiment file schema,
+the trainers' Adam step, shard arithmetic of the time-sharded chain.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_sde_parameter_block():
+    from vidp_amd import sde
+    dw = sde.DoubleWellSDE(q=torch.diag(torch.tensor([0.5, 2.0], dtype=torch.float64)), scale=3.0, c=0.8, scale_trainable=True)
+    prm = dw.params(0.01, np.array([0.1, -0.2]), np.array([[2.0, 0.3], [0.3, 1.0]]), lr=0.25, clip=(-1.0, 1.0))
+    assert prm.kind == 0 and prm.dt == 0.01
+    np.testing.assert_allclose([prm.alpha[0], prm.beta[0]], [1 + 0.01 * 3.0 * 0.8, 0.01 * 3.0])
+    np.testing.assert_allclose([prm.W[0], prm.W[1]], [1 / (0.01 * 0.5), 1 / (0.01 * 2.0)])
+    P0inv = np.linalg.inv(np.array([[2.0, 0.3], [0.3, 1.0]]))
+    np.testing.assert_allclose([prm.P0inv[0], prm.P0inv[1], prm.P0inv[2]], [P0inv[0, 0], P0inv[1, 0], P0inv[1, 1]])
+    np.testing.assert_allclose(prm.logdetQp, math.log(0.005) + math.log(0.02))
+    assert (prm.lr, prm.clip_lo, prm.clip_hi) == (0.25, -1.0, 1.0)
+    assert dw.trainable_variables == ["scale"]
+    np.testing.assert_allclose(dw.cubic_jacobian(0.01)["scale"], (0.01 * 0.8, 0.01))
+    np.testing.assert_allclose(dw.drift_cubic_jacobian()["c"], (3.0, 0.0))
+    ou = sde.OrnsteinUhlenbeckSDE(1.5, torch.eye(1, dtype=torch.float64), trainable=True)
+    assert ou.cubic(0.1) == (1 - 0.15, 0.0) and ou.trainable_variables == ["decay"]
+    b = sde.BenesSDE(1.3)
+    assert b.kind == 1 and b.params(0.02, np.zeros(1), np.eye(1)).theta[0] == 1.3
+    with pytest.raises(NotImplementedError):
+        b.cubic(0.02)
+    with pytest.raises(ValueError):     # non-diagonal diffusion for d > 1
+        sde.DoubleWellSDE(q=torch.tensor([[1.0, 0.2], [0.2, 1.0]], dtype=torch.float64))
+    with pytest.raises(ValueError):
+        sde.SineDiffusionSDE(0.1, torch.eye(5, dtype=torch.float64))
+
+
+def test_kernel_spec_and_closed_forms():
+    from oracle import np_kernels
+    from vidp_amd import kernels as K
+    k = K.Sum([K.Matern52(0.7, 1.3), K.Matern12(0.4, 0.9)], jitter=1e-6)
+    spec = k._spec()
+    assert spec.ncomp == 2 and list(spec.order)[:2] == [3, 1] and list(spec.offset)[:2] == [0, 3] and spec.jitter == 1e-6
+    np.testing.assert_allclose(spec.lam[0], math.sqrt(5.0) / 0.7)
+    ok = np_kernels.Sum([np_kernels.Matern52(0.7, 1.3), np_kernels.Matern12(0.4, 0.9)])
+    np.testing.assert_allclose(k.steady_state_covariance.numpy(), ok.steady_state_covariance(), rtol=1e-13)
+    A, Q = k.transition_statistics_local(torch.tensor([0.05, 0.3], dtype=torch.float64))
+    oA, oQ = ok.transition_statistics(np.array([0.05, 0.3]))
+    np.testing.assert_allclose(A.numpy(), oA, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(Q.numpy() - 1e-6 * np.eye(4), oQ, rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        K.Matern32(-1.0, 1.0)
+
+
+def test_exp_data_schema(tmp_path):
+    from vidp_amd import exp_io
+    path = str(tmp_path / "d.npz")
+    grid = np.linspace(0, 1, 11)
+    exp_io.save_exp_data(path, Q=np.eye(1), x0=np.ones(1), sigma=0.2, latent_process=np.zeros((11, 1)), observation_grid=grid[::2],
+                         observations=np.ones((6, 1)), test_grid=grid[1::4], test_observations=np.zeros((3, 1)), time_grid=grid)
+    assert sorted(np.load(path).files) == sorted(["Q", "x0", "sigma", "latent_process", "observation_grid", "observations", "test_grid",
+                                                  "test_observations", "time_grid"])
+    Q, x0, noise, latent, obs, tg, test = exp_io.load_exp_data(path, device="cpu")
+    assert noise.shape == (1, 1) and noise.item() == 0.2 and obs[0].dtype == torch.float64 and tuple(test[1].shape) == (3, 1)
+
+
+def test_adam_matches_the_documented_update():
+    from vidp_amd.trainers import _Adam
+    opt = _Adam(0.1, 2)
+    x, m, v = [1.0, -2.0], [0.0, 0.0], [0.0, 0.0]
+    for t, g in enumerate(([0.3, -0.1], [0.2, 0.4], [-0.5, 0.1]), start=1):
+        want = []
+        for i in range(2):
+            m[i] = 0.9 * m[i] + 0.1 * g[i]
+            v[i] = 0.999 * v[i] + 0.001 * g[i] ** 2
+            a = 0.1 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+            want.append(x[i] - a * m[i] / (math.sqrt(v[i]) + 1e-7))
+        x = opt.step(x, g)
+        np.testing.assert_allclose(x, want, rtol=1e-14)
+
+
+def test_shard_bounds_cover_every_segment():
+    from vidp_amd.distributed import shard_bounds
+    for total in (1, 7, 64, 1021):
+        for world in (1, 2, 3, 8):
+            if world > total:
+                continue
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 3, 3)
