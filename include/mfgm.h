@@ -149,6 +149,12 @@ int mfgm_packed_sde_kl(const mfgm_plan* plan, int mode, const mfgm_sde_params* p
 int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* L, const double* G, const double* y, double* Sig,
                            double* Sub, double* x, double* mom, void* ws, void* stream);
 
+/* The same, for a factorisation made with G = NULL in mfgm_packed_factor (d <= 8): L_{t+1,t} = aS S L^{-T} is never stored; the
+ * backward sweep rebuilds what it needs from the input sub-diagonal blocks S (H = aS S (L L^T)^{-1}).  Same bytes read, d^2 doubles
+ * per node fewer written by the forward sweep.  S and aS must be those given to mfgm_packed_factor. */
+int mfgm_packed_selinv_mom_s(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
+                             double* Sig, double* x, double* mom, void* ws, void* stream);
+
 /* CVI-DP on the moment array: KL[q||p] = -H[q] - E_q[log p] where E_q[log p] of a per-dimension cubic drift with diagonal
  * diffusion depends on q only through mom, so d KL / d eta = theta_q - theta~(mom) with explicit "effective prior naturals"
  * theta~ (csrc/mfgm_sde.h) and no d x d factorisation:

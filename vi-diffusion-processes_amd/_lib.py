@@ -46,6 +46,8 @@ EXPORTS = {
     "mfgm_packed_vdp_lagrange": (ctypes.c_int, [ctypes.c_void_p] * 12),
     "mfgm_packed_vdp_update_param": (ctypes.c_int, [ctypes.c_void_p] * 9),
     "mfgm_packed_selinv_mom": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9),
+    "mfgm_packed_selinv_mom_s": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+                                 + [ctypes.c_void_p] * 6),
     "mfgm_packed_sde_lean": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9),
     "mfgm_natural_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_btd_cholesky": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),

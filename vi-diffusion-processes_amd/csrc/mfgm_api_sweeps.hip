@@ -41,7 +41,12 @@ int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub
     dim3 grid(a.lv.Lpad / 64), block(64);
     const bool mom = (a.momg != nullptr);
 #define BW(R_, U_, S_, M_) hipLaunchKernelGGL((k_backward<D, R_, U_, S_, M_>), grid, block, 0, st, a)
-    if (mom) {
+    if (mom && a.Sg != nullptr) {
+        // level 0 rebuilt from the input sub-diagonal blocks (the forward pass stored no L_{t+1,t}); moment output, no Sub
+        if (want_sub) return 1;
+        if (has_up) hipLaunchKernelGGL((k_backward<D, true, true, false, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_backward<D, true, false, false, true, true>), grid, block, 0, st, a);
+    } else if (mom) {
         // the moment array needs the means: has_rhs is guaranteed by the entry point
         if (has_up) { if (want_sub) BW(true, true, true, true); else BW(true, true, false, true); }
         else { if (want_sub) BW(true, false, true, true); else BW(true, false, false, true); }
@@ -132,7 +137,8 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
 
 template <int D>
 int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub,
-                double* x, double* ws, hipStream_t st, int only_level = -1, double* mom = nullptr) {
+                double* x, double* ws, hipStream_t st, int only_level = -1, double* mom = nullptr, const double* Sg = nullptr,
+                double aS = 1.0) {
     const bool has_rhs = (yg != nullptr);
     const int K = P.nlevels - 1;
     for (int l = K; l >= 0; --l) {
@@ -143,6 +149,7 @@ int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double*
         if (l == 0) {
             a.Lg = const_cast<double*>(Lg); a.Gg = const_cast<double*>(Gg); a.yg = const_cast<double*>(yg);
             a.Sigg = Sig; a.Subg = Sub; a.mug = x; a.momg = mom;
+            a.Sg = Sg; a.aS = aS;          // non-null Sg: level 0 reads S instead of L_{t+1,t} (see k_backward, USE_S)
         } else {
             bind_level_inputs(P, l, ws, a);
         }
@@ -160,8 +167,9 @@ extern "C" {
 int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, const double* r, double aD, double aS,
                        double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
                        void* stream) {
-    if (!plan || !D || !L || !G || !info) return 1;
+    if (!plan || !D || !L || !info) return 1;
     const Plan& P = plan->p;
+    if (!G && P.wide) return 1;           // the lane-per-segment kernels may skip the L_{t+1,t} output (see mfgm_packed_selinv_mom_s)
     if (P.T > 1 && !S) return 1;
     if ((r != nullptr) != (y != nullptr)) return 1;
     if (!ws && P.ws_doubles > 0) return 1;
@@ -204,6 +212,15 @@ int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, 
     if ((y != nullptr) != (x != nullptr)) return 1;
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, G, y, Sig, Sub, x, (double*)ws, st, level)));
+}
+
+int mfgm_packed_selinv_mom_s(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
+                             double* Sig, double* x, double* mom, void* ws, void* stream) {
+    if (!plan || !L || !S || !Sig || !y || !x || !mom) return 1;
+    const Plan& P = plan->p;
+    if (P.wide || only_level >= P.nlevels) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, nullptr, y, Sig, nullptr, x, (double*)ws, st, only_level, mom, S, aS)));
 }
 
 int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* L, const double* G, const double* y, double* Sig,

@@ -305,7 +305,7 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
             if (HAS_RHS) trsv_lower<D>(F, invd, h);
             trsm_right_lower_t<D>(F, invd, G);
             st_node<ET>(a.Lg, R, s, me, F);
-            st_node<EF>(a.Gg, R, s, me, G);
+            if (a.Gg) st_node<EF>(a.Gg, R, s, me, G);     // callers that rebuild H from S in the backward pass skip this store
             if (HAS_RHS) st_node<D>(a.yg, R, s, me, h);
             syrk_set<D>(G, C);
             if (HAS_RHS) gemv<D>(G, h, c);
@@ -324,8 +324,12 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
 }
 
 // ---- backward -----------------------------------------------------------------------------------
-template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM>
+// USE_S: the forward pass did not store L_{t+1,t} = S L^{-T}; with P = L^{-T} L^{-1} the same quantities follow from the input
+// sub-diagonal block S (scaled by aS):  H = L_{t+1,t} L^{-1} = S P,  L_{t+1,t}^T x = L^{-1} (S^T x).  Same bytes read here (S for
+// L_{t+1,t}), d^2 doubles per node fewer written by the forward pass.
+template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM, bool USE_S = false>
 static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
+    const double* __restrict__ Gsrc = USE_S ? a.Sg : a.Gg;
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
@@ -377,7 +381,7 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     double Ln[ET], Gn[EF], yn[D];
     if (len > 1) {
         ld_node<ET>(a.Lg, R, se - 1, me, Ln);
-        ld_node<EF>(a.Gg, R, se - 1, me, Gn);
+        ld_node<EF>(Gsrc, R, se - 1, me, Gn);
         if (HAS_RHS) ld_node<D>(a.yg, R, se - 1, me, yn);
     }
     for (int s = R - 2; s >= 0; --s) {
@@ -391,22 +395,47 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
             for (int e = 0; e < D; ++e) x[e] = HAS_RHS ? yn[e] : 0.0;
             if (s > 0) {
                 ld_node<ET>(a.Lg, R, s - 1, me, Ln);
-                ld_node<EF>(a.Gg, R, s - 1, me, Gn);
+                ld_node<EF>(Gsrc, R, s - 1, me, Gn);
                 if (HAS_RHS) ld_node<D>(a.yg, R, s - 1, me, yn);
             }
             double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET];
 #pragma unroll
             for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
             tri_inverse<D>(Lt, invd, X);
-            gemm_full_tri<D>(G, X, H);            // H = L_{t+1,t} L_tt^{-1}
+            tri_t_tri<D>(X, Sig);                 // P = L^{-T} L^{-1}
+            if (USE_S) {
+                // H = aS S P
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Sig[six(k, j)], t);
+                        H[i * D + j] = a.aS * t;
+                    }
+            } else {
+                gemm_full_tri<D>(G, X, H);        // H = L_{t+1,t} L_tt^{-1}
+            }
             gemm_sym_full<D>(Sn, H, Ssub);        // S_{t+1,t+1} H
 #pragma unroll
             for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
-            tri_t_tri<D>(X, Sig);                 // L^{-T} L^{-1}
-            gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);  // - S_{t+1,t}^T H
+            gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);  // + H^T S_{t+1,t+1} H = - S_{t+1,t}^T H
             if (HAS_RHS) {
                 double t[D];
-                gemv_t<D>(G, xn, t);
+                gemv_t<D>(G, xn, t);              // G^T x_n  (USE_S: S^T x_n, still to be scaled and multiplied by L^{-1})
+                if (USE_S) {
+                    double u[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= i; ++k) acc = __builtin_fma(X[tix(i, k)], t[k], acc);
+                        u[i] = a.aS * acc;
+                    }
+#pragma unroll
+                    for (int e = 0; e < D; ++e) t[e] = u[e];
+                }
 #pragma unroll
                 for (int e = 0; e < D; ++e) x[e] -= t[e];
                 trsv_lower_t<D>(Lt, invd, x);
@@ -430,11 +459,25 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
         // S_{t0, t0-1} for the separator on the left, whose own blocks belong to lane-1
         double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF];
         ld_node<ET>(a.Lg, R, R - 1, LaneRef::of(lane - 1), Lt);
-        ld_node<EF>(a.Gg, R, R - 1, LaneRef::of(lane - 1), G);
+        ld_node<EF>(Gsrc, R, R - 1, LaneRef::of(lane - 1), G);
 #pragma unroll
         for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
         tri_inverse<D>(Lt, invd, X);
-        gemm_full_tri<D>(G, X, H);
+        if (USE_S) {
+            double Pm[ET];
+            tri_t_tri<D>(X, Pm);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Pm[six(k, j)], t);
+                    H[i * D + j] = a.aS * t;
+                }
+        } else {
+            gemm_full_tri<D>(G, X, H);
+        }
         gemm_sym_full<D>(Sn, H, Ssub);
 #pragma unroll
         for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];

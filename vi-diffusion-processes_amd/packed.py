@@ -73,11 +73,14 @@ class Plan:
         return out
 
     # -- sweeps -------------------------------------------------------------------------------
-    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False, out=None):
-        """Block Cholesky (+ forward substitution).  Returns dict(L, G, y, logdet, quad)."""
+    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False, out=None, store_G=True):
+        """Block Cholesky (+ forward substitution).  Returns dict(L, G, y, logdet, quad).  store_G=False (d <= 8) skips the
+        L_{t+1,t} output; the selected inverse then has to be taken with selinv_mom(..., S=S, aS=aS)."""
         out = {} if out is None else out
         L = out.get("L") if out.get("L") is not None else self.empty(TRI)
-        G = out.get("G") if out.get("G") is not None else self.empty(FULL)
+        G = None
+        if store_G:
+            G = out.get("G") if out.get("G") is not None else self.empty(FULL)
         y = None
         if r is not None:
             y = out.get("y") if out.get("y") is not None else self.empty(VEC)
@@ -192,8 +195,9 @@ class Plan:
         base = torch.arange(self.B, dtype=torch.int64, device=self.device).unsqueeze(1) * self.T
         return (base + ti).reshape(-1).contiguous()
 
-    def selinv_mom(self, L, G, y, want_sub=False, out=None):
-        """Selected inverse that also writes the moment array (mu, diag Sigma, diag Sigma_sub).  Returns dict(Sig, Sub, x, mom)."""
+    def selinv_mom(self, L, G, y, want_sub=False, out=None, S=None, aS=1.0):
+        """Selected inverse that also writes the moment array (mu, diag Sigma, diag Sigma_sub).  Returns dict(Sig, Sub, x, mom).
+        With G = None the factorisation was made with store_G=False and (S, aS) are its sub-diagonal input and scale."""
         out = {} if out is None else out
         Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
         Sub = None
@@ -203,8 +207,14 @@ class Plan:
         mom = out.get("mom")
         if mom is None:
             mom = torch.empty(3 * x.numel(), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.mfgm_packed_selinv_mom(self.h, -1, _ptr(L), _ptr(G), _ptr(y), _ptr(Sig), _ptr(Sub), _ptr(x), _ptr(mom),
-                                                   _ptr(self.ws), _stream()), "mfgm_packed_selinv_mom")
+        if G is None:
+            if want_sub or S is None:
+                raise ValueError("selinv_mom without L_{t+1,t} needs (S, aS) and cannot return the full cross-covariance blocks")
+            _lib.check(self.lib.mfgm_packed_selinv_mom_s(self.h, -1, _ptr(L), _ptr(S), float(aS), _ptr(y), _ptr(Sig), _ptr(x), _ptr(mom),
+                                                         _ptr(self.ws), _stream()), "mfgm_packed_selinv_mom_s")
+        else:
+            _lib.check(self.lib.mfgm_packed_selinv_mom(self.h, -1, _ptr(L), _ptr(G), _ptr(y), _ptr(Sig), _ptr(Sub), _ptr(x), _ptr(mom),
+                                                       _ptr(self.ws), _stream()), "mfgm_packed_selinv_mom")
         return dict(Sig=Sig, Sub=Sub, x=x, mom=mom)
 
     def unpack_moments(self, mom):

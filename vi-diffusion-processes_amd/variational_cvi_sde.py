@@ -150,9 +150,14 @@ class CVISitesSSM:
         if self._q is None:
             pl = self.plan
             tq = self.full_sites()
-            f = pl.factor(tq.diag, tq.sub, tq.lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=self._bufs["f"])
-            s = pl.selinv_mom(f["L"], f["G"], f["y"], want_sub=want_sub, out=self._bufs["s"])
-            self._bufs["f"].update(L=f["L"], G=f["G"], y=f["y"])
+            # without the full cross-covariances the forward sweep need not store L_{t+1,t}: the backward sweep rebuilds what it
+            # uses from theta_sub (d^2 doubles per node fewer written)
+            lean = (not want_sub) and pl.d <= 8
+            f = pl.factor(tq.diag, tq.sub, tq.lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=self._bufs["f"], store_G=not lean)
+            s = pl.selinv_mom(f["L"], f["G"], f["y"], want_sub=want_sub, out=self._bufs["s"], S=tq.sub if lean else None, aS=-1.0)
+            self._bufs["f"].update(L=f["L"], y=f["y"])
+            if f["G"] is not None:
+                self._bufs["f"]["G"] = f["G"]
             self._bufs["s"].update(Sig=s["Sig"], x=s["x"], mom=s["mom"])
             if s["Sub"] is not None:
                 self._bufs["s"]["Sub"] = s["Sub"]
