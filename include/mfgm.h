@@ -90,6 +90,10 @@ int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, con
  * variational_cvi_sde.py:167-172, 303-304 and kalman_filter.py:577. */
 int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed2, const long long* node_ids, int n,
                  double* values, int mode, double scale, void* stream);
+/* The same for a vector array and a symmetric array at the same nodes in one launch (the CVI site updates always move the
+ * linear and the diagonal-block part together, variational_cvi_sde.py:167-172, 301-317); d <= 8. */
+int mfgm_node_io_pair(const mfgm_plan* plan, double* packed_vec, double* packed_sym, const long long* node_ids, int n,
+                      double* values_vec, double* values_sym, int mode, double scale, void* stream);
 
 /* SSM parameters -> natural parameters (cD=-0.5, cS=1; ssm_gaussian_transformations.py:182-253 `ssm_to_naturals`)
  * or precision blocks (cD=1, cS=-1; state_space_model.py:431-483 `_build_precision`), all packed:

@@ -33,6 +33,8 @@ EXPORTS = {
                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_node_io": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+    "mfgm_node_io_pair": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "mfgm_packed_ssm_to_naturals": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),
     "mfgm_packed_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
                                  + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 6),

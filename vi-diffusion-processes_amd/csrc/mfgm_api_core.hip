@@ -202,6 +202,21 @@ int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed
     return 0;
 }
 
+int mfgm_node_io_pair(const mfgm_plan* plan, double* packed_vec, double* packed_sym, const long long* node_ids, int n,
+                      double* values_vec, double* values_sym, int mode, double scale, void* stream) {
+    if (!plan || !packed_vec || !packed_sym || mode < 0 || mode > 2 || n < 0) return 1;
+    if (n == 0) return 0;
+    if (!node_ids || !values_vec || !values_sym) return 1;
+    const Plan& P = plan->p;
+    if (P.wide) return 1;
+    const size_t total = (size_t)n * (P.d + P.d * P.d);
+    if (total >= (1ull << 32) || (size_t)P.B * P.T >= (1ull << 32)) return 1;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_node_io_pair, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.lv[0], P.T, P.d, packed_vec, packed_sym,
+                       node_ids, n, values_vec, values_sym, mode, scale);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
 
 }  // extern "C"
 

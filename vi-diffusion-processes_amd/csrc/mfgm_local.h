@@ -40,39 +40,56 @@ static __global__ __launch_bounds__(256) void k_lincomb(size_t n, double* out, d
 // ---- gather / scatter of a sparse list of nodes (observation times) --------------------------------------
 // node_ids[i] = b*T + t.  values: natural [n, E_nat].  mode 0: packed -> values, 1: values -> packed (set),
 // 2: packed += scale*values (and packed2 += scale*values when given).  SYM scatters read the lower triangle.
+// one element of one listed node (shared by the single-array and the paired kernels)
+MFGM_DEV void node_io_elem(const LevelDesc& lv, int T, int d, int kind, double* packed, double* packed2,
+                           const long long* __restrict__ node_ids, double* values, int mode, double scale, unsigned idx) {
+    const unsigned En = (kind == 0) ? d : d * d;
+    const unsigned i = idx / En, ne = idx - i * En;
+    // the host guarantees B * T < 2^32: 32-bit division (a 64-bit one costs more than the memory access it addresses)
+    const unsigned id = (unsigned)node_ids[i];
+    const unsigned b = id / (unsigned)T, t = id - b * (unsigned)T;
+    const unsigned p = t / lv.R, s = t - p * lv.R, lane = b * lv.P + p;
+    unsigned Ep = En, e = ne;
+    bool skip = false, zero = false;
+    if (kind >= 2) {
+        Ep = d * (d + 1) / 2;
+        const unsigned r = ne / d, c = ne - r * d;
+        if (mode == 0) {
+            if (kind == 3 && c > r) zero = true;
+            e = six(r, c);
+        } else {
+            if (c > r) skip = true;
+            e = tix(r, c > r ? r : c);
+        }
+    }
+    if (skip) return;
+    const size_t off = (((size_t)(lane >> 6) * lv.R + s) * Ep + e) * 64 + (lane & 63);
+    if (mode == 0) values[idx] = zero ? 0.0 : packed[off];
+    else if (mode == 1) packed[off] = values[idx];
+    else {
+        const double v = scale * values[idx];
+        packed[off] += v;
+        if (packed2) packed2[off] += v;
+    }
+}
+
 static __global__ __launch_bounds__(256) void k_node_io(LevelDesc lv, int T, int d, int kind, double* packed, double* packed2,
                                                 const long long* __restrict__ node_ids, int n, double* values, int mode,
                                                 double scale) {
-    const unsigned En = (kind == 0) ? d : d * d;
-    const unsigned total = (unsigned)n * En;
+    const unsigned total = (unsigned)n * ((kind == 0) ? d : d * d);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+        node_io_elem(lv, T, d, kind, packed, packed2, node_ids, values, mode, scale, idx);
+}
+
+// a vector array and a symmetric array at the same nodes in ONE launch (the site updates always move both; the two scattered
+// access streams then overlap instead of paying their latency one after the other)
+static __global__ __launch_bounds__(256) void k_node_io_pair(LevelDesc lv, int T, int d, double* packed_vec, double* packed_sym,
+                                                             const long long* __restrict__ node_ids, int n, double* values_vec,
+                                                             double* values_sym, int mode, double scale) {
+    const unsigned nv = (unsigned)n * d, total = nv + (unsigned)n * d * d;
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const unsigned i = idx / En, ne = idx - i * En;
-        // the host guarantees B * T < 2^32: 32-bit division (a 64-bit one costs more than the memory access it addresses)
-        const unsigned id = (unsigned)node_ids[i];
-        const unsigned b = id / (unsigned)T, t = id - b * (unsigned)T;
-        const unsigned p = t / lv.R, s = t - p * lv.R, lane = b * lv.P + p;
-        unsigned Ep = En, e = ne;
-        bool skip = false, zero = false;
-        if (kind >= 2) {
-            Ep = d * (d + 1) / 2;
-            const unsigned r = ne / d, c = ne - r * d;
-            if (mode == 0) {
-                if (kind == 3 && c > r) zero = true;
-                e = six(r, c);
-            } else {
-                if (c > r) skip = true;
-                e = tix(r, c > r ? r : c);
-            }
-        }
-        if (skip) continue;
-        const size_t off = (((size_t)(lane >> 6) * lv.R + s) * Ep + e) * 64 + (lane & 63);
-        if (mode == 0) values[idx] = zero ? 0.0 : packed[off];
-        else if (mode == 1) packed[off] = values[idx];
-        else {
-            const double v = scale * values[idx];
-            packed[off] += v;
-            if (packed2) packed2[off] += v;
-        }
+        if (idx < nv) node_io_elem(lv, T, d, 0, packed_vec, nullptr, node_ids, values_vec, mode, scale, idx);
+        else node_io_elem(lv, T, d, 2, packed_sym, nullptr, node_ids, values_sym, mode, scale, idx - nv);
     }
 }
 

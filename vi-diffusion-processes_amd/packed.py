@@ -136,6 +136,26 @@ class Plan:
                                          2 if accumulate else 1, float(scale), _stream()), "mfgm_node_io(scatter)")
         return packed
 
+    def gather_nodes_pair(self, packed_vec, packed_sym, node_ids, out_vec, out_sym):
+        """gather_nodes of a VEC and a SYM array at the same nodes in one launch (d <= 8), into the given buffers."""
+        if self.d > 8:
+            self.gather_nodes(VEC, packed_vec, node_ids, out=out_vec)
+            self.gather_nodes(SYM, packed_sym, node_ids, out=out_sym)
+            return out_vec, out_sym
+        _lib.check(self.lib.mfgm_node_io_pair(self.h, _ptr(packed_vec), _ptr(packed_sym), _ptr(node_ids), node_ids.numel(),
+                                              _ptr(out_vec), _ptr(out_sym), 0, 1.0, _stream()), "mfgm_node_io_pair(gather)")
+        return out_vec, out_sym
+
+    def scatter_nodes_pair(self, packed_vec, packed_sym, node_ids, values_vec, values_sym, scale=1.0):
+        """packed_vec += scale * values_vec and packed_sym += scale * values_sym at the listed nodes, in one launch (d <= 8)."""
+        values_vec, values_sym = values_vec.contiguous(), values_sym.contiguous()
+        if self.d > 8:
+            self.scatter_nodes(VEC, packed_vec, node_ids, values_vec, accumulate=True, scale=scale)
+            self.scatter_nodes(SYM, packed_sym, node_ids, values_sym, accumulate=True, scale=scale)
+            return
+        _lib.check(self.lib.mfgm_node_io_pair(self.h, _ptr(packed_vec), _ptr(packed_sym), _ptr(node_ids), node_ids.numel(),
+                                              _ptr(values_vec), _ptr(values_sym), 2, float(scale), _stream()), "mfgm_node_io_pair(scatter)")
+
     def ssm_to_naturals(self, A, off, chol, precision=False, want_logdet=False, out=None):
         """Packed SSM parameters -> naturals (or precision blocks).  Returns dict(lin, diag, sub, sumlogchol)."""
         out = {} if out is None else out

@@ -180,8 +180,7 @@ class CVISitesSSM:
         q = self._refresh()
         # persistent buffers, updated in place: the state that crosses iterations keeps its addresses (a captured HIP graph
         # of one iteration can then be replayed)
-        self.plan.gather_nodes(VEC, q["mu"], self.obs_node_ids, out=self.fx_mus_obs)
-        self.plan.gather_nodes(SYM, q["Sig"], self.obs_node_ids, out=self.fx_covs_obs)
+        self.plan.gather_nodes_pair(q["mu"], q["Sig"], self.obs_node_ids, self.fx_mus_obs, self.fx_covs_obs)
         self._obs_fresh = True
 
     @property
@@ -210,8 +209,7 @@ class CVISitesSSM:
         new1 = (1 - lr) * self.data_nat1 + lr * g1
         new2 = (1 - lr) * self.data_nat2 + lr * g2
         tq = self.full_sites()
-        self.plan.scatter_nodes(VEC, tq.lin, self.obs_node_ids, new1 - self.data_nat1, accumulate=True)
-        self.plan.scatter_nodes(SYM, tq.diag, self.obs_node_ids, new2 - self.data_nat2, accumulate=True)
+        self.plan.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, new1 - self.data_nat1, new2 - self.data_nat2)
         self.data_nat1.copy_(new1)
         self.data_nat2.copy_(new2)
         self._q = None
@@ -235,8 +233,7 @@ class CVISitesSSM:
         pl, tq, tp = self.plan, self.full_sites(), self._theta_p
         for qq, pp in ((tq.lin, tp.lin), (tq.diag, tp.diag), (tq.sub, tp.sub)):
             pl.lincomb(qq, 1.0 - lr, qq, lr, pp)               # theta_q += lr (theta_p - theta_q)
-        pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=lr)
-        pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=lr)
+        pl.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, self.data_nat1, self.data_nat2, scale=lr)
         self._q = None
         self._obs_fresh = False
         self._started = True
@@ -432,8 +429,7 @@ class CVISitesSDE(CVISitesSSM):
         pl, tq = self.plan, self.full_sites()
         self._sde_prm.lr = float(lr)
         pl.sde_lean(self._sde_prm, q["mom"], mode=3, theta_q=(tq.lin, tq.diag, tq.sub))
-        pl.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True, scale=lr)
-        pl.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self.data_nat2, accumulate=True, scale=lr)
+        pl.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, self.data_nat1, self.data_nat2, scale=lr)
         self._q = None
         self._obs_fresh = False
         self._started = True
