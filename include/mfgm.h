@@ -40,7 +40,7 @@ typedef struct mfgm_plan mfgm_plan;
 #define MFGM_TRI 3  /* [d, d] lower-triangular: upper triangle written as zero       */
 
 /* Partition plan for B chains of T nodes with d x d blocks.  R0 = nodes per lane segment at the finest
- * level (0 = choose so that about 64 Ki lanes exist), Rup = segment length of the coarser levels (0 = 8; 4 for d > 8).
+ * level (0 = choose so that about 64 Ki lanes exist), Rup = segment length of the coarser levels (0 = 4).
  * Supported d: 1..32.  d <= 8 runs the lane-per-segment kernels on the packed wave-tiled layout; 8 < d <= 32 runs the
  * wavefront-per-segment ("wide") kernels, for which the "packed" arrays are simply the natural [B, T, d*d] / [B, T, d]
  * arrays (mfgm_pack / mfgm_unpack then only symmetrise / zero-fill) and R0 = 0 chooses about 8 Ki segments.  The wide

@@ -31,9 +31,9 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
     memset(&P, 0, sizeof(P));
     P.B = B; P.T = T; P.d = d;
     P.wide = (d > 8);
-    // measured best on MI355X for the coarse levels (tools/sweep_partition.sh, tools/sweep_wide.sh): the wide kernels' steps are
-    // ~10x longer, so their coarse levels are kept shallower per level
-    if (Rup <= 1) Rup = (d > 8) ? 4 : 8;
+    // measured best on MI355X for the coarse levels (tools/sweep_coarse.sh, tools/sweep_wide.sh): short segments above level 0 --
+    // those levels are latency-bound (few lanes, dependent steps), so their depth counts, not their traffic
+    if (Rup <= 1) Rup = 4;
     if (const char* e = getenv("MFGM_RUP")) { int v = atoi(e); if (v > 1) Rup = v; }
     if (R0 <= 0) {
         if (const char* e = getenv("MFGM_R0")) R0 = atoi(e);
@@ -45,9 +45,8 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
         R0 = (int)std::min<long long>(std::max<long long>(r, 8), 1 << 20);
     }
     int n = T, l = 0;
-    // chains this short are swept sequentially by one lane (narrow) or one wavefront (wide: a step costs ~10 us there, so
-    // the sequential top is kept shorter)
-    int top = P.wide ? 12 : 48;
+    // chains this short are swept sequentially by one lane (narrow) or one wavefront (wide)
+    int top = 12;
     if (const char* e = getenv("MFGM_TOP")) { int v = atoi(e); if (v > 1) top = v; }
     while (true) {
         int R = (l == 0) ? R0 : Rup;
