@@ -188,38 +188,68 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: level-0 backward (selected inverse) sweep, timed alone ----------
+        # ---- roofline: every level-0 sweep kernel of the step timed alone; the one with the largest share of the step is reported --
         lib = vidp_amd._lib.load()
         from vidp_amd.packed import _ptr, _stream
+        import ctypes
         f, s = model._bufs["f"], model._bufs["s"]
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        reps = 20
+        tq, sp = model.full_sites(), getattr(model, "_theta_spare", None)
+        fused = sp is not None
+        ET, EF = d * (d + 1) // 2, d * d
+        null = ctypes.c_void_p(0)
 
-        tq = model.full_sites()
+        def timed(fn, reps=20):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            fn()
+            torch.cuda.synchronize()
+            ev[0].record()   # torch's current stream is the stream the kernels are launched on (_stream())
+            for _ in range(reps):
+                fn()
+            ev[1].record()
+            torch.cuda.synchronize()
+            return ev[0].elapsed_time(ev[1]) / reps
 
-        def one():
-            # the model's own level-0 backward launch: L_{t+1,t} is not stored, the kernel reads theta_sub (same byte count)
-            rc = lib.mfgm_packed_selinv_mom_s(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), _ptr(s["Sig"]),
-                                              _ptr(s["x"]), _ptr(s["mom"]), _ptr(plan.ws), _stream())
-            assert rc == 0
-        one()
-        torch.cuda.synchronize()
-        ev[0].record()   # torch's current stream is the stream the kernel is launched on (_stream())
-        for _ in range(reps):
-            one()
-        ev[1].record()
-        torch.cuda.synchronize()
-        k_ms = ev[0].elapsed_time(ev[1]) / reps
-        ET = d * (d + 1) // 2
-        # read L, theta_sub (in place of L_sub), y; write Sigma (packed), mu, and the 3d moment array (mu, diag Sigma, diag Sigma_sub)
-        bytes_per_node = 8 * ((ET + d * d + d) + (ET + d + 3 * d))
-        alg_bytes = bytes_per_node * B * T
-        ach = alg_bytes / (k_ms * 1e-3) / 1e9
-        kname = f"void mfgm::k_backward<{d}, true, true, false, true, true>(mfgm::SweepArgs)"
-        out["roofline"] = {"bound": "hbm", "kernel": kname + " (level 0: selected inverse + back-substitution)", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic(kname, B, T, d),
-                           "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
+        def stage(st):
+            # level-0 reduce (0) / forward (1) of the model's own factorisation (L_{t+1,t} not stored: G = NULL)
+            assert lib.mfgm_packed_factor_stage(plan.h, st, 0, _ptr(tq.diag), _ptr(tq.sub), _ptr(tq.lin), -2.0, -1.0, 1.0, _ptr(f["L"]),
+                                                null, _ptr(f["y"]), _ptr(plan.ws), _ptr(plan.info), _stream()) == 0
+
+        def backward():
+            # level-0 backward of the refresh before the ELBO: reads theta_sub in place of L_{t+1,t} (same byte count)
+            assert lib.mfgm_packed_selinv_mom_s(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), _ptr(s["Sig"]), _ptr(s["x"]),
+                                                _ptr(s["mom"]), _ptr(plan.ws), _stream()) == 0
+
+        def girsanov():
+            # level-0 backward fused with the Girsanov-site update; writes the spare theta_q buffers (the model's state is untouched)
+            assert lib.mfgm_packed_selinv_girsanov(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), ctypes.byref(model._sde_prm),
+                                                   _ptr(tq.lin), _ptr(tq.diag), _ptr(sp.lin), _ptr(sp.diag), _ptr(sp.sub),
+                                                   _ptr(plan.ws), _stream()) == 0
+
+        # (kernel, launches per step, algorithmic doubles per node read + written, launcher)
+        cand = [
+            (f"void mfgm::k_forward<{d}, true, false, true>(mfgm::SweepArgs)", 2, (ET + EF + d) + (ET + d), lambda: stage(1),
+             "level 0 forward: block Cholesky + forward substitution; reads theta_q, writes L and y"),
+            (f"void mfgm::k_reduce<{d}, true, false>(mfgm::SweepArgs)", 2, (ET + EF + d), lambda: stage(0),
+             "level 0 reduce: segment elimination; reads theta_q"),
+            (f"void mfgm::k_backward<{d}, true, true, false, true, true>(mfgm::SweepArgs)", 1 if fused else 2,
+             (ET + EF + d) + (ET + d + 3 * d), backward,
+             "level 0 backward: selected inverse + back-substitution; reads L, theta_sub, y, writes Sigma, mu, moments"),
+        ]
+        if fused:
+            cand.append((f"void mfgm::k_backward_girsanov<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::GirsanovArgs)", 1,
+                         (ET + EF + d) + (d + ET) + (d + ET + EF), girsanov,
+                         "level 0 backward fused with the Girsanov-site update; reads L, y, theta_q, writes the new theta_q"))
+        rows = []
+        for kname, per_step, doubles, fn, what in cand:
+            k_ms = timed(fn)
+            alg_bytes = 8 * doubles * B * T
+            ach = alg_bytes / (k_ms * 1e-3) / 1e9
+            rows.append({"bound": "hbm", "kernel": f"{kname} ({what})", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(kname, B, T, d), "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": per_step,
+                         "share_of_step": per_step * k_ms / ms_per_step})
+        rows.sort(key=lambda r: -r["share_of_step"])
+        out["roofline"] = dict(rows[0], other_kernels=rows[1:])
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise, first_elbo[0].cpu().numpy())

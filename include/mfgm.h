@@ -159,6 +159,16 @@ int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* 
 int mfgm_packed_selinv_mom_s(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
                              double* Sig, double* x, double* mom, void* ws, void* stream);
 
+/* Backward sweep of a G = NULL factorisation fused with the Girsanov-site update of CVI-DP (variational_cvi_sde.py:279-299, the
+ * update mfgm_packed_sde_lean mode 3 makes from the moment array): instead of the marginals it writes
+ *   (n1, nd, ns) = (1 - lr) (q1, qd, S) + lr theta~(mu, diag Sigma, diag Sigma_sub),      lr = prm->lr,
+ * out of place (n1 != q1, nd != qd, ns != S).  (qd, S, q1) with scales (-2, aS = -1, 1) must be what mfgm_packed_factor was given.
+ * Cubic drifts (prm->kind == 0), d <= 8, plans with at least two levels; returns 1 otherwise (callers then run
+ * mfgm_packed_selinv_mom_s + mfgm_packed_sde_lean).  only_level as in mfgm_packed_selinv_mom. */
+int mfgm_packed_selinv_girsanov(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
+                                const mfgm_sde_params* prm, const double* q1, const double* qd, double* n1, double* nd, double* ns,
+                                void* ws, void* stream);
+
 /* CVI-DP on the moment array: KL[q||p] = -H[q] - E_q[log p] where E_q[log p] of a per-dimension cubic drift with diagonal
  * diffusion depends on q only through mom, so d KL / d eta = theta_q - theta~(mom) with explicit "effective prior naturals"
  * theta~ (csrc/mfgm_sde.h) and no d x d factorisation:

@@ -943,3 +943,43 @@ def test_variational_markov_gp_stabilized(amd, rng):
     assert clipped                                   # the scenario does exercise the clipping
     ssm_A = np.abs(host(plan.unpack(amd.FULL, g._ssm_bufs[0], T - 1))).max()
     assert ssm_A <= 1.0 + 1e-12                   # the clipped transitions
+
+
+@pytest.mark.parametrize("d,kind,B,T,R0", [(1, "dw", 3, 57, 8), (2, "dw", 2, 61, 8), (3, "ou", 2, 64, 4), (6, "dw", 3, 131, 8), (6, "dw", 1, 33, 16)])
+def test_fused_girsanov_update_equals_two_kernel_update(amd, rng, d, kind, B, T, R0):
+    """
+    update_girsanov_sites inside the backward sweep (mfgm_packed_selinv_girsanov) against the refresh + moment-array update
+    (mfgm_packed_selinv_mom_s + mfgm_packed_sde_lean mode 3) from the same state: ragged last segments (one node, several
+    nodes), several trajectories, two consecutive steps (the second one reads the swapped buffers).
+    """
+    import torch
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    dt = 0.02
+    q = torch.diag(torch.from_numpy(0.5 + rng.random(d)))
+    grid = np.arange(T) * dt
+    idx = np.sort(rng.choice(np.arange(1, T), size=7, replace=False))
+    y = np.sign(rng.normal(size=(B, 7, d))) + 0.2 * rng.normal(size=(B, 7, d))
+    init = (0.3 * rng.normal(size=d), 0.5 * np.eye(d) + 0.1 * np.ones((d, d)))
+
+    def run(fused):
+        sde = gsde.OrnsteinUhlenbeckSDE(1.2, q) if kind == "ou" else gsde.DoubleWellSDE(q)
+        m = CVISitesSDE(sde, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(0.3 * np.eye(d))), prior_initial_state=init,
+                        plan=amd.Plan(B, T, d, R0=R0, Rup=3))
+        m.fused_girsanov = fused
+        out = []
+        for lr_d, lr_g in ((0.5, 0.3), (0.3, 0.15)):
+            m.update_data_sites(lr_d)
+            m.update_girsanov_sites(lr_g)
+            tq = m.full_sites()
+            pl = m.plan
+            out.append((host(pl.unpack(amd.VEC, tq.lin)), host(pl.unpack(amd.SYM, tq.diag)), host(pl.unpack(amd.FULL, tq.sub, T - 1)),
+                        host(m.classic_elbo_per_trajectory())))
+        return out
+
+    a, b = run(True), run(False)
+    for sa, sb in zip(a, b):
+        for xa, xb in zip(sa, sb):
+            assert np.isfinite(xa).all()
+            np.testing.assert_allclose(xa, xb, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(xb).max()))

@@ -66,8 +66,9 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
     P.seg_hi = P.lv[0].P;
     size_t off = 0;
     auto take = [&](size_t nd) { size_t o = off; off += (nd + 63) / 64 * 64; return o; };
-    // per-segment partial sums; the wide local kernels keep one partial per node
-    P.off_part[0] = take(2 * (P.wide ? std::max<size_t>(P.lv[0].Lpad, (size_t)B * T) : (size_t)P.lv[0].Lpad));
+    // per-segment partial sums (narrow: also the d-vector hand-over of the fused Girsanov sweep); the wide local kernels keep one
+    // partial per node
+    P.off_part[0] = take(P.wide ? 2 * std::max<size_t>(P.lv[0].Lpad, (size_t)B * T) : (size_t)std::max(2, d) * P.lv[0].Lpad);
     for (int i = 1; i < P.nlevels; ++i) {
         const LevelDesc& lv = P.lv[i];
         P.off_Dhat[i] = take(level_elems(P, lv, 2));

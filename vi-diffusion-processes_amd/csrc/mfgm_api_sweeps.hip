@@ -1,6 +1,7 @@
 // Multi-level drivers of the lane-per-segment sweeps (d <= 8): reduce / forward / backward over the partition levels.
 #include "mfgm_internal.h"
 #include "mfgm_sweeps.h"
+#include "mfgm_girsanov.h"
 
 using namespace mfgm;
 
@@ -160,6 +161,37 @@ int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double*
     return 0;
 }
 
+template <int D>
+int selinv_girsanov_impl(const Plan& P, const double* Lg, const double* Sg, double aS, const double* yg, const SdeParams& pr,
+                         const GirsanovArgs& g, double* ws, hipStream_t st, int only_level) {
+    // coarser levels exactly as in a plain selected inverse, then the fused level-0 sweep
+    const int K = P.nlevels - 1;
+    for (int l = K; l >= 1; --l) {
+        if (only_level >= 0 && only_level != l) continue;
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.lv = P.lv[l];
+        bind_level_inputs(P, l, ws, a);
+        if (l < K) bind_up(P, l, ws, a);
+        int rc = launch_backward<D>(a, true, l < K, false, st);
+        if (rc) return rc;
+    }
+    if (only_level > 0) return 0;
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lv = P.lv[0];
+    a.Lg = const_cast<double*>(Lg); a.yg = const_cast<double*>(yg); a.Sg = Sg; a.aS = aS;
+    bind_up(P, 0, ws, a);
+    GirsanovArgs ga = g;
+    ga.fix = ws + P.off_part[0];
+    dim3 grid(a.lv.Lpad / 64), block(64);
+    hipLaunchKernelGGL((k_backward_girsanov<D>), grid, block, 0, st, a, pr, ga);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_girsanov_fixup<D>), grid, block, 0, st, a.lv, ga);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -196,8 +228,9 @@ int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, 
 int mfgm_packed_factor_stage(const mfgm_plan* plan, int stage, int level, const double* D, const double* S, const double* r,
                              double aD, double aS, double aR, double* L, double* G, double* y, void* ws, int* info,
                              void* stream) {
-    if (!plan || !D || !L || !G || !info || stage < 0 || stage > 1) return 1;
+    if (!plan || !D || !L || !info || stage < 0 || stage > 1) return 1;        // G may be NULL as in mfgm_packed_factor
     const Plan& P = plan->p;
+    if (P.wide) return 1;
     if (level < 0 || level >= P.nlevels || (stage == 0 && level >= P.nlevels - 1)) return 1;
     if ((r != nullptr) != (y != nullptr)) return 1;
     hipStream_t st = (hipStream_t)stream;
@@ -221,6 +254,21 @@ int mfgm_packed_selinv_mom_s(const mfgm_plan* plan, int only_level, const double
     if (P.wide || only_level >= P.nlevels) return 1;
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (selinv_impl<DD>(P, L, nullptr, y, Sig, nullptr, x, (double*)ws, st, only_level, mom, S, aS)));
+}
+
+int mfgm_packed_selinv_girsanov(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
+                                const mfgm_sde_params* prm, const double* q1, const double* qd, double* n1, double* nd, double* ns,
+                                void* ws, void* stream) {
+    if (!plan || !L || !S || !y || !prm || !q1 || !qd || !n1 || !nd || !ns || !ws) return 1;
+    if (n1 == q1 || nd == qd || ns == S) return 1;            // the update is out of place (see mfgm_girsanov.h)
+    const Plan& P = plan->p;
+    if (P.wide || P.nlevels < 2 || only_level >= P.nlevels || prm->kind != 0) return 1;
+    static_assert(sizeof(mfgm_sde_params) == sizeof(mfgm::SdeParams), "public and internal SDE parameter structs must match");
+    SdeParams pr;
+    memcpy(&pr, prm, sizeof(pr));
+    GirsanovArgs g{q1, qd, n1, nd, ns, nullptr};
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_girsanov_impl<DD>(P, L, S, aS, y, pr, g, (double*)ws, st, only_level)));
 }
 
 int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* L, const double* G, const double* y, double* Sig,

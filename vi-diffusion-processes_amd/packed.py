@@ -251,6 +251,14 @@ class Plan:
                                                  _ptr(q[1]), _ptr(q[2]), _ptr(self.ws), _stream()), "mfgm_packed_sde_lean")
         return out
 
+    def selinv_girsanov(self, L, S, aS, y, prm, theta_q, out, only_level=-1):
+        """Backward sweep of a store_G=False factorisation fused with the Girsanov-site update: `out` = (lin, diag, sub) receives
+        (1 - lr) theta_q + lr theta~ (out of place; theta_q = (lin, diag, sub) with sub = S)."""
+        _lib.check(self.lib.mfgm_packed_selinv_girsanov(self.h, int(only_level), _ptr(L), _ptr(S), float(aS), _ptr(y), ctypes.byref(prm),
+                                                        _ptr(theta_q[0]), _ptr(theta_q[1]), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                                        _ptr(self.ws), _stream()), "mfgm_packed_selinv_girsanov")
+        return out
+
     def check_info(self):
         """Raise ArithmeticError if a pivot block was not positive definite (synchronises)."""
         if int(self.info.item()) != 0:

@@ -10,6 +10,8 @@ Same method names as the reference (`full_sites`, `dist_q`, `update_data_sites`,
   * all per-time-step state (prior naturals, Girsanov sites, posterior naturals, marginals) lives in the
     packed device layout and is refreshed once per site update, not once per property access.
 """
+import os
+
 import torch
 
 from ._lib import FULL, SYM, VEC
@@ -329,6 +331,8 @@ class CVISitesSDE(CVISitesSSM):
         self._theta_q_valid = True
         self._q = q_valid
 
+    # update_girsanov_sites inside the backward sweep when no refresh is cached (VIDP_FUSED_GIRSANOV=0: always refresh + update)
+    fused_girsanov = os.environ.get("VIDP_FUSED_GIRSANOV", "1") != "0"
     _need_sub = False    # the closed-form SDE KL needs only (mu, diag Sigma, diag Sigma_sub): the moment array
 
     def KL_q_p(self):
@@ -425,10 +429,22 @@ class CVISitesSDE(CVISitesSSM):
 
     def update_girsanov_sites(self, lr: float):
         """Fused: g <- g + lr (scatter(data) - dKL/d eta), theta_q moves by the same increment (variational_cvi_sde.py:279-299)."""
-        q = self._refresh()
         pl, tq = self.plan, self.full_sites()
         self._sde_prm.lr = float(lr)
-        pl.sde_lean(self._sde_prm, q["mom"], mode=3, theta_q=(tq.lin, tq.diag, tq.sub))
+        if self._q is None and self.fused_girsanov and pl.d <= 8 and pl.nlevels >= 2 and self._sde_prm.kind == 0:
+            # no refresh of these sites is cached: the backward sweep of the refresh makes the update itself, without ever
+            # writing the marginals (mfgm_girsanov.h); theta_q moves to the spare buffer
+            f = pl.factor(tq.diag, tq.sub, tq.lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False, out=self._bufs["f"], store_G=False)
+            self._bufs["f"].update(L=f["L"], y=f["y"])
+            if getattr(self, "_theta_spare", None) is None:
+                self._theta_spare = PackedBTDNat(pl.zeros(VEC), pl.zeros(SYM), pl.zeros(FULL))
+            sp = self._theta_spare
+            pl.selinv_girsanov(f["L"], tq.sub, -1.0, f["y"], self._sde_prm, (tq.lin, tq.diag, tq.sub), (sp.lin, sp.diag, sp.sub))
+            self._theta_q, self._theta_spare = sp, tq
+            tq = sp
+        else:
+            q = self._refresh()
+            pl.sde_lean(self._sde_prm, q["mom"], mode=3, theta_q=(tq.lin, tq.diag, tq.sub))
         pl.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, self.data_nat1, self.data_nat2, scale=lr)
         self._q = None
         self._obs_fresh = False
