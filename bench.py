@@ -197,6 +197,7 @@ def main():
         fused = sp is not None
         ET, EF = d * (d + 1) // 2, d * d
         null = ctypes.c_void_p(0)
+        klbuf = torch.empty(B, dtype=torch.float64, device=device)
 
         def timed(fn, reps=20):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -215,9 +216,14 @@ def main():
                                                 null, _ptr(f["y"]), _ptr(plan.ws), _ptr(plan.info), _stream()) == 0
 
         def backward():
-            # level-0 backward of the refresh before the ELBO: reads theta_sub in place of L_{t+1,t} (same byte count)
-            assert lib.mfgm_packed_selinv_mom_s(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), _ptr(s["Sig"]), _ptr(s["x"]),
-                                                _ptr(s["mom"]), _ptr(plan.ws), _stream()) == 0
+            # level-0 backward of the refresh before the ELBO: reads theta_sub in place of L_{t+1,t}; fused: the KL sum is taken in
+            # the sweep and no moment array is written
+            if fused:
+                assert lib.mfgm_packed_selinv_kl(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), ctypes.byref(model._sde_prm),
+                                                 _ptr(s["Sig"]), _ptr(s["x"]), _ptr(klbuf), _ptr(plan.ws), _stream()) == 0
+            else:
+                assert lib.mfgm_packed_selinv_mom_s(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), _ptr(s["Sig"]), _ptr(s["x"]),
+                                                    _ptr(s["mom"]), _ptr(plan.ws), _stream()) == 0
 
         def girsanov():
             # level-0 backward fused with the Girsanov-site update; writes the spare theta_q buffers (the model's state is untouched)
@@ -231,9 +237,10 @@ def main():
              "level 0 forward: block Cholesky + forward substitution; reads theta_q, writes L and y"),
             (f"void mfgm::k_reduce<{d}, true, false>(mfgm::SweepArgs)", 2, (ET + EF + d), lambda: stage(0),
              "level 0 reduce: segment elimination; reads theta_q"),
-            (f"void mfgm::k_backward<{d}, true, true, false, true, true>(mfgm::SweepArgs)", 1 if fused else 2,
-             (ET + EF + d) + (ET + d + 3 * d), backward,
-             "level 0 backward: selected inverse + back-substitution; reads L, theta_sub, y, writes Sigma, mu, moments"),
+            ((f"void mfgm::k_backward_kl<{d}>(mfgm::SweepArgs, mfgm::SdeParams)", 1, (ET + EF + d) + (ET + d), backward,
+              "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, theta_sub, y, writes Sigma, mu") if fused else
+             (f"void mfgm::k_backward<{d}, true, true, false, true, true>(mfgm::SweepArgs)", 2, (ET + EF + d) + (ET + d + 3 * d), backward,
+              "level 0 backward: selected inverse + back-substitution; reads L, theta_sub, y, writes Sigma, mu, moments")),
         ]
         if fused:
             cand.append((f"void mfgm::k_backward_girsanov<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::GirsanovArgs)", 1,

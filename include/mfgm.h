@@ -169,6 +169,12 @@ int mfgm_packed_selinv_girsanov(const mfgm_plan* plan, int only_level, const dou
                                 const mfgm_sde_params* prm, const double* q1, const double* qd, double* n1, double* nd, double* ns,
                                 void* ws, void* stream);
 
+/* Backward sweep of a G = NULL factorisation that returns, next to the marginals (Sig, x), what mfgm_packed_sde_lean mode 0 would
+ * compute from the moment array: kl_part [B], to which the caller adds log|L_q| - T d / 2 (variational_cvi_sde.py:446-486).  The
+ * moment array is never written.  Same restrictions and fallback as mfgm_packed_selinv_girsanov. */
+int mfgm_packed_selinv_kl(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
+                          const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, void* ws, void* stream);
+
 /* CVI-DP on the moment array: KL[q||p] = -H[q] - E_q[log p] where E_q[log p] of a per-dimension cubic drift with diagonal
  * diffusion depends on q only through mom, so d KL / d eta = theta_q - theta~(mom) with explicit "effective prior naturals"
  * theta~ (csrc/mfgm_sde.h) and no d x d factorisation:

@@ -51,6 +51,8 @@ EXPORTS = {
     "mfgm_packed_selinv_mom_s": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
                                  + [ctypes.c_void_p] * 6),
     "mfgm_packed_sde_lean": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9),
+    "mfgm_packed_selinv_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+                              + [ctypes.c_void_p] * 7),
     "mfgm_packed_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
                                     + [ctypes.c_void_p] * 9),
     "mfgm_natural_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),

@@ -192,6 +192,35 @@ int selinv_girsanov_impl(const Plan& P, const double* Lg, const double* Sg, doub
     return 0;
 }
 
+template <int D>
+int selinv_kl_impl(const Plan& P, const double* Lg, const double* Sg, double aS, const double* yg, const SdeParams& pr, double* Sig,
+                   double* x, double* kl, double* ws, hipStream_t st, int only_level) {
+    const int K = P.nlevels - 1;
+    for (int l = K; l >= 1; --l) {
+        if (only_level >= 0 && only_level != l) continue;
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.lv = P.lv[l];
+        bind_level_inputs(P, l, ws, a);
+        if (l < K) bind_up(P, l, ws, a);
+        int rc = launch_backward<D>(a, true, l < K, false, st);
+        if (rc) return rc;
+    }
+    if (only_level > 0) return 0;
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lv = P.lv[0];
+    a.Lg = const_cast<double*>(Lg); a.yg = const_cast<double*>(yg); a.Sg = Sg; a.aS = aS;
+    a.Sigg = Sig; a.mug = x;
+    a.part = ws + P.off_part[0];
+    bind_up(P, 0, ws, a);
+    hipLaunchKernelGGL((k_backward_kl<D>), dim3(a.lv.Lpad / 64), dim3(64), 0, st, a, pr);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, a.part, a.lv.P, 0, kl, (double*)nullptr);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -269,6 +298,17 @@ int mfgm_packed_selinv_girsanov(const mfgm_plan* plan, int only_level, const dou
     GirsanovArgs g{q1, qd, n1, nd, ns, nullptr};
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (selinv_girsanov_impl<DD>(P, L, S, aS, y, pr, g, (double*)ws, st, only_level)));
+}
+
+int mfgm_packed_selinv_kl(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
+                          const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, void* ws, void* stream) {
+    if (!plan || !L || !S || !y || !prm || !Sig || !x || !kl_part || !ws) return 1;
+    const Plan& P = plan->p;
+    if (P.wide || P.nlevels < 2 || only_level >= P.nlevels || prm->kind != 0) return 1;
+    SdeParams pr;
+    memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (selinv_kl_impl<DD>(P, L, S, aS, y, pr, Sig, x, kl_part, (double*)ws, st, only_level)));
 }
 
 int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* L, const double* G, const double* y, double* Sig,

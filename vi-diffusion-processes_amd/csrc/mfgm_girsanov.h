@@ -275,6 +275,165 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov(SweepArgs a, Sd
     girsanov_store_lin<D>(pr, g, R, 0, me, pend, wprev);
 }
 
+// ---- backward sweep that also accumulates E_q[log p] of the SDE prior ----------------------------------------------------------
+// One transition's share of the moment-array KL (k_sde_lean MODE 0): 1/2 sum_i W_i [v' + m'^2 - 2 (J c + ubar m') + V + ubar^2]
+// + 1/2 logdet Qp, from (m, v, c) of the node and (m', v') of its successor.
+template <int D>
+MFGM_DEV double kl_transition(const SdeParams& pr, const double (&m)[D], const double (&v)[D], const double (&c)[D],
+                              const double (&mn)[D], const double (&vn)[D]) {
+    double acc = 0.5 * pr.logdetQp;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double W = pr.W[i], al = pr.alpha[i], be = pr.beta[i];
+        asm volatile("" : "+s"(W), "+s"(al), "+s"(be));      // see girsanov_node
+        const double mi = m[i], vi = v[i], m2 = mi * mi, a2 = m2 + vi;
+        const double ub = al * mi - be * mi * (m2 + 3.0 * vi);
+        const double J = al - 3.0 * be * a2;
+        const double V = al * al * vi - 6.0 * al * be * vi * a2 + be * be * vi * (9.0 * m2 * m2 + 36.0 * m2 * vi + 15.0 * vi * vi);
+        acc += 0.5 * W * (vn[i] + mn[i] * mn[i] - 2.0 * (J * c[i] + ub * mn[i]) + V + ub * ub);
+    }
+    return acc;
+}
+
+// Level-0 backward sweep of the refresh before the ELBO: marginals (Sigma_tt, mu) as k_backward's USE_S variant, and, instead of
+// the moment array that k_sde_lean MODE 0 would re-read, the per-lane partial of that kernel's sum directly (part[lane]).
+template <int D>
+static __global__ __launch_bounds__(64) void k_backward_kl(SweepArgs a, SdeParams pr) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, n - p * R);
+    const int se = len - 1;
+    const int uP = a.up.P, uR = a.up.R;
+    double acc = 0.0;
+
+    double Sn[ET], xn[D];
+    {
+        const int ul = b * uP + p / uR, us = p % uR;
+        ld_node<ET>(a.uSig, uR, us, LaneRef::of(ul), Sn);
+        ld_node<D>(a.umu, uR, us, LaneRef::of(ul), xn);
+    }
+    st_node<ET>(a.Sigg, R, se, me, Sn);
+    st_node<D>(a.mug, R, se, me, xn);
+
+    double Ln[ET], Gn[EF], yn[D];
+    if (len > 1) {
+        ld_node<ET>(a.Lg, R, se - 1, me, Ln);
+        ld_node<EF>(a.Sg, R, se - 1, me, Gn);
+        ld_node<D>(a.yg, R, se - 1, me, yn);
+    }
+    for (int s = R - 2; s >= 0; --s) {
+        if (s < len - 1) {
+            double Lt[ET], G[EF], x[D];
+#pragma unroll
+            for (int e = 0; e < ET; ++e) Lt[e] = Ln[e];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) G[e] = Gn[e];
+#pragma unroll
+            for (int e = 0; e < D; ++e) x[e] = yn[e];
+            if (s > 0) {
+                ld_node<ET>(a.Lg, R, s - 1, me, Ln);
+                ld_node<EF>(a.Sg, R, s - 1, me, Gn);
+                ld_node<D>(a.yg, R, s - 1, me, yn);
+            }
+            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET];
+#pragma unroll
+            for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
+            tri_inverse<D>(Lt, invd, X);
+            tri_t_tri<D>(X, Sig);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Sig[six(k, j)], t);
+                    H[i * D + j] = a.aS * t;
+                }
+            double tg[D];
+            gemv_t<D>(G, xn, tg);
+            gemm_sym_full<D>(Sn, H, Ssub);
+#pragma unroll
+            for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
+            gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);
+            {
+                double u[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k <= i; ++k) t = __builtin_fma(X[tix(i, k)], tg[k], t);
+                    u[i] = a.aS * t;
+                }
+#pragma unroll
+                for (int e = 0; e < D; ++e) x[e] -= u[e];
+                trsv_lower_t<D>(Lt, invd, x);
+            }
+            st_node<D>(a.mug, R, s, me, x);
+            st_node<ET>(a.Sigg, R, s, me, Sig);
+            double v[D], c[D], vn[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { v[i] = Sig[tix(i, i)]; c[i] = Ssub[i * D + i]; vn[i] = Sn[tix(i, i)]; }
+            acc += kl_transition<D>(pr, x, v, c, xn, vn);
+#pragma unroll
+            for (int i = 0; i < D; ++i) xn[i] = x[i];
+#pragma unroll
+            for (int e = 0; e < ET; ++e) Sn[e] = Sig[e];
+        }
+    }
+    if (p > 0) {
+        // the transition out of the separator on the left (its own moments come from the coarser level)
+        const LaneRef left = LaneRef::of(lane - 1);
+        double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF], Pm[ET];
+        ld_node<ET>(a.Lg, R, R - 1, left, Lt);
+        ld_node<EF>(a.Sg, R, R - 1, left, G);
+#pragma unroll
+        for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
+        tri_inverse<D>(Lt, invd, X);
+        tri_t_tri<D>(X, Pm);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Pm[six(k, j)], t);
+                H[i * D + j] = a.aS * t;
+            }
+        gemm_sym_full<D>(Sn, H, Ssub);
+        double m[D], v[D], c[D], vn[D];
+        {
+            const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
+            const LaneRef uw = LaneRef::of(ul);
+            ld_node<D>(a.umu, uR, us, uw, m);
+            const double* ps = a.uSig + ((size_t)uw.tile * uR + us) * (size_t)(ET * 64);
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i] = ps[tix(i, i) * 64 + uw.l];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) { c[i] = -Ssub[i * D + i]; vn[i] = Sn[tix(i, i)]; }
+        acc += kl_transition<D>(pr, m, v, c, xn, vn);
+    } else {
+        // node 0: 1/2 [ tr(P0^{-1} Sigma_0) + (m0 - mu0)^T P0^{-1} (m0 - mu0) + logdet P0 ]
+        double tr = 0.0, mh = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double pm = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                pm = __builtin_fma(pr.P0inv[six(i, j)], xn[j] - pr.mu0[j], pm);
+                tr = __builtin_fma(pr.P0inv[six(i, j)], Sn[six(i, j)], tr);
+            }
+            mh = __builtin_fma(pm, xn[i] - pr.mu0[i], mh);
+        }
+        acc += 0.5 * (tr + mh + pr.logdetP0);
+    }
+    a.part[lane] = acc;
+}
+
 // theta_lin of every separator += the hand-over of the segment's last interior node
 template <int D>
 static __global__ __launch_bounds__(64) void k_girsanov_fixup(LevelDesc lv, GirsanovArgs g) {

@@ -251,6 +251,17 @@ class Plan:
                                                  _ptr(q[1]), _ptr(q[2]), _ptr(self.ws), _stream()), "mfgm_packed_sde_lean")
         return out
 
+    def selinv_kl(self, L, S, aS, y, prm, out=None):
+        """Backward sweep of a store_G=False factorisation returning dict(Sig, x, klpart): marginals and the per-chain moment-array
+        KL sum of `sde_lean(mode=0)` (add log|L_q| - T d / 2), without ever writing the moment array."""
+        out = {} if out is None else out
+        Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
+        x = out.get("x") if out.get("x") is not None else self.empty(VEC)
+        kl = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_packed_selinv_kl(self.h, -1, _ptr(L), _ptr(S), float(aS), _ptr(y), ctypes.byref(prm), _ptr(Sig), _ptr(x),
+                                                  _ptr(kl), _ptr(self.ws), _stream()), "mfgm_packed_selinv_kl")
+        return dict(Sig=Sig, x=x, klpart=kl)
+
     def selinv_girsanov(self, L, S, aS, y, prm, theta_q, out, only_level=-1):
         """Backward sweep of a store_G=False factorisation fused with the Girsanov-site update: `out` = (lin, diag, sub) receives
         (1 - lr) theta_q + lr theta~ (out of place; theta_q = (lin, diag, sub) with sub = S)."""

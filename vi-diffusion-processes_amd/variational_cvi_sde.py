@@ -144,11 +144,17 @@ class CVISitesSSM:
 
     _need_sub = True     # the linear-prior KL (kl_terms) reads the full cross-covariance blocks
 
-    def _refresh(self, want_sub=None):
-        """theta_q -> (L, log|L|, mu, Sigma_tt, [Sigma_{t+1,t}], moments) in one forward and one backward sweep."""
+    def _sweep_fusion(self):
+        """True when the level-0 backward sweep can do the model's local work itself (CVISitesSDE, mfgm_girsanov.h)."""
+        return False
+
+    def _refresh(self, want_sub=None, want_mom=None):
+        """theta_q -> (L, log|L|, mu, Sigma_tt, [Sigma_{t+1,t}], [moments | KL sum]) in one forward and one backward sweep."""
         want_sub = self._need_sub if want_sub is None else want_sub
-        if self._q is not None and want_sub and self._q["Sub"] is None:
-            self._q = None      # cached refresh lacks the cross-covariances now requested
+        fuse = self._sweep_fusion() and not want_sub
+        want_mom = (not fuse) if want_mom is None else want_mom
+        if self._q is not None and ((want_sub and self._q["Sub"] is None) or (want_mom and self._q["mom"] is None)):
+            self._q = None      # cached refresh lacks the cross-covariances / moments now requested
         if self._q is None:
             pl = self.plan
             tq = self.full_sites()
@@ -156,14 +162,20 @@ class CVISitesSSM:
             # uses from theta_sub (d^2 doubles per node fewer written)
             lean = (not want_sub) and pl.d <= 8
             f = pl.factor(tq.diag, tq.sub, tq.lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=self._bufs["f"], store_G=not lean)
-            s = pl.selinv_mom(f["L"], f["G"], f["y"], want_sub=want_sub, out=self._bufs["s"], S=tq.sub if lean else None, aS=-1.0)
             self._bufs["f"].update(L=f["L"], y=f["y"])
             if f["G"] is not None:
                 self._bufs["f"]["G"] = f["G"]
+            if fuse and not want_mom:
+                # the KL sum comes out of the backward sweep; the moment array is not written
+                s = pl.selinv_kl(f["L"], tq.sub, -1.0, f["y"], self._sde_prm, out=self._bufs["s"])
+                self._bufs["s"].update(Sig=s["Sig"], x=s["x"])
+                self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=None, mom=None, klpart=s["klpart"])
+                return self._q
+            s = pl.selinv_mom(f["L"], f["G"], f["y"], want_sub=want_sub, out=self._bufs["s"], S=tq.sub if lean else None, aS=-1.0)
             self._bufs["s"].update(Sig=s["Sig"], x=s["x"], mom=s["mom"])
             if s["Sub"] is not None:
                 self._bufs["s"]["Sub"] = s["Sub"]
-            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=s["Sub"], mom=s["mom"])
+            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=s["Sub"], mom=s["mom"], klpart=None)
         return self._q
 
     @property
@@ -331,8 +343,14 @@ class CVISitesSDE(CVISitesSSM):
         self._theta_q_valid = True
         self._q = q_valid
 
-    # update_girsanov_sites inside the backward sweep when no refresh is cached (VIDP_FUSED_GIRSANOV=0: always refresh + update)
+    # the level-0 backward sweep makes the Girsanov-site update / the KL sum itself (VIDP_FUSED_GIRSANOV=0: separate kernels on
+    # the moment array)
     fused_girsanov = os.environ.get("VIDP_FUSED_GIRSANOV", "1") != "0"
+
+    def _sweep_fusion(self):
+        pl, prm = self.plan, getattr(self, "_sde_prm", None)
+        return self.fused_girsanov and prm is not None and pl.d <= 8 and pl.nlevels >= 2 and prm.kind == 0
+
     _need_sub = False    # the closed-form SDE KL needs only (mu, diag Sigma, diag Sigma_sub): the moment array
 
     def KL_q_p(self):
@@ -341,7 +359,9 @@ class CVISitesSDE(CVISitesSSM):
         -H[q] - E_q[log p]: log|L_q| - T d / 2 + the moment-array sum of k_sde_lean.
         """
         q = self._refresh()
-        part = self.plan.sde_lean(self._sde_prm, q["mom"], q["Sig"], mode=0)
+        if q["klpart"] is None and q["mom"] is None:
+            q = self._refresh(want_mom=True)
+        part = q["klpart"] if q["klpart"] is not None else self.plan.sde_lean(self._sde_prm, q["mom"], q["Sig"], mode=0)
         return part + q["logdetL"] - 0.5 * self.T * self.state_dim
 
     def KL_q_p_full(self):
@@ -360,6 +380,8 @@ class CVISitesSDE(CVISitesSSM):
     # -- prior-parameter learning (variational_cvi_sde.py:495-518) ------------------------------------------------------------
     def _refresh_sde_params(self):
         self._sde_prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1])
+        if self._q is not None:
+            self._q["klpart"] = None      # a KL sum taken inside the sweep was that of the previous prior parameters
 
     def set_prior_initial_state(self, mean, cov):
         """Replace p(x0) (the trainer re-sets it to the stationary OU covariance after every decay update)."""
@@ -372,7 +394,7 @@ class CVISitesSDE(CVISitesSSM):
         state dimensions: KL = sum_t 1/2 w E_q[(x' - u(x))^2] + terms free of the drift, with Gaussian moments of
         (x, x') up to order six from the moment array (mu, diag Sigma, diag Sigma_{t+1,t}).
         """
-        q = self._refresh()
+        q = self._refresh(want_mom=True)
         d, T = self.state_dim, self.T
         mom = self.plan.unpack_moments(q["mom"])
         m, s, c = mom[:, :-1, :d], mom[:, :-1, d:2 * d], mom[:, :-1, 2 * d:]
@@ -431,7 +453,7 @@ class CVISitesSDE(CVISitesSSM):
         """Fused: g <- g + lr (scatter(data) - dKL/d eta), theta_q moves by the same increment (variational_cvi_sde.py:279-299)."""
         pl, tq = self.plan, self.full_sites()
         self._sde_prm.lr = float(lr)
-        if self._q is None and self.fused_girsanov and pl.d <= 8 and pl.nlevels >= 2 and self._sde_prm.kind == 0:
+        if (self._q is None or self._q["mom"] is None) and self._sweep_fusion():
             # no refresh of these sites is cached: the backward sweep of the refresh makes the update itself, without ever
             # writing the marginals (mfgm_girsanov.h); theta_q moves to the spare buffer
             f = pl.factor(tq.diag, tq.sub, tq.lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False, out=self._bufs["f"], store_G=False)
@@ -443,7 +465,7 @@ class CVISitesSDE(CVISitesSSM):
             self._theta_q, self._theta_spare = sp, tq
             tq = sp
         else:
-            q = self._refresh()
+            q = self._refresh(want_mom=True)
             pl.sde_lean(self._sde_prm, q["mom"], mode=3, theta_q=(tq.lin, tq.diag, tq.sub))
         pl.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, self.data_nat1, self.data_nat2, scale=lr)
         self._q = None
