@@ -219,8 +219,10 @@ typedef struct mfgm_vdp_params {
     double chol0[36];
     double dt;
     double lr;
-    double clip;          /* > 0: stabilize_system (vi_sde.py:312-323): NaN -> 1e-8 and clipping to [-clip, clip] of dE/dm, dE/dS and
-                           * the jump conditions inside the Lagrange sweep (CLIP_MAX = 5000 in the reference); 0: off */
+    double clip;          /* > 0: stabilize_system: NaN -> 1e-8 and clipping to [-clip, clip] of dE/dm, dE/dS and the jump conditions
+                           * inside the Lagrange sweep (vi_sde.py:312-323; CLIP_MAX = 5000 in the reference) and of psi / lambda, in
+                           * place, in update_param (vi_sde.py:393-397); the SSM's state transitions and offsets are clipped to
+                           * [-1, 1] in vdp_to_ssm (vi_sde.py:186-200).  0: off */
 } mfgm_vdp_params;
 
 /* forward_pass (vi_sde.py:171-204; LinearDrift(-A, b).to_ssm, drift.py:66-117): variational parameters Am (FULL), bm (VEC),
@@ -238,7 +240,8 @@ size_t mfgm_vdp_workspace_doubles(const mfgm_plan* plan);
 int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
                              const double* Am, const double* bm, const double* yR, const double* dobsS, double* psi,
                              double* lam, double* seg, void* stream);
-/* update_param (vi_sde.py:377-414): A <- (1-lr) A + lr (-E f' + 2 q psi), b <- (1-lr) b + lr (E f + A~ m - q lambda). */
+/* update_param (vi_sde.py:377-414): A <- (1-lr) A + lr (-E f' + 2 q psi), b <- (1-lr) b + lr (E f + A~ m - q lambda).
+ * With prm->clip > 0 psi and lam are overwritten by their clipped values (they are not const then). */
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
                                  const double* psi, const double* lam, double* Am, double* bm, void* stream);
 

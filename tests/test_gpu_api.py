@@ -355,7 +355,8 @@ def test_cvi_gaussian_process(amd, rng, kname):
         np.testing.assert_allclose(float(g2.classic_elbo()), o2.classic_elbo(), rtol=max(tol, 1e-6))
 
 
-@pytest.mark.parametrize("d,B,T,kind", [(1, 1, 60, "dw"), (2, 2, 47, "dw"), (1, 2, 33, "ou"), (3, 1, 140, "dw")])
+@pytest.mark.parametrize("d,B,T,kind", [(1, 1, 60, "dw"), (2, 2, 47, "dw"), (1, 2, 33, "ou"), (3, 1, 140, "dw"),
+                                        (2, 2, 700, "ou")])     # 88 segments: more than one per lane of the Lagrange scan
 def test_variational_markov_gp(amd, rng, d, B, T, kind):
     """VDP (vi_sde.py): forward pass, energy and gradients, Lagrange sweep, parameter / initial-state updates and ELBO
     against the oracle's restatement of the reference loop, per trajectory."""

@@ -24,11 +24,13 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
     } else if (what == 2) {
         hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
         MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((k_vdp_lagrange_scan<D>), dim3((P.B + 63) / 64), block, 0, st, lv, o2);
+        hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 0>), dim3(P.B), block, 0, st, lv, o2);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 1>), dim3(P.B), block, 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
     } else {
-        hipLaunchKernelGGL((k_vdp_update_param<D>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, o0, o1);
+        hipLaunchKernelGGL((k_vdp_update_param<D>), grid, block, 0, st, lv, pr, a0, a1, const_cast<double*>(a2), const_cast<double*>(a3), o0, o1);
     }
     MFGM_CHECK_LAUNCH();
     return 0;

@@ -4,7 +4,7 @@
 //   k_vdp_lagrange<P>  update_lagrange (vi_sde.py:289-347): the backward Euler sweep for (psi, lambda) as a partitioned
 //                      affine recurrence  psi_{t-1} = psi_t (I - 2 dt A_t) + c_t,  lambda_{t-1} = (I - dt A_t) lambda_t + e_t
 //                      (the reference's Python loop with O(T) tensor_scatter_nd_update copies), in three passes:
-//                      segment summaries, a short per-chain scan over segments, and the final sweep.
+//                      segment summaries, a per-chain scan over the segments (one wavefront per chain), and the final sweep.
 //   k_vdp_update_param update_param (vi_sde.py:377-414)
 // Drifts are per-dimension cubics f_i(x) = af x - bf x^3 (OU, double-well) with diagonal diffusion q.
 #pragma once
@@ -144,6 +144,15 @@ __global__ __launch_bounds__(64) void k_vdp_to_ssm(LevelDesc lv, VdpParams pr, c
 #pragma unroll
                 for (int e = 0; e < EF; ++e) A[e] = 0.0;
             }
+            if (pr.clip > 0.0) {
+                // stabilize_system (vi_sde.py:186-200): NaN -> 1e-8, state transitions and offsets clipped to [-1, 1]
+#pragma unroll
+                for (int e = 0; e < EF; ++e) A[e] = vdp_stab(A[e], 1.0);
+                if (t > 0) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) off[i] = vdp_stab(off[i], 1.0);
+                }
+            }
             st_node<D>(offg, R, s, me, off);
             st_node<ET>(cholg, R, s, me, ch);
             st_node<EF>(Ag, R, s, me, A);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, con
 // yR (VEC) = R^{-1} y at observation nodes (zero elsewhere), dobsS (SYM) = -1/2 R^{-1} at observation nodes: the jump
 // conditions d_obs_m = yR + 2 dobsS m, d_obs_S = dobsS (vi_sde.py:262-287 for a Gaussian likelihood).
 // PASS 1: per-segment affine summary (Mpsi, Cpsi, Mlam, Clam) with zero input; PASS 3: the sweep from the known value
-// at the segment's last node (bpsi, blam: [lanes] arrays written by k_vdp_lagrange_scan).
+// at the segment's last node (bpsi, blam: [lanes] arrays written by k_vdp_lagrange_scan_wave).
 template <int D, int PASS>
 __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
                                                     const double* __restrict__ Sigg, const double* __restrict__ Am,
@@ -285,52 +294,99 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
     }
 }
 
-// PASS 2: one lane per chain walks the segments from the last to the first:
-//   value at the last node of segment p-1 = (value at the last node of segment p) o map_p
-template <int D>
-__global__ __launch_bounds__(64) void k_vdp_lagrange_scan(LevelDesc lv, double* __restrict__ seg) {
-    constexpr int EF = D * D;
-    constexpr int SEG = 3 * EF + D;
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b * lv.P >= lv.L) return;
-    const int P = lv.P, Lp = lv.Lpad;
-    double* bnd = seg + (size_t)SEG * Lp;
-    double psi[EF], lam[D];
+// PASS 2: value at the last node of segment p-1 = (value at the last node of segment p) o map_p, for every chain.
+// One wavefront per chain (one lane walking all the segments costs a memory round trip per segment: 10.7 ms at P = 1021):
+// lane j composes the maps of K = ceil(P / 64) consecutive segments, the 64 composed maps are chained through v_readlane
+// broadcasts, and each lane then replays its own K segments from the value that enters them.
+//   PART 0: psi (value X, maps X -> X M + C);  PART 1: lambda (value v, maps v -> M v + C)
+MFGM_DEV double vdp_bcast(double x, int src) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <int D, int PART>
+__global__ __launch_bounds__(64) void k_vdp_lagrange_scan_wave(LevelDesc lv, double* __restrict__ seg) {
+    constexpr int EF = D * D, SEG = 3 * EF + D, NV = PART == 0 ? EF : D;
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int P = lv.P;
+    const size_t Lp = lv.Lpad;
+    const int K = (P + 63) / 64;
+    const int hi = P - j * K;                      // this lane's segments: hi-1, hi-2, ..., max(hi-K, 0)
+    const double* Mg = seg + (size_t)(PART == 0 ? 0 : 2 * EF) * Lp;
+    const double* Cg = seg + (size_t)(PART == 0 ? EF : 3 * EF) * Lp;
+    double* bnd = seg + (size_t)SEG * Lp + (size_t)(PART == 0 ? 0 : EF) * Lp;
+
+    auto apply = [&](double (&val)[NV], const double (&Mm)[EF], const double (&Cc)[NV]) {
+        double t[NV];
+        if constexpr (PART == 0) gemm<D>(val, Mm, t); else gemv<D>(Mm, val, t);
 #pragma unroll
-    for (int e = 0; e < EF; ++e) psi[e] = 0.0;
+        for (int e = 0; e < NV; ++e) val[e] = t[e] + Cc[e];
+    };
+    auto load_map = [&](int p, double (&Mm)[EF], double (&Cc)[NV]) {
+        const size_t lane = (size_t)b * P + p;
 #pragma unroll
-    for (int i = 0; i < D; ++i) { lam[i] = 0.0; psi[i * D + i] = 1e-10; }     // psi_{N-1} = 1e-10 I, lambda_{N-1} = 0
-    for (int p = P - 1; p >= 0; --p) {
-        const int lane = b * P + p;
-        // the last segment's boundary value sits on node N-1 whatever its position inside the segment: the sweep
-        // kernels start writing at t <= N-1, so the same value is correct for them
+        for (int e = 0; e < EF; ++e) Mm[e] = Mg[(size_t)e * Lp + lane];
 #pragma unroll
-        for (int e = 0; e < EF; ++e) bnd[(size_t)e * Lp + lane] = psi[e];
+        for (int e = 0; e < NV; ++e) Cc[e] = Cg[(size_t)e * Lp + lane];
+    };
+
+    // the lane's composed map
+    double M[EF], C[NV];
 #pragma unroll
-        for (int i = 0; i < D; ++i) bnd[(size_t)(EF + i) * Lp + lane] = lam[i];
-        double Mp[EF], Cp[EF], Ml[EF], Cl[D], t1[EF], t2[D];
+    for (int e = 0; e < EF; ++e) M[e] = 0.0;
 #pragma unroll
-        for (int e = 0; e < EF; ++e) {
-            Mp[e] = seg[(size_t)e * Lp + lane];
-            Cp[e] = seg[(size_t)(EF + e) * Lp + lane];
-            Ml[e] = seg[(size_t)(2 * EF + e) * Lp + lane];
+    for (int i = 0; i < D; ++i) M[i * D + i] = 1.0;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) C[e] = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const int p = hi - 1 - k;
+        if (p >= 0) {
+            double Mm[EF], Cc[NV], t[EF];
+            load_map(p, Mm, Cc);
+            apply(C, Mm, Cc);
+            if constexpr (PART == 0) gemm<D>(M, Mm, t); else gemm<D>(Mm, M, t);
+#pragma unroll
+            for (int e = 0; e < EF; ++e) M[e] = t[e];
         }
+    }
+    // value at the last node of the chain: psi_{N-1} = 1e-10 I, lambda_{N-1} = 0; chained through the lanes' maps
+    double run[NV], mine[NV];
 #pragma unroll
-        for (int i = 0; i < D; ++i) Cl[i] = seg[(size_t)(3 * EF + i) * Lp + lane];
-        gemm<D>(psi, Mp, t1);
-        gemv<D>(Ml, lam, t2);
+    for (int e = 0; e < NV; ++e) { run[e] = 0.0; mine[e] = 0.0; }
+    if constexpr (PART == 0) {
 #pragma unroll
-        for (int e = 0; e < EF; ++e) psi[e] = t1[e] + Cp[e];
+        for (int i = 0; i < D; ++i) run[i * D + i] = 1e-10;
+    }
+    for (int jj = 0; jj < 64; ++jj) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) lam[i] = t2[i] + Cl[i];
+        for (int e = 0; e < NV; ++e) mine[e] = (jj == j) ? run[e] : mine[e];
+        double Mb[EF], Cb[NV];
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Mb[e] = vdp_bcast(M[e], jj);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) Cb[e] = vdp_bcast(C[e], jj);
+        apply(run, Mb, Cb);
+    }
+    // replay: boundary value of every segment of this lane
+    for (int k = 0; k < K; ++k) {
+        const int p = hi - 1 - k;
+        if (p >= 0) {
+            const size_t lane = (size_t)b * P + p;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) bnd[(size_t)e * Lp + lane] = mine[e];
+            double Mm[EF], Cc[NV];
+            load_map(p, Mm, Cc);
+            apply(mine, Mm, Cc);
+        }
     }
 }
 
 // ---- update_param ---------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void k_vdp_update_param(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
-                                                        const double* __restrict__ Sigg, const double* __restrict__ psig,
-                                                        const double* __restrict__ lamg, double* __restrict__ Am,
+                                                        const double* __restrict__ Sigg, double* __restrict__ psig,
+                                                        double* __restrict__ lamg, double* __restrict__ Am,
                                                         double* __restrict__ bm) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
@@ -349,6 +405,15 @@ __global__ __launch_bounds__(64) void k_vdp_update_param(LevelDesc lv, VdpParams
             ld_node<D>(lamg, R, s, me, lam);
             ld_node<EF>(Am, R, s, me, A);
             ld_node<D>(bm, R, s, me, bb);
+            if (pr.clip > 0.0) {
+                // stabilize_system (vi_sde.py:393-397): the multipliers are scrubbed and clipped in place before they are used
+#pragma unroll
+                for (int e = 0; e < EF; ++e) psi[e] = vdp_stab(psi[e], pr.clip);
+#pragma unroll
+                for (int i = 0; i < D; ++i) lam[i] = vdp_stab(lam[i], pr.clip);
+                st_node<EF>(psig, R, s, me, psi);
+                st_node<D>(lamg, R, s, me, lam);
+            }
             double Ef[D], Jf[D], Vf[D], t0[D], t1[D], t2[D], t3[D], t4[D];
             drift_moments<D>(pr, m, S, Ef, Jf, Vf, t0, t1, t2, t3, t4);
             double At[EF], bt[D];

@@ -96,11 +96,8 @@ class VariationalMarkovGP:
         prm = self._params()
         _lib.check(self.lib.mfgm_packed_vdp_to_ssm(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(A), _ptr(off), _ptr(chol),
                                                    _stream()), "mfgm_packed_vdp_to_ssm")
-        if self.stabilize_system:
-            # vi_sde.py:186-200: NaN -> 1e-8 and clipping of the state transitions and offsets to [-1, 1] (node 0 of `off`, the
-            # initial mean, is rewritten just below)
-            torch.nan_to_num(A, nan=1e-8, out=A).clamp_(-1.0, 1.0)
-            torch.nan_to_num(off, nan=1e-8, out=off).clamp_(-1.0, 1.0)
+        # stabilize_system (vi_sde.py:186-200): NaN -> 1e-8 and clipping of the state transitions and offsets to [-1, 1] happen
+        # inside the kernel (prm.clip > 0)
         # node 0 carries q(x0), which is per trajectory
         node0 = pl.node_ids(torch.zeros(1, dtype=torch.int64))
         pl.scatter_nodes(VEC, off, node0, self.q0_mu)
@@ -201,9 +198,7 @@ class VariationalMarkovGP:
         """A <- (1-lr) A + lr A~, b <- (1-lr) b + lr b~ (vi_sde.py:377-414)."""
         pl = self.plan
         m, S = mS if mS is not None else self._mS
-        if self.stabilize_system:       # vi_sde.py:393-397
-            for arr in (self.psi_lagrange, self.lambda_lagrange):
-                torch.nan_to_num(arr, nan=1e-8, out=arr).clamp_(-5000.0, 5000.0)
+        # stabilize_system (vi_sde.py:393-397): psi / lambda are scrubbed and clipped in place by the kernel (prm.clip > 0)
         _lib.check(self.lib.mfgm_packed_vdp_update_param(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S),
                                                          _ptr(self.psi_lagrange), _ptr(self.lambda_lagrange), _ptr(self.A),
                                                          _ptr(self.b), _stream()), "mfgm_packed_vdp_update_param")
