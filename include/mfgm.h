@@ -157,7 +157,7 @@ int mfgm_packed_selinv_mom(const mfgm_plan* plan, int only_level, const double* 
  * backward sweep rebuilds what it needs from the input sub-diagonal blocks S (H = aS S (L L^T)^{-1}).  Same bytes read, d^2 doubles
  * per node fewer written by the forward sweep.  S and aS must be those given to mfgm_packed_factor. */
 int mfgm_packed_selinv_mom_s(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
-                             double* Sig, double* x, double* mom, void* ws, void* stream);
+                             double* Sig, double* x, double* mom /* may be NULL: marginals only */, void* ws, void* stream);
 
 /* Backward sweep of a G = NULL factorisation fused with the Girsanov-site update of CVI-DP (variational_cvi_sde.py:279-299, the
  * update mfgm_packed_sde_lean mode 3 makes from the moment array): instead of the marginals it writes
@@ -233,6 +233,13 @@ int mfgm_packed_vdp_to_ssm(const mfgm_plan* plan, const mfgm_vdp_params* prm, co
  * form; gm (VEC) / gS (SYM) receive dE/dm / dt and dE/dS / dt (vi_sde.py:206-239) when non-NULL. */
 int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
                          const double* Am, const double* bm, double* e_over_dt, double* gm, double* gS, void* ws, void* stream);
+/* forward_pass without the intermediate SSM arrays: the precision blocks (diag SYM, sub FULL) and linear term (lin VEC) of the Euler
+ * chain of the drift (-A, b) with per-trajectory q(x0): p0inv [B][d(d+1)/2] = P0^{-1} (packed lower triangles), p0lin [B][d] =
+ * P0^{-1} mu0.  Equals mfgm_packed_vdp_to_ssm + node-0 overwrite + mfgm_packed_ssm_to_naturals(cD = 1, cS = -1); factor the result
+ * with scales (1, 1, 1). */
+int mfgm_packed_vdp_to_naturals(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
+                                const double* p0inv, const double* p0lin, double* lin, double* diag, double* sub, void* stream);
+
 /* update_lagrange (vi_sde.py:289-347): psi (FULL) and lambda (VEC) on nodes 0..T-2.  yR (VEC) = R^{-1} y and dobsS (SYM) =
  * -1/2 R^{-1} at the observation nodes, zero elsewhere (jump conditions of a Gaussian likelihood, vi_sde.py:262-287).
  * seg: scratch of mfgm_vdp_workspace_doubles(plan) doubles. */

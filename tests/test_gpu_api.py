@@ -942,8 +942,10 @@ def test_variational_markov_gp_stabilized(amd, rng):
         assert_close(host(plan.unpack(amd.FULL, g.A, T - 1))[0], o.A)
         assert_close(host(plan.unpack(amd.VEC, g.b, T - 1))[0], o.b)
     assert clipped                                   # the scenario does exercise the clipping
-    ssm_A = np.abs(host(plan.unpack(amd.FULL, g._ssm_bufs[0], T - 1))).max()
-    assert ssm_A <= 1.0 + 1e-12                   # the clipped transitions
+    # the clipped transitions T_t, read back from the sub-diagonal precision blocks -W T_t of the last forward pass (W = 1 / (dt q))
+    sub = host(plan.unpack(amd.FULL, g._fw["nat"][2], T - 1))
+    ssm_A = np.abs(sub * (g.dt * np.asarray(g.prior_sde.q_diag))[:, None]).max()
+    assert ssm_A <= 1.0 + 1e-12
 
 
 @pytest.mark.parametrize("d,kind,B,T,R0", [(1, "dw", 3, 57, 8), (2, "dw", 2, 61, 8), (3, "ou", 2, 64, 4), (6, "dw", 3, 131, 8), (6, "dw", 1, 33, 16)])

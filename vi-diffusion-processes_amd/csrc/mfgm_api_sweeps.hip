@@ -42,11 +42,16 @@ int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub
     dim3 grid(a.lv.Lpad / 64), block(64);
     const bool mom = (a.momg != nullptr);
 #define BW(R_, U_, S_, M_) hipLaunchKernelGGL((k_backward<D, R_, U_, S_, M_>), grid, block, 0, st, a)
-    if (mom && a.Sg != nullptr) {
-        // level 0 rebuilt from the input sub-diagonal blocks (the forward pass stored no L_{t+1,t}); moment output, no Sub
-        if (want_sub) return 1;
-        if (has_up) hipLaunchKernelGGL((k_backward<D, true, true, false, true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_backward<D, true, false, false, true, true>), grid, block, 0, st, a);
+    if (a.Gg == nullptr && a.Sg != nullptr) {
+        // level 0 rebuilt from the input sub-diagonal blocks (the forward pass stored no L_{t+1,t}); means wanted, no Sub
+        if (want_sub || !has_rhs) return 1;
+        if (mom) {
+            if (has_up) hipLaunchKernelGGL((k_backward<D, true, true, false, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_backward<D, true, false, false, true, true>), grid, block, 0, st, a);
+        } else {
+            if (has_up) hipLaunchKernelGGL((k_backward<D, true, true, false, false, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_backward<D, true, false, false, false, true>), grid, block, 0, st, a);
+        }
     } else if (mom) {
         // the moment array needs the means: has_rhs is guaranteed by the entry point
         if (has_up) { if (want_sub) BW(true, true, true, true); else BW(true, true, false, true); }
@@ -278,7 +283,7 @@ int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, 
 
 int mfgm_packed_selinv_mom_s(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
                              double* Sig, double* x, double* mom, void* ws, void* stream) {
-    if (!plan || !L || !S || !Sig || !y || !x || !mom) return 1;
+    if (!plan || !L || !S || !Sig || !y || !x) return 1;          // mom may be NULL: marginals only
     const Plan& P = plan->p;
     if (P.wide || only_level >= P.nlevels) return 1;
     hipStream_t st = (hipStream_t)stream;

@@ -29,6 +29,8 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 1>), dim3(P.B), block, 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
+    } else if (what == 4) {
+        hipLaunchKernelGGL((k_vdp_to_naturals<D>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, o0, o1, o2);
     } else {
         hipLaunchKernelGGL((k_vdp_update_param<D>), grid, block, 0, st, lv, pr, a0, a1, const_cast<double*>(a2), const_cast<double*>(a3), o0, o1);
     }
@@ -52,6 +54,15 @@ int mfgm_packed_vdp_to_ssm(const mfgm_plan* plan, const mfgm_vdp_params* prm, co
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(0, P, pr, Am, bm, nullptr, nullptr, nullptr, nullptr, A, off, chol, nullptr, st)));
+}
+
+int mfgm_packed_vdp_to_naturals(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
+                                const double* p0inv, const double* p0lin, double* lin, double* diag, double* sub, void* stream) {
+    if (!plan || !prm || !Am || !bm || !p0inv || !p0lin || !lin || !diag || !sub) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(4, P, pr, Am, bm, p0inv, p0lin, nullptr, nullptr, lin, diag, sub, nullptr, st)));
 }
 
 int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, const double* Am,

@@ -251,6 +251,15 @@ class Plan:
                                                  _ptr(q[1]), _ptr(q[2]), _ptr(self.ws), _stream()), "mfgm_packed_sde_lean")
         return out
 
+    def selinv_s(self, L, S, aS, y, out=None):
+        """Selected inverse of a store_G=False factorisation: dict(Sig, x) (marginals only; (S, aS) as given to `factor`)."""
+        out = {} if out is None else out
+        Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
+        x = out.get("x") if out.get("x") is not None else self.empty(VEC)
+        _lib.check(self.lib.mfgm_packed_selinv_mom_s(self.h, -1, _ptr(L), _ptr(S), float(aS), _ptr(y), _ptr(Sig), _ptr(x), None,
+                                                     _ptr(self.ws), _stream()), "mfgm_packed_selinv_mom_s")
+        return dict(Sig=Sig, x=x)
+
     def selinv_kl(self, L, S, aS, y, prm, out=None):
         """Backward sweep of a store_G=False factorisation returning dict(Sig, x, klpart): marginals and the per-chain moment-array
         KL sum of `sde_lean(mode=0)` (add log|L_q| - T d / 2), without ever writing the moment array."""

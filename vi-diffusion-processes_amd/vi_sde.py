@@ -90,14 +90,16 @@ class VariationalMarkovGP:
 
     def _forward_packed(self):
         pl = self.plan
+        prm = self._params()
+        if pl.d <= 8 and pl.T > 1:
+            return self._forward_packed_direct(prm)
         if self._ssm_bufs is None:
             self._ssm_bufs = (pl.empty(FULL), pl.empty(VEC), pl.empty(TRI))
         A, off, chol = self._ssm_bufs
-        prm = self._params()
-        _lib.check(self.lib.mfgm_packed_vdp_to_ssm(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(A), _ptr(off), _ptr(chol),
-                                                   _stream()), "mfgm_packed_vdp_to_ssm")
         # stabilize_system (vi_sde.py:186-200): NaN -> 1e-8 and clipping of the state transitions and offsets to [-1, 1] happen
         # inside the kernel (prm.clip > 0)
+        _lib.check(self.lib.mfgm_packed_vdp_to_ssm(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(A), _ptr(off), _ptr(chol),
+                                                   _stream()), "mfgm_packed_vdp_to_ssm")
         # node 0 carries q(x0), which is per trajectory
         node0 = pl.node_ids(torch.zeros(1, dtype=torch.int64))
         pl.scatter_nodes(VEC, off, node0, self.q0_mu)
@@ -105,6 +107,30 @@ class VariationalMarkovGP:
         pr = pl.ssm_to_naturals(A, off, chol, precision=True)
         f = pl.factor(pr["diag"], pr["sub"], pr["lin"], want_logdet=False)
         s = pl.selinv(f["L"], f["G"], f["y"], want_sub=False)
+        self._mS = (s["x"], s["Sig"])
+        return self._mS
+
+    def _forward_packed_direct(self, prm):
+        """
+        The same marginals without materialising the SSM: (A, b) -> precision blocks in one kernel (mfgm_packed_vdp_to_naturals),
+        a factorisation that does not store L_{t+1,t}, and the selected inverse rebuilt from the sub-diagonal precision blocks.
+        """
+        pl, d = self.plan, self.state_dim
+        key = (self.q0_mu, self.q0_chol)
+        if getattr(self, "_p0_key", None) is None or self._p0_key[0] is not key[0] or self._p0_key[1] is not key[1]:
+            p0inv = linalg.spd_inverse(chol=self.q0_chol)                                   # [B, d, d]
+            il = torch.tril_indices(d, d, device=self.device)
+            self._p0 = (p0inv[:, il[0], il[1]].contiguous(), (p0inv @ self.q0_mu[..., None])[..., 0].contiguous())
+            self._p0_key = key
+        if getattr(self, "_fw", None) is None:
+            self._fw = dict(nat=(pl.empty(VEC), pl.empty(SYM), pl.empty(FULL)), f={})
+        lin, diag, sub = self._fw["nat"]
+        _lib.check(self.lib.mfgm_packed_vdp_to_naturals(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(self._p0[0]),
+                                                        _ptr(self._p0[1]), _ptr(lin), _ptr(diag), _ptr(sub), _stream()),
+                   "mfgm_packed_vdp_to_naturals")
+        f = pl.factor(diag, sub, lin, want_logdet=False, out=self._fw["f"], store_G=False)
+        self._fw["f"].update(L=f["L"], y=f["y"])
+        s = pl.selinv_s(f["L"], sub, 1.0, f["y"])        # fresh outputs: callers keep the marginals of earlier passes
         self._mS = (s["x"], s["Sig"])
         return self._mS
 
