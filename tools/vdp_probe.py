@@ -1,6 +1,6 @@
 """
 VDP (VariationalMarkovGP) inference step at the headline size, one GPU: the loop body of VIMarkovGPTrainer.perform_inference
-(forward pass, Lagrange sweep, parameter update, forward pass, ELBO) on B double-well trajectories of T steps, d dimensions,
+(Lagrange sweep, parameter update, forward pass, ELBO) on B double-well trajectories of T steps, d dimensions,
 with the reference's stabilize_system clipping (a chain this long overflows the multiplier recursion without it, vi_sde.py:59-60).
 
     python tools/vdp_probe.py [B T d steps]
@@ -46,11 +46,14 @@ def main():
         ev.setdefault(name, []).append((a, b))
         return out
 
+    state = {"mS": m._forward_packed()}
+
     def step():
-        mS = timed("forward_pass", m._forward_packed)
+        # as the trainer: the marginals that close one iteration open the next
+        mS = state["mS"]
         timed("update_lagrange", lambda: m.update_lagrange(mS))
         timed("update_param", lambda: m.update_param(mS, lr=LR))
-        mS = timed("forward_pass", m._forward_packed)
+        state["mS"] = mS = timed("forward_pass", m._forward_packed)
         return timed("elbo", lambda: m.elbo(mS))
 
     for _ in range(3):

@@ -224,10 +224,12 @@ class VIMarkovGPTrainer:
     def perform_inference(self):
         """vi_markov_gp_trainer.py:50-92."""
         mdl = self.model
-        elbos, nlpds, rmses = [float(mdl.elbo())], [], []
+        mS = mdl._forward_packed()
+        elbos, nlpds, rmses = [float(mdl.elbo(mS))], [], []
         q_lr, x0_lr = self.q_lr, self.x0_lr
         for i in range(self.max_itr):
-            mS = mdl._forward_packed()
+            # the marginals that close an iteration (for its ELBO) are those the next one starts from: the parameters do not change
+            # in between, so the reference's second forward_pass per iteration (vi_markov_gp_trainer.py:60) is not repeated
             mdl.update_lagrange(mS)
             mdl.update_param(mS, lr=q_lr)
             if i > self.warmup_x0_itr:
