@@ -986,3 +986,41 @@ def test_fused_girsanov_update_equals_two_kernel_update(amd, rng, d, kind, B, T,
         for xa, xb in zip(sa, sb):
             assert np.isfinite(xa).all()
             np.testing.assert_allclose(xa, xb, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(xb).max()))
+
+
+@pytest.mark.parametrize("d,B,T,stab,kind", [(1, 2, 60, False, "dw"), (2, 2, 700, False, "ou"), (3, 1, 140, True, "dw"), (6, 2, 90, True, "dw")])
+def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind):
+    """update_lagrange_and_param (one set of sweeps) against update_lagrange followed by update_param, three consecutive iterations."""
+    import torch
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    dt = 0.01
+    grid = np.arange(T) * dt
+    idx = np.arange(5, T - 1, 9)
+    y = np.sign(rng.normal(size=(B, len(idx), d))) + 0.1 * rng.normal(size=(B, len(idx), d))
+    # a small observation noise makes the multipliers large enough for stabilize_system to clip them
+    lik_chol = (0.02 if stab else 0.5) * np.eye(d)
+
+    def run(fused):
+        q = torch.eye(d, dtype=torch.float64)
+        g = VariationalMarkovGP((grid[idx], dev(y)), gsde.DoubleWellSDE(q) if kind == "dw" else gsde.OrnsteinUhlenbeckSDE(0.9, q), grid,
+                                MultivariateGaussian(dev(lik_chol)), prior_initial_state=(np.zeros(d), 0.5 * np.eye(d)),
+                                stabilize_system=stab, plan=amd.Plan(B, T, d, R0=8, Rup=3))
+        out = []
+        for _ in range(3):
+            mS = g._forward_packed()
+            if fused:
+                g.update_lagrange_and_param(mS, lr=0.05)
+            else:
+                g.update_lagrange(mS)
+                g.update_param(mS, lr=0.05)
+            pl = g.plan
+            out.append([host(pl.unpack(amd.FULL, g.A, T - 1)), host(pl.unpack(amd.VEC, g.b, T - 1)),
+                        host(pl.unpack(amd.FULL, g.psi_lagrange, T - 1)), host(pl.unpack(amd.VEC, g.lambda_lagrange, T - 1))])
+        return out
+
+    for sa, sb in zip(run(True), run(False)):
+        for xa, xb in zip(sa, sb):
+            assert np.isfinite(xb).all()
+            np.testing.assert_allclose(xa, xb, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(xb).max()))

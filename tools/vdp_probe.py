@@ -51,8 +51,7 @@ def main():
     def step():
         # as the trainer: the marginals that close one iteration open the next
         mS = state["mS"]
-        timed("update_lagrange", lambda: m.update_lagrange(mS))
-        timed("update_param", lambda: m.update_param(mS, lr=LR))
+        timed("lagrange+param", lambda: m.update_lagrange_and_param(mS, lr=LR))
         state["mS"] = mS = timed("forward_pass", m._forward_packed)
         return timed("elbo", lambda: m.elbo(mS))
 

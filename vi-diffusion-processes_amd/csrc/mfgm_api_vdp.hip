@@ -21,14 +21,18 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         else hipLaunchKernelGGL((k_vdp_esde<D, false>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, part, o1, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, o0, (double*)nullptr);
-    } else if (what == 2) {
-        hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
+    } else if (what == 2 || what == 5) {
+        // segment summaries, per-chain scan of the segment maps, final sweep (what == 5: the sweep also makes update_param)
+        double* Aw = const_cast<double*>(a2);
+        double* bw = const_cast<double*>(a3);
+        hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 0>), dim3(P.B), block, 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 1>), dim3(P.B), block, 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, a4, a5, o0, o1, o2);
+        if (what == 2) hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
+        else hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
     } else if (what == 4) {
         hipLaunchKernelGGL((k_vdp_to_naturals<D>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, o0, o1, o2);
     } else {
@@ -82,6 +86,16 @@ int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, 
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(2, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st)));
+}
+
+int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
+                                    double* bm, const double* yR, const double* dobsS, double* psi, double* lam, double* seg,
+                                    void* stream) {
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !dobsS || !psi || !lam || !seg) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(5, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st)));
 }
 
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

@@ -290,10 +290,12 @@ __global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, con
 // conditions d_obs_m = yR + 2 dobsS m, d_obs_S = dobsS (vi_sde.py:262-287 for a Gaussian likelihood).
 // PASS 1: per-segment affine summary (Mpsi, Cpsi, Mlam, Clam) with zero input; PASS 3: the sweep from the known value
 // at the segment's last node (bpsi, blam: [lanes] arrays written by k_vdp_lagrange_scan_wave).
+// PASS 4: PASS 3 that also makes update_param at every node it visits (A, b replaced in place; with pr.clip > 0 the stored psi /
+// lambda are the clipped values update_param would leave, the recurrence itself continues with the unclipped ones).
 template <int D, int PASS>
 __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
-                                                    const double* __restrict__ Sigg, const double* __restrict__ Am,
-                                                    const double* __restrict__ bm, const double* __restrict__ yR,
+                                                    const double* __restrict__ Sigg, double* Am,
+                                                    double* bm, const double* __restrict__ yR,
                                                     const double* __restrict__ dobsS, double* __restrict__ psig,
                                                     double* __restrict__ lamg, double* __restrict__ seg /* per-lane summaries */) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
@@ -329,12 +331,41 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                     st_node<EF>(psig, R, s, me, psi);
                     st_node<D>(lamg, R, s, me, lam);
                 }
-                if (t >= 1) {
-                    double m[D], S[ET], A[EF], bb[D], dm[D], dS[ET], yr[D], dob[ET];
+                double m[D], S[ET], A[EF], bb[D];
+                if (PASS == 4 || t >= 1) {
                     ld_node<D>(mug, R, s, me, m);
                     ld_node<ET>(Sigg, R, s, me, S);
                     ld_node<EF>(Am, R, s, me, A);
                     ld_node<D>(bm, R, s, me, bb);
+                }
+                if (PASS == 4) {
+                    // update_param at node t (vi_sde.py:377-414) from the multipliers just obtained
+                    double pc[EF], lc[D];
+#pragma unroll
+                    for (int e = 0; e < EF; ++e) pc[e] = pr.clip > 0.0 ? vdp_stab(psi[e], pr.clip) : psi[e];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) lc[i] = pr.clip > 0.0 ? vdp_stab(lam[i], pr.clip) : lam[i];
+                    st_node<EF>(psig, R, s, me, pc);
+                    st_node<D>(lamg, R, s, me, lc);
+                    double Ef[D], Jf[D], Vf[D], t0[D], t1[D], t2[D], t3[D], t4[D];
+                    drift_moments<D>(pr, m, S, Ef, Jf, Vf, t0, t1, t2, t3, t4);
+                    double At[EF], bt[D], An[EF], bn[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) At[i * D + j] = 2.0 * pr.q[i] * pc[i * D + j] - (i == j ? Jf[i] : 0.0);
+                    gemv<D>(At, m, bt);
+#pragma unroll
+                    for (int i = 0; i < D; ++i) bt[i] += Ef[i] - pr.q[i] * lc[i];
+#pragma unroll
+                    for (int e = 0; e < EF; ++e) An[e] = (1.0 - pr.lr) * A[e] + pr.lr * At[e];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) bn[i] = (1.0 - pr.lr) * bb[i] + pr.lr * bt[i];
+                    st_node<EF>(Am, R, s, me, An);
+                    st_node<D>(bm, R, s, me, bn);
+                }
+                if (t >= 1) {
+                    double dm[D], dS[ET], yr[D], dob[ET];
                     ld_node<D>(yR, R, s, me, yr);
                     ld_node<ET>(dobsS, R, s, me, dob);
                     vdp_energy<D, true>(pr, m, S, A, bb, dm, dS);

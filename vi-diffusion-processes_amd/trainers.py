@@ -230,8 +230,7 @@ class VIMarkovGPTrainer:
         for i in range(self.max_itr):
             # the marginals that close an iteration (for its ELBO) are those the next one starts from: the parameters do not change
             # in between, so the reference's second forward_pass per iteration (vi_markov_gp_trainer.py:60) is not repeated
-            mdl.update_lagrange(mS)
-            mdl.update_param(mS, lr=q_lr)
+            mdl.update_lagrange_and_param(mS, lr=q_lr)
             if i > self.warmup_x0_itr:
                 mdl.update_initial_statistics(lr=x0_lr)
             mS = mdl._forward_packed()

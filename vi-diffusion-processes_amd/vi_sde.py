@@ -229,6 +229,18 @@ class VariationalMarkovGP:
                                                          _ptr(self.psi_lagrange), _ptr(self.lambda_lagrange), _ptr(self.A),
                                                          _ptr(self.b), _stream()), "mfgm_packed_vdp_update_param")
 
+    def update_lagrange_and_param(self, mS=None, lr=0.1):
+        """
+        update_lagrange(mS) followed by update_param(mS, lr), as the trainer calls them (vi_markov_gp_trainer.py:56-57), in one
+        set of sweeps: the final Lagrange sweep makes the parameter update node by node (mfgm_packed_vdp_lagrange_update).
+        """
+        pl = self.plan
+        m, S = mS if mS is not None else self._mS
+        _lib.check(self.lib.mfgm_packed_vdp_lagrange_update(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
+                                                            _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
+                                                            _ptr(self.lambda_lagrange), _ptr(self._seg), _stream()),
+                   "mfgm_packed_vdp_lagrange_update")
+
     def update_initial_statistics(self, lr):
         """q(x0) from the multipliers at t = 0 (vi_sde.py:241-260); tiny per-trajectory d x d algebra."""
         pl = self.plan
