@@ -89,6 +89,41 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
     return out
 
 
+def vdp_step_rate(B, T, d, dt, noise, idx, ys, device, steps=10):
+    """
+    Secondary figure: the VDP (VariationalMarkovGP) inference step of VIMarkovGPTrainer.perform_inference on the same trajectories
+    (Lagrange sweep + parameter update, forward pass, ELBO), stabilize_system on, q started at the OU drift -4 x (from A = 0 the
+    marginal variance of a chain this long reaches T dt and the sixth-order moments overflow the first update).
+    """
+    import vidp_amd
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.sde import DoubleWellSDE
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    grid = np.arange(T) * dt
+    lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))
+    m = VariationalMarkovGP((grid[idx], torch.from_numpy(ys).to(device)), DoubleWellSDE(q=torch.eye(d, dtype=torch.float64)), grid, lik,
+                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=vidp_amd.Plan(B, T, d, device=device))
+    eye = (4.0 * torch.eye(d, dtype=torch.float64, device=device)).expand(B, T, d, d).contiguous()
+    m.plan.pack(vidp_amd.FULL, eye, out=m.A)
+    del eye
+    mS = m._forward_packed()
+    e = None
+    for it in range(3 + steps):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        m.update_lagrange_and_param(mS, lr=0.01)
+        mS = m._forward_packed()
+        e = m.elbo(mS)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    m.plan.check_info()
+    e = float(e)
+    assert np.isfinite(e), "non-finite VDP ELBO"
+    return {"value": steps / el, "unit": "ELBO steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "elbo_last": e,
+            "workload": f"VDP (VariationalMarkovGP) inference step on the same {B} trajectories, T={T}, d={d}, stabilize_system on"}
+
+
 def pmc_traffic(kernel_name, B, T, d):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc/pmc_traffic.json:
     separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same bench, read side doubled as the gfx950 guide
@@ -116,6 +151,7 @@ def main():
     ap.add_argument("--lr-girsanov", type=float, default=0.1)
     ap.add_argument("--obs-every", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vdp", action="store_true", help="skip the secondary VDP step measurement")
     args = ap.parse_args()
 
     import vidp_amd
@@ -257,6 +293,11 @@ def main():
                          "share_of_step": per_step * k_ms / ms_per_step})
         rows.sort(key=lambda r: -r["share_of_step"])
         out["roofline"] = dict(rows[0], other_kernels=rows[1:])
+        if world == 1 and not args.no_vdp:
+            # free the CVI-DP state first: the VDP model keeps its own ~15 GB resident
+            del model, f, s, tq, sp
+            torch.cuda.empty_cache()
+            out["vdp"] = vdp_step_rate(B, T, d, dt, noise, idx, ys, device)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise, first_elbo[0].cpu().numpy())
