@@ -1024,3 +1024,64 @@ def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind)
         for xa, xb in zip(sa, sb):
             assert np.isfinite(xb).all()
             np.testing.assert_allclose(xa, xb, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(xb).max()))
+
+
+def test_full_size_fused_model_steps(amd):
+    """
+    Headline size (B = 64, T = 100k, d = 6; the bench workload): two CVI-DP steps with the Girsanov update and the KL sum made inside
+    the backward sweeps against the same steps through the moment array, and one VDP step with the parameter update made inside the
+    Lagrange sweep against the two separate calls.  Per-trajectory ELBOs must agree: a property that does not need the CPU oracle.
+    """
+    import gc
+    import torch
+    import bench
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    B, T, d, dt, noise = 64, 100000, 6, 0.01, 0.1
+    idx, ys = bench.synth_double_well(B, T, d, dt, 50, noise, seed=5)
+    grid = np.arange(T) * dt
+    dev_ = torch.device("cuda", 0)
+    lik = lambda: MultivariateGaussian(torch.from_numpy(bench.obs_chol(d, noise)).to(dev_))
+    q = torch.eye(d, dtype=torch.float64)
+
+    def cvi(fused):
+        m = CVISitesSDE(gsde.DoubleWellSDE(q=q), grid, (grid[idx], torch.from_numpy(ys).to(dev_)), lik(),
+                        prior_initial_state=(np.zeros(d), np.eye(d)), plan=amd.Plan(B, T, d))
+        m.fused_girsanov = fused
+        out = []
+        for _ in range(2):
+            m.update_data_sites(0.5)
+            m.update_girsanov_sites(0.1)
+            out.append(host(m.classic_elbo_per_trajectory()))
+        m.plan.check_info()
+        return out
+
+    a = cvi(True)
+    gc.collect(); torch.cuda.empty_cache()
+    b = cvi(False)
+    gc.collect(); torch.cuda.empty_cache()
+    for ea, eb in zip(a, b):
+        assert np.isfinite(ea).all()
+        np.testing.assert_allclose(ea, eb, rtol=1e-9)
+
+    def vdp(fused):
+        m = VariationalMarkovGP((grid[idx], torch.from_numpy(ys).to(dev_)), gsde.DoubleWellSDE(q=q), grid, lik(),
+                                prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=amd.Plan(B, T, d))
+        m.plan.pack(amd.FULL, (4.0 * torch.eye(d, dtype=torch.float64, device=dev_)).expand(B, T, d, d).contiguous(), out=m.A)
+        mS = m._forward_packed()
+        if fused:
+            m.update_lagrange_and_param(mS, lr=0.01)
+        else:
+            m.update_lagrange(mS)
+            m.update_param(mS, lr=0.01)
+        e = host(m.elbo_per_trajectory(m._forward_packed()))
+        m.plan.check_info()
+        return e
+
+    ea = vdp(True)
+    gc.collect(); torch.cuda.empty_cache()
+    eb = vdp(False)
+    assert np.isfinite(ea).all()
+    np.testing.assert_allclose(ea, eb, rtol=1e-9)
