@@ -95,6 +95,20 @@ int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed
 int mfgm_node_io_pair(const mfgm_plan* plan, double* packed_vec, double* packed_sym, const long long* node_ids, int n,
                       double* values_vec, double* values_sym, int mode, double scale, void* stream);
 
+/* update_data_sites of the CVI models at the listed nodes (variational_cvi_sde.py:301-317) in one pass: sites <- (1 - lr) sites + lr g
+ * for the linear part (sites_vec, g_vec: natural [n, d]) and the diagonal-block part (sites_sym, g_sym: natural [n, d, d], symmetric),
+ * and packed_vec / packed_sym (the posterior naturals theta_lin VEC, theta_diag SYM) += new - old at those nodes.  d <= 8. */
+int mfgm_site_update_pair(const mfgm_plan* plan, double* packed_vec, double* packed_sym, const long long* node_ids, int n,
+                          double* sites_vec, double* sites_sym, const double* g_vec, const double* g_sym, double lr, void* stream);
+
+/* Variational expectations of a multivariate Gaussian likelihood N(y; f, R) at the observation nodes, per trajectory
+ * (multivariate_gaussian.py:80-115; variational_cvi_sde.py:319-337): sum_i -1/2 tr(Sinv Sigma_i) - 1/2 |y_i - mu_i|^2_Sinv + cst, as
+ * nb = ceil(n_per / 256) partial sums per trajectory: ve [B, nb] (the caller adds them).
+ * node_ids / y ([B * n_per], [B * n_per, d]) are trajectory-major; Sinv [d, d] = R^{-1} and cst = -log|chol R| - d/2 log(2 pi) on the
+ * device / by value; the gathered marginals go to out_mu [B n_per, d], out_cov [B n_per, d, d] when not NULL.  d <= 8. */
+int mfgm_mvn_obs_ve(const mfgm_plan* plan, const double* mu, const double* Sig, const long long* node_ids, int n_per, const double* y,
+                    const double* Sinv, double cst, double* out_mu, double* out_cov, double* ve, void* stream);
+
 /* SSM parameters -> natural parameters (cD=-0.5, cS=1; ssm_gaussian_transformations.py:182-253 `ssm_to_naturals`)
  * or precision blocks (cD=1, cS=-1; state_space_model.py:431-483 `_build_precision`), all packed:
  *   A (FULL, transition t->t+1 at node t), off (VEC: mu0 then b_k), chol (TRI: chol P0 then chol Q_k)

@@ -1085,3 +1085,51 @@ def test_full_size_fused_model_steps(amd):
     eb = vdp(False)
     assert np.isfinite(ea).all()
     np.testing.assert_allclose(ea, eb, rtol=1e-9)
+
+
+@pytest.mark.parametrize("d,B,T,n_obs", [(1, 2, 40, 5), (3, 3, 77, 9), (6, 2, 131, 300)])
+def test_site_update_and_obs_ve_kernels(amd, rng, d, B, T, n_obs):
+    """mfgm_site_update_pair and mfgm_mvn_obs_ve against the torch formulas they replace (blend + difference + scatter; gather +
+    multivariate-Gaussian variational expectations + per-trajectory sum)."""
+    import math
+    import torch
+    from vidp_amd.likelihoods import MultivariateGaussian
+    n_obs = min(n_obs, T - 1)
+    plan = amd.Plan(B, T, d, R0=8, Rup=3)
+    ti = np.stack([np.sort(rng.choice(T, size=n_obs, replace=False)) for _ in range(B)])
+    ids = plan.node_ids(ti)
+    n = B * n_obs
+    lin0, diag0 = dev(rng.normal(size=(B, T, d))), dev(rng.normal(size=(B, T, d, d)))
+    diag0 = diag0 + diag0.transpose(-1, -2)
+    pv, ps = plan.pack(amd.VEC, lin0), plan.pack(amd.SYM, diag0)
+    s1, s2 = dev(rng.normal(size=(n, d))), dev(rng.normal(size=(n, d, d)))
+    s2 = (s2 + s2.transpose(-1, -2)).contiguous()
+    g1, g2 = dev(rng.normal(size=(n, d))), dev(rng.normal(size=(n, d, d)))
+    g2 = (g2 + g2.transpose(-1, -2)).contiguous()
+    lr = 0.3
+    new1, new2 = (1 - lr) * s1 + lr * g1, (1 - lr) * s2 + lr * g2
+    ref_v, ref_s = pv.clone(), ps.clone()
+    plan.scatter_nodes_pair(ref_v, ref_s, ids, new1 - s1, new2 - s2)
+    a1, a2 = s1.clone(), s2.clone()
+    plan.site_update_pair(pv, ps, ids, a1, a2, g1, g2, lr)
+    np.testing.assert_allclose(host(a1), host(new1), rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(host(a2), host(new2), rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(host(plan.unpack(amd.VEC, pv)), host(plan.unpack(amd.VEC, ref_v)), rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(host(plan.unpack(amd.SYM, ps)), host(plan.unpack(amd.SYM, ref_s)), rtol=1e-13, atol=1e-14)
+
+    # variational expectations at the observation nodes
+    cov = dev(rng.normal(size=(B, T, d, d)))
+    cov = cov @ cov.transpose(-1, -2) + 0.5 * torch.eye(d, dtype=torch.float64, device="cuda")
+    mu = dev(rng.normal(size=(B, T, d)))
+    pm, pc = plan.pack(amd.VEC, mu), plan.pack(amd.SYM, cov)
+    cholR = np.linalg.cholesky(0.2 * np.eye(d) + 0.05 * np.ones((d, d)))
+    lik = MultivariateGaussian(dev(cholR))
+    y = dev(rng.normal(size=(n, d)))
+    om, oc = torch.empty((n, d), dtype=torch.float64, device="cuda"), torch.empty((n, d, d), dtype=torch.float64, device="cuda")
+    cst = -float(lik.log_det_chol) - 0.5 * d * math.log(2.0 * math.pi)
+    ve = plan.mvn_obs_ve(pm, pc, ids, n_obs, y, lik.inv_covariance, cst, out_mu=om, out_cov=oc)
+    gm, gc = plan.gather_nodes(amd.VEC, pm, ids), plan.gather_nodes(amd.SYM, pc, ids)
+    np.testing.assert_array_equal(host(om), host(gm))
+    np.testing.assert_array_equal(host(oc), host(gc))
+    ref = lik.variational_expectations(gm, gc, y).reshape(B, n_obs).sum(-1)
+    np.testing.assert_allclose(host(ve), host(ref), rtol=1e-12)

@@ -53,6 +53,9 @@ EXPORTS = {
     "mfgm_packed_selinv_mom_s": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
                                  + [ctypes.c_void_p] * 6),
     "mfgm_packed_sde_lean": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9),
+    "mfgm_site_update_pair": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_void_p]),
+    "mfgm_mvn_obs_ve": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+                        + [ctypes.c_void_p] * 4),
     "mfgm_packed_selinv_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
                               + [ctypes.c_void_p] * 7),
     "mfgm_packed_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]

@@ -218,6 +218,46 @@ int mfgm_node_io_pair(const mfgm_plan* plan, double* packed_vec, double* packed_
     return 0;
 }
 
+int mfgm_site_update_pair(const mfgm_plan* plan, double* packed_vec, double* packed_sym, const long long* node_ids, int n,
+                          double* sites_vec, double* sites_sym, const double* g_vec, const double* g_sym, double lr, void* stream) {
+    if (!plan || !packed_vec || !packed_sym || n < 0) return 1;
+    if (n == 0) return 0;
+    if (!node_ids || !sites_vec || !sites_sym || !g_vec || !g_sym) return 1;
+    const Plan& P = plan->p;
+    if (P.wide) return 1;
+    const size_t total = (size_t)n * (P.d + P.d * P.d);
+    if (total >= (1ull << 32) || (size_t)P.B * P.T >= (1ull << 32)) return 1;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_site_update_pair, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P.lv[0], P.T, P.d, packed_vec, packed_sym,
+                       node_ids, n, sites_vec, sites_sym, g_vec, g_sym, lr);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+template <int D>
+int mvn_obs_ve_impl(const Plan& P, const double* mu, const double* Sig, const long long* node_ids, int n_per, const double* y,
+                    const double* Sinv, double cst, double* out_mu, double* out_cov, double* ve, hipStream_t st) {
+    hipLaunchKernelGGL((k_mvn_obs_ve<D>), dim3((n_per + 255) / 256, P.B), dim3(256), 0, st, P.lv[0], P.T, mu, Sig, node_ids, n_per, y,
+                       Sinv, cst, out_mu, out_cov, ve);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int mfgm_mvn_obs_ve(const mfgm_plan* plan, const double* mu, const double* Sig, const long long* node_ids, int n_per, const double* y,
+                    const double* Sinv, double cst, double* out_mu, double* out_cov, double* ve, void* stream) {
+    if (!plan || !mu || !Sig || !node_ids || n_per < 1 || !y || !Sinv || !ve) return 1;
+    const Plan& P = plan->p;
+    if (P.wide || (size_t)P.B * P.T >= (1ull << 32)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (mvn_obs_ve_impl<DD>(P, mu, Sig, node_ids, n_per, y, Sinv, cst, out_mu, out_cov, ve, st)));
+}
+
 }  // extern "C"
 
 // ---- natural-layout convenience entry points ---------------------------------------------------------------------------

@@ -93,6 +93,98 @@ static __global__ __launch_bounds__(256) void k_node_io_pair(LevelDesc lv, int T
     }
 }
 
+// ---- CVI site update at the listed nodes (variational_cvi_sde.py:301-317) --------------------------------------------------------
+// sites <- (1 - lr) sites + lr g  and  packed += (new - old), for the linear part (natural [n, d]) and the full d x d diagonal-block
+// part (natural [n, d, d], symmetric; the packed array holds its lower triangle): the blend, the difference, the copy back and the
+// scatter of update_data_sites in one pass over the site arrays.
+static __global__ __launch_bounds__(256) void k_site_update_pair(LevelDesc lv, int T, int d, double* packed_vec, double* packed_sym,
+                                                                 const long long* __restrict__ node_ids, int n, double* sites_vec,
+                                                                 double* sites_sym, const double* __restrict__ g_vec,
+                                                                 const double* __restrict__ g_sym, double lr) {
+    const unsigned nv = (unsigned)n * d, total = nv + (unsigned)n * d * d;
+    const unsigned Et = d * (d + 1) / 2;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const bool vec = idx < nv;
+        const unsigned k = vec ? idx : idx - nv, En = vec ? d : d * d;
+        const unsigned i = k / En, ne = k - i * En;
+        double* sites = vec ? sites_vec : sites_sym;
+        const double old = sites[k], g = vec ? g_vec[k] : g_sym[k];
+        const double nw = (1.0 - lr) * old + lr * g;
+        sites[k] = nw;
+        unsigned Ep = d, e = ne;
+        if (!vec) {
+            const unsigned r = ne / d, c = ne - r * d;
+            if (c > r) continue;                      // the packed block is the lower triangle
+            Ep = Et;
+            e = tix(r, c);
+        }
+        const unsigned id = (unsigned)node_ids[i];
+        const unsigned b = id / (unsigned)T, t = id - b * (unsigned)T;
+        const unsigned p = t / lv.R, s = t - p * lv.R, lane = b * lv.P + p;
+        const size_t off = (((size_t)(lane >> 6) * lv.R + s) * Ep + e) * 64 + (lane & 63);
+        double* packed = vec ? packed_vec : packed_sym;
+        packed[off] += nw - old;
+    }
+}
+
+// ---- variational expectations of a multivariate Gaussian likelihood at the observation nodes -------------------------------------
+// ve[b] = sum_i { -1/2 tr(Sinv Sigma_i) - 1/2 (y_i - mu_i)^T Sinv (y_i - mu_i) } + n cst   (multivariate_gaussian.py:80-115), the
+// marginals gathered from the packed arrays (and written to out_mu [n, d], out_cov [n, d, d] for the callers that want them):
+// gather_nodes_pair, the element-wise VE arithmetic and the sum in one launch.  Block (x, b) sums observations x*256 ... of trajectory b
+// into ve[b * gridDim.x + x] (fixed order; the caller adds the few partials of a trajectory).  node_ids / y are trajectory-major with
+// n_per observations each.
+template <int D>
+static __global__ __launch_bounds__(256) void k_mvn_obs_ve(LevelDesc lv, int T, const double* __restrict__ mug,
+                                                          const double* __restrict__ Sigg, const long long* __restrict__ node_ids,
+                                                          int n_per, const double* __restrict__ y, const double* __restrict__ Sinv,
+                                                          double cst, double* __restrict__ out_mu, double* __restrict__ out_cov,
+                                                          double* __restrict__ ve) {
+    constexpr int ET = MFGM_NTRI(D);
+    __shared__ double sS[D * D];
+    __shared__ double red[256];
+    for (int e = threadIdx.x; e < D * D; e += blockDim.x) sS[e] = Sinv[e];
+    __syncthreads();
+    const int b = blockIdx.y;
+    double acc = 0.0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_per; j += gridDim.x * blockDim.x) {
+        const size_t i = (size_t)b * n_per + j;
+        const unsigned id = (unsigned)node_ids[i];
+        const unsigned cb = id / (unsigned)T, t = id - cb * (unsigned)T;
+        const unsigned p = t / lv.R, s = t - p * lv.R, lane = cb * lv.P + p;
+        const size_t nb = (size_t)(lane >> 6) * lv.R + s;       // node block: element e of a kind with E doubles at (nb * E + e) * 64 + lane % 64
+        double m[D], S[ET];
+#pragma unroll
+        for (int e = 0; e < D; ++e) m[e] = mug[(nb * D + e) * 64 + (lane & 63)];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) S[e] = Sigg[(nb * ET + e) * 64 + (lane & 63)];
+        double diff[D], v = 0.0;
+#pragma unroll
+        for (int r = 0; r < D; ++r) diff[r] = y[i * D + r] - m[r];
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int c = 0; c < D; ++c) v += sS[r * D + c] * (S[six(r, c)] + diff[r] * diff[c]);
+        acc += -0.5 * v + cst;
+        if (out_mu) {
+#pragma unroll
+            for (int e = 0; e < D; ++e) out_mu[i * D + e] = m[e];
+        }
+        if (out_cov) {
+#pragma unroll
+            for (int r = 0; r < D; ++r)
+#pragma unroll
+                for (int c = 0; c < D; ++c) out_cov[(i * D + r) * D + c] = S[six(r, c)];
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ve[(size_t)b * gridDim.x + blockIdx.x] = red[0];
+}
+
 // ---- SSM parameters -> natural parameters / precision blocks ---------------------------------------------
 // Per node t:  A (FULL, transition t -> t+1, unused at the last node), off (VEC: mu0 at node 0, b_{t-1} after),
 // chol (TRI: chol P0 at node 0, chol Q_{t-1} after).  Writes

@@ -156,6 +156,22 @@ class Plan:
         _lib.check(self.lib.mfgm_node_io_pair(self.h, _ptr(packed_vec), _ptr(packed_sym), _ptr(node_ids), node_ids.numel(),
                                               _ptr(values_vec), _ptr(values_sym), 2, float(scale), _stream()), "mfgm_node_io_pair(scatter)")
 
+    def site_update_pair(self, packed_vec, packed_sym, node_ids, sites_vec, sites_sym, g_vec, g_sym, lr):
+        """sites <- (1 - lr) sites + lr g (in place) and packed += new - old at the listed nodes, in one launch (d <= 8)."""
+        for t in (sites_vec, sites_sym, g_vec, g_sym):
+            assert t.is_contiguous()
+        _lib.check(self.lib.mfgm_site_update_pair(self.h, _ptr(packed_vec), _ptr(packed_sym), _ptr(node_ids), node_ids.numel(),
+                                                  _ptr(sites_vec), _ptr(sites_sym), _ptr(g_vec), _ptr(g_sym), float(lr), _stream()),
+                   "mfgm_site_update_pair")
+
+    def mvn_obs_ve(self, mu, Sig, node_ids, n_per, y, Sinv, cst, out_mu=None, out_cov=None):
+        """Per-trajectory variational expectations of a multivariate Gaussian likelihood at the observation nodes, gathered from the
+        packed marginals in the same launch (d <= 8).  y: [B * n_per, d] trajectory-major; returns ve [B]."""
+        ve = torch.empty((self.B, (int(n_per) + 255) // 256), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_mvn_obs_ve(self.h, _ptr(mu), _ptr(Sig), _ptr(node_ids), int(n_per), _ptr(y), _ptr(Sinv), float(cst),
+                                            _ptr(out_mu), _ptr(out_cov), _ptr(ve), _stream()), "mfgm_mvn_obs_ve")
+        return ve.sum(-1)
+
     def ssm_to_naturals(self, A, off, chol, precision=False, want_logdet=False, out=None):
         """Packed SSM parameters -> naturals (or precision blocks).  Returns dict(lin, diag, sub, sumlogchol)."""
         out = {} if out is None else out

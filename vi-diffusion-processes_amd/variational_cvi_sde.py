@@ -10,6 +10,7 @@ Same method names as the reference (`full_sites`, `dist_q`, `update_data_sites`,
   * all per-time-step state (prior naturals, Girsanov sites, posterior naturals, marginals) lives in the
     packed device layout and is refreshed once per site update, not once per property access.
 """
+import math
 import os
 
 import torch
@@ -143,6 +144,9 @@ class CVISitesSSM:
         return self._theta_q
 
     _need_sub = True     # the linear-prior KL (kl_terms) reads the full cross-covariance blocks
+    # site update / observation-node variational expectations in one launch each (VIDP_FUSED_OBS=0: torch arithmetic around the
+    # sparse gather / scatter kernels)
+    fused_obs_kernels = os.environ.get("VIDP_FUSED_OBS", "1") != "0"
 
     def _sweep_fusion(self):
         """True when the level-0 backward sweep can do the model's local work itself (CVISitesSDE, mfgm_girsanov.h)."""
@@ -220,12 +224,18 @@ class CVISitesSSM:
         mu_o, cov_o = self._obs_marginals()
         self._started = True      # before the first update the marginals are those of the initial posterior path
         g1, g2 = self.likelihood.ve_gradients_expectation(mu_o, cov_o, self._obs_flat())
-        new1 = (1 - lr) * self.data_nat1 + lr * g1
-        new2 = (1 - lr) * self.data_nat2 + lr * g2
         tq = self.full_sites()
-        self.plan.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, new1 - self.data_nat1, new2 - self.data_nat2)
-        self.data_nat1.copy_(new1)
-        self.data_nat2.copy_(new2)
+        if (self.fused_obs_kernels and self.plan.d <= 8 and g1.shape == self.data_nat1.shape and g2.shape == self.data_nat2.shape
+                and self.data_nat1.is_contiguous() and self.data_nat2.is_contiguous()):
+            # blend, difference, copy back and scatter in one pass over the site arrays
+            self.plan.site_update_pair(tq.lin, tq.diag, self.obs_node_ids, self.data_nat1, self.data_nat2, g1.contiguous(),
+                                       g2.contiguous(), lr)
+        else:
+            new1 = (1 - lr) * self.data_nat1 + lr * g1
+            new2 = (1 - lr) * self.data_nat2 + lr * g2
+            self.plan.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, new1 - self.data_nat1, new2 - self.data_nat2)
+            self.data_nat1.copy_(new1)
+            self.data_nat2.copy_(new2)
         self._q = None
         self._obs_fresh = False   # marginals at the observation times are gathered lazily, when next needed
 
@@ -255,9 +265,20 @@ class CVISitesSSM:
     # -- objective -----------------------------------------------------------------------------------------
     def variational_expectation(self):
         """sum_i E_q log p(y_i | x_i), per trajectory [B] (variational_cvi_sde.py:319-337)."""
+        lik = self.likelihood
+        if self.fused_obs_kernels and self.plan.d <= 8 and hasattr(lik, "inv_covariance") and hasattr(lik, "log_det_chol"):
+            # multivariate Gaussian likelihood: gather, element-wise arithmetic and per-trajectory sum in one launch (it also
+            # refreshes the gathered marginals)
+            q = self._refresh()
+            if getattr(lik, "_ve_cst", None) is None:
+                lik._ve_cst = -float(lik.log_det_chol) - 0.5 * lik.obs_dim * math.log(2.0 * math.pi)
+            ve = self.plan.mvn_obs_ve(q["mu"], q["Sig"], self.obs_node_ids, self.n_obs, self._obs_flat(), lik.inv_covariance,
+                                      lik._ve_cst, out_mu=self.fx_mus_obs, out_cov=self.fx_covs_obs)
+            self._obs_fresh = True
+            return ve
         if self._q is None or not getattr(self, "_obs_fresh", False):
             self._gather_obs()
-        ve = self.likelihood.variational_expectations(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
+        ve = lik.variational_expectations(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
         return ve.reshape(self.B, self.n_obs).sum(-1)
 
     def KL_q_p(self):
