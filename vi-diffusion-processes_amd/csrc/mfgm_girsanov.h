@@ -99,6 +99,83 @@ MFGM_DEV void girsanov_store_lin(const SdeParams& pr, const GirsanovArgs& g, int
     st_node<D>(g.n1, R, s, w, a1);
 }
 
+// ---- the step of the level-0 backward sweep that both kernels below share (k_backward's USE_S variant: L_{t+1,t} rebuilt from theta_sub) ----
+// first half: X = L^{-1}, P = L^{-T} L^{-1} (left in Sig), H = L_{t+1,t} L^{-1} = aS S P, tg = S^T x_next
+template <int D>
+MFGM_DEV void backward_s_head(const double (&Lt)[MFGM_NTRI(D)], const double (&G)[D * D], double aS, const double (&xn)[D],
+                              double (&invd)[D], double (&X)[MFGM_NTRI(D)], double (&Sig)[MFGM_NTRI(D)], double (&H)[D * D],
+                              double (&tg)[D]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
+    tri_inverse<D>(Lt, invd, X);
+    tri_t_tri<D>(X, Sig);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Sig[six(k, j)], t);
+            H[i * D + j] = aS * t;
+        }
+    gemv_t<D>(G, xn, tg);
+}
+// second half: Sigma_{t+1,t} = -Sigma_{t+1} H (Ssub), Sigma_t = P - Sigma_{t+1,t}^T H (Sig), mean x = L^{-T} (y - L^{-1} aS tg) (x holds y on entry)
+template <int D>
+MFGM_DEV void backward_s_tail(const double (&Lt)[MFGM_NTRI(D)], const double (&invd)[D], const double (&X)[MFGM_NTRI(D)], double aS,
+                              const double (&Sn)[MFGM_NTRI(D)], const double (&H)[D * D], const double (&tg)[D],
+                              double (&Sig)[MFGM_NTRI(D)], double (&Ssub)[D * D], double (&x)[D]) {
+    gemm_sym_full<D>(Sn, H, Ssub);
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) Ssub[e] = -Ssub[e];
+    gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);
+    double u[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k <= i; ++k) acc = __builtin_fma(X[tix(i, k)], tg[k], acc);
+        u[i] = aS * acc;
+    }
+#pragma unroll
+    for (int e = 0; e < D; ++e) x[e] -= u[e];
+    trsv_lower_t<D>(Lt, invd, x);
+}
+// the separator on the left of a segment: +Sigma_{t0} H of its transition (the caller negates), from its L and theta_sub blocks
+template <int D>
+MFGM_DEV void backward_s_left(const SweepArgs& a, int R, LaneRef left, const double (&Sn)[MFGM_NTRI(D)], double (&G)[D * D],
+                              double (&SnH)[D * D]) {
+    constexpr int ET = MFGM_NTRI(D);
+    double Lt[ET], invd[D], X[ET], H[D * D], Pm[ET];
+    ld_node<ET>(a.Lg, R, R - 1, left, Lt);
+    ld_node<D * D>(a.Sg, R, R - 1, left, G);
+#pragma unroll
+    for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
+    tri_inverse<D>(Lt, invd, X);
+    tri_t_tri<D>(X, Pm);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Pm[six(k, j)], t);
+            H[i * D + j] = a.aS * t;
+        }
+    gemm_sym_full<D>(Sn, H, SnH);
+}
+// (mu, diag Sigma) of node q of the coarser level
+template <int D>
+MFGM_DEV void up_moments(const SweepArgs& a, int b, int q, double (&m)[D], double (&v)[D]) {
+    constexpr int ET = MFGM_NTRI(D);
+    const int uP = a.up.P, uR = a.up.R, ul = b * uP + q / uR, us = q % uR;
+    const LaneRef uw = LaneRef::of(ul);
+    ld_node<D>(a.umu, uR, us, uw, m);
+    const double* ps = a.uSig + ((size_t)uw.tile * uR + us) * (size_t)(ET * 64);
+#pragma unroll
+    for (int i = 0; i < D; ++i) v[i] = ps[tix(i, i) * 64 + uw.l];
+}
+
 // Level-0 backward sweep (always below a coarser level, means wanted, L_{t+1,t} rebuilt from theta_sub: the USE_S variant of
 // k_backward) that writes the updated theta_q instead of the marginals.
 template <int D>
@@ -159,42 +236,12 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov(SweepArgs a, Sd
                 ld_node<EF>(a.Sg, R, s - 1, me, Gn);
                 ld_node<D>(a.yg, R, s - 1, me, yn);
             }
-            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET];
-#pragma unroll
-            for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
-            tri_inverse<D>(Lt, invd, X);
-            tri_t_tri<D>(X, Sig);                 // P = L^{-T} L^{-1}
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Sig[six(k, j)], t);
-                    H[i * D + j] = a.aS * t;      // H = L_{t+1,t} L_tt^{-1} = aS S P
-                }
-            double tg[D], Gd[D];
-            gemv_t<D>(G, xn, tg);
-            girsanov_store_sub_offdiag<D>(pr, g, R, s, me, true, G);
+            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET], tg[D], Gd[D];
+            backward_s_head<D>(Lt, G, a.aS, xn, invd, X, Sig, H, tg);
+            girsanov_store_sub_offdiag<D>(pr, g, R, s, me, true, G);      // the raw theta_sub block is not needed any further
 #pragma unroll
             for (int i = 0; i < D; ++i) Gd[i] = G[i * D + i];
-            gemm_sym_full<D>(Sn, H, Ssub);
-#pragma unroll
-            for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
-            gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);
-            {
-                double u[D];
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int k = 0; k <= i; ++k) acc = __builtin_fma(X[tix(i, k)], tg[k], acc);
-                    u[i] = a.aS * acc;
-                }
-#pragma unroll
-                for (int e = 0; e < D; ++e) x[e] -= u[e];
-                trsv_lower_t<D>(Lt, invd, x);
-            }
+            backward_s_tail<D>(Lt, invd, X, a.aS, Sn, H, tg, Sig, Ssub, x);
             double v[D], c[D], lin[D], dg[D], sb[D], wd[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) { v[i] = Sig[tix(i, i)]; c[i] = Ssub[i * D + i]; }
@@ -219,32 +266,10 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov(SweepArgs a, Sd
     if (p > 0) {
         // the separator on the left: Sigma_{t0, t0-1} as in k_backward, then its theta~ (its moments come from the coarser level)
         const LaneRef left = LaneRef::of(lane - 1);
-        double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF], Pm[ET];
-        ld_node<ET>(a.Lg, R, R - 1, left, Lt);
-        ld_node<EF>(a.Sg, R, R - 1, left, G);
-#pragma unroll
-        for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
-        tri_inverse<D>(Lt, invd, X);
-        tri_t_tri<D>(X, Pm);
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Pm[six(k, j)], t);
-                H[i * D + j] = a.aS * t;
-            }
-        gemm_sym_full<D>(Sn, H, Ssub);
+        double G[EF], Ssub[EF];
+        backward_s_left<D>(a, R, left, Sn, G, Ssub);
         double m[D], v[D], c[D], lin[D], dg[D], sb[D], zero[D];
-        {
-            const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
-            const LaneRef uw = LaneRef::of(ul);
-            ld_node<D>(a.umu, uR, us, uw, m);
-            const double* ps = a.uSig + ((size_t)uw.tile * uR + us) * (size_t)(ET * 64);
-#pragma unroll
-            for (int i = 0; i < D; ++i) v[i] = ps[tix(i, i) * 64 + uw.l];
-        }
+        up_moments<D>(a, b, p - 1, m, v);
 #pragma unroll
         for (int i = 0; i < D; ++i) { c[i] = -Ssub[i * D + i]; zero[i] = 0.0; }
         girsanov_node<D>(pr, true, m, v, c, xn, lin, dg, sb, wprev);
@@ -339,39 +364,9 @@ static __global__ __launch_bounds__(64) void k_backward_kl(SweepArgs a, SdeParam
                 ld_node<EF>(a.Sg, R, s - 1, me, Gn);
                 ld_node<D>(a.yg, R, s - 1, me, yn);
             }
-            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET];
-#pragma unroll
-            for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
-            tri_inverse<D>(Lt, invd, X);
-            tri_t_tri<D>(X, Sig);
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Sig[six(k, j)], t);
-                    H[i * D + j] = a.aS * t;
-                }
-            double tg[D];
-            gemv_t<D>(G, xn, tg);
-            gemm_sym_full<D>(Sn, H, Ssub);
-#pragma unroll
-            for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
-            gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);
-            {
-                double u[D];
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int k = 0; k <= i; ++k) t = __builtin_fma(X[tix(i, k)], tg[k], t);
-                    u[i] = a.aS * t;
-                }
-#pragma unroll
-                for (int e = 0; e < D; ++e) x[e] -= u[e];
-                trsv_lower_t<D>(Lt, invd, x);
-            }
+            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET], tg[D];
+            backward_s_head<D>(Lt, G, a.aS, xn, invd, X, Sig, H, tg);
+            backward_s_tail<D>(Lt, invd, X, a.aS, Sn, H, tg, Sig, Ssub, x);
             st_node<D>(a.mug, R, s, me, x);
             st_node<ET>(a.Sigg, R, s, me, Sig);
             double v[D], c[D], vn[D];
@@ -387,32 +382,10 @@ static __global__ __launch_bounds__(64) void k_backward_kl(SweepArgs a, SdeParam
     if (p > 0) {
         // the transition out of the separator on the left (its own moments come from the coarser level)
         const LaneRef left = LaneRef::of(lane - 1);
-        double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF], Pm[ET];
-        ld_node<ET>(a.Lg, R, R - 1, left, Lt);
-        ld_node<EF>(a.Sg, R, R - 1, left, G);
-#pragma unroll
-        for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
-        tri_inverse<D>(Lt, invd, X);
-        tri_t_tri<D>(X, Pm);
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Pm[six(k, j)], t);
-                H[i * D + j] = a.aS * t;
-            }
-        gemm_sym_full<D>(Sn, H, Ssub);
+        double G[EF], Ssub[EF];
+        backward_s_left<D>(a, R, left, Sn, G, Ssub);
         double m[D], v[D], c[D], vn[D];
-        {
-            const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
-            const LaneRef uw = LaneRef::of(ul);
-            ld_node<D>(a.umu, uR, us, uw, m);
-            const double* ps = a.uSig + ((size_t)uw.tile * uR + us) * (size_t)(ET * 64);
-#pragma unroll
-            for (int i = 0; i < D; ++i) v[i] = ps[tix(i, i) * 64 + uw.l];
-        }
+        up_moments<D>(a, b, p - 1, m, v);
 #pragma unroll
         for (int i = 0; i < D; ++i) { c[i] = -Ssub[i * D + i]; vn[i] = Sn[tix(i, i)]; }
         acc += kl_transition<D>(pr, m, v, c, xn, vn);
