@@ -8,6 +8,7 @@ update_lagrange (with an O(T) tensor copy per step) is a partitioned affine recu
 Prior / initial distributions are (mean [d], covariance [d, d]) pairs.
 """
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -271,10 +272,16 @@ class VariationalMarkovGP:
     def elbo_per_trajectory(self, mS=None):
         pl = self.plan
         m, S = mS if mS is not None else self._forward_packed()
-        mu = pl.gather_nodes(VEC, m, self.obs_node_ids)
-        cov = pl.gather_nodes(SYM, S, self.obs_node_ids)
         n, d = self.B * self.n_obs, self.state_dim
-        e_obs = self.likelihood.variational_expectations(mu, cov, self.observations.reshape(n, d)).reshape(self.B, self.n_obs).sum(-1)
+        lik = self.likelihood
+        if pl.d <= 8 and hasattr(lik, "inv_covariance") and hasattr(lik, "log_det_chol"):
+            # multivariate Gaussian likelihood: gather, arithmetic and per-trajectory sums in one launch
+            cst = -float(lik.log_det_chol) - 0.5 * lik.obs_dim * math.log(2.0 * math.pi)
+            e_obs = pl.mvn_obs_ve(m, S, self.obs_node_ids, self.n_obs, self.observations.reshape(n, d).contiguous(), lik.inv_covariance, cst)
+        else:
+            mu = pl.gather_nodes(VEC, m, self.obs_node_ids)
+            cov = pl.gather_nodes(SYM, S, self.obs_node_ids)
+            e_obs = lik.variational_expectations(mu, cov, self.observations.reshape(n, d)).reshape(self.B, self.n_obs).sum(-1)
         # the reference re-runs forward_pass inside E_sde() (vi_sde.py:443): identical parameters, identical value
         return e_obs - self.E_sde((m, S)) - self.KL_initial_state()
 
