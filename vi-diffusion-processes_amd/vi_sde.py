@@ -259,15 +259,22 @@ class VariationalMarkovGP:
     def KL_initial_state(self):
         """KL[q(x0) || p(x0)] per trajectory (vi_sde.py:416-420)."""
         d = self.state_dim
-        P0 = torch.from_numpy(self.p0_cov).to(self.device)
-        mu0 = torch.from_numpy(self.p0_mu).to(self.device)
-        P0inv = linalg.spd_inverse(P0)
+        mu0, P0inv, ldP0 = self._prior_x0_device()
         S0 = self.q0_chol @ self.q0_chol.transpose(-1, -2)
         dm = mu0 - self.q0_mu
         tr = (P0inv * S0).sum(dim=(-1, -2))
         mh = ((dm @ P0inv) * dm).sum(-1)
         ld0 = 2.0 * torch.log(torch.diagonal(self.q0_chol, dim1=-2, dim2=-1)).sum(-1)
-        return 0.5 * (tr + mh - d + linalg.logdet_spd(P0) - ld0)
+        return 0.5 * (tr + mh - d + ldP0 - ld0)
+
+    def _prior_x0_device(self):
+        """(mu0, P0^{-1}, log det P0) of the prior initial state on the device: computed once per (p0_mu, p0_cov), not on every
+        ELBO evaluation (two host-to-device copies and a dozen d x d launches each time otherwise)."""
+        key = (self.p0_mu.tobytes(), self.p0_cov.tobytes())
+        if getattr(self, "_p0_dev", (None,))[0] != key:
+            P0 = torch.from_numpy(self.p0_cov).to(self.device)
+            self._p0_dev = (key, torch.from_numpy(self.p0_mu).to(self.device), linalg.spd_inverse(P0), linalg.logdet_spd(P0))
+        return self._p0_dev[1:]
 
     def elbo_per_trajectory(self, mS=None):
         pl = self.plan
