@@ -25,6 +25,8 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         // segment summaries, per-chain scan of the segment maps, final sweep (what == 5: the sweep also makes update_param)
         double* Aw = const_cast<double*>(a2);
         double* bw = const_cast<double*>(a3);
+        hipLaunchKernelGGL((k_vdp_lagrange_products<D>), grid, block, 0, st, lv, pr, a2, o2);
+        MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 0>), dim3(P.B), block, 0, st, lv, o2);

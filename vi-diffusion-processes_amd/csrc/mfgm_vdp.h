@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, con
 // ---- update_lagrange ------------------------------------------------------------------------------------------------
 // yR (VEC) = R^{-1} y at observation nodes (zero elsewhere), dobsS (SYM) = -1/2 R^{-1} at observation nodes: the jump
 // conditions d_obs_m = yR + 2 dobsS m, d_obs_S = dobsS (vi_sde.py:262-287 for a Gaussian likelihood).
-// PASS 1: per-segment affine summary (Mpsi, Cpsi, Mlam, Clam) with zero input; PASS 3: the sweep from the known value
+// PASS 1: the offsets (Cpsi, Clam) of the per-segment affine maps, i.e. the sweep with zero input (their linear parts Mpsi, Mlam come
+// from k_vdp_lagrange_products); PASS 3: the sweep from the known value
 // at the segment's last node (bpsi, blam: [lanes] arrays written by k_vdp_lagrange_scan_wave).
 // PASS 4: PASS 3 that also makes update_param at every node it visits (A, b replaced in place; with pr.clip > 0 the stored psi /
 // lambda are the clipped values update_param would leave, the recurrence itself continues with the unclipped ones).
@@ -308,13 +309,13 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
     const int len = min(R, n - p * R);
     (void)b;
     const int N = n - 1;                     // number of transitions; psi / lambda live on nodes 0 .. N-1
-    // state: psi (full), lam; in PASS 1 also the running products
-    double psi[EF], lam[D], Mp[EF], Ml[EF];
+    // state: psi (full), lam (the running products of the segment maps are k_vdp_lagrange_products' job)
+    double psi[EF], lam[D];
     if (PASS == 1) {
 #pragma unroll
-        for (int e = 0; e < EF; ++e) { psi[e] = 0.0; Mp[e] = 0.0; Ml[e] = 0.0; }
+        for (int e = 0; e < EF; ++e) psi[e] = 0.0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) { lam[i] = 0.0; Mp[i * D + i] = 1.0; Ml[i * D + i] = 1.0; }
+        for (int i = 0; i < D; ++i) lam[i] = 0.0;
     } else {
         // boundary value at this segment's last node (slot layout: seg2[(e)*Lpad + lane])
         const double* bnd = seg + (size_t)SEG * Lp;
@@ -390,17 +391,6 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                         for (int j = 0; j < D; ++j)
                             psi[i * D + j] = psi[i * D + j] - pr.dt * (2.0 * pa[i * D + j] - dS[six(i, j)]) - dob[six(i, j)];
                     }
-                    if (PASS == 1) {
-                        // running products: Mp <- Mp (I - 2 dt A),  Ml <- (I - dt A) Ml
-                        double t1[EF], t2[EF];
-                        gemm<D>(Mp, A, t1);
-                        gemm<D>(A, Ml, t2);
-#pragma unroll
-                        for (int e = 0; e < EF; ++e) {
-                            Mp[e] -= 2.0 * pr.dt * t1[e];
-                            Ml[e] -= pr.dt * t2[e];
-                        }
-                    }
                 }
             }
         }
@@ -408,13 +398,53 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
     if (PASS == 1) {
         // psi / lam now hold the affine offsets (C) of the segment map: value entering the previous segment's last node
 #pragma unroll
-        for (int e = 0; e < EF; ++e) {
-            seg[(size_t)e * Lp + lane] = Mp[e];
-            seg[(size_t)(EF + e) * Lp + lane] = psi[e];
-            seg[(size_t)(2 * EF + e) * Lp + lane] = Ml[e];
-        }
+        for (int e = 0; e < EF; ++e) seg[(size_t)(EF + e) * Lp + lane] = psi[e];
 #pragma unroll
         for (int i = 0; i < D; ++i) seg[(size_t)(3 * EF + i) * Lp + lane] = lam[i];
+    }
+}
+
+// The linear parts of the segment maps: Mpsi = prod (I - 2 dt A_t), Mlam = prod (I - dt A_t) over the segment's transitions
+// t >= 1, in the order the sweep visits them.  They depend on A alone: a pass of their own reads 8 d^2 bytes per node with the
+// next block prefetched, and relieves PASS 1 (which otherwise carries 3 d^2 + d more doubles of state than it has registers for).
+template <int D>
+__global__ __launch_bounds__(64) void k_vdp_lagrange_products(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
+                                                             double* __restrict__ seg) {
+    constexpr int EF = D * D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n, Lp = lv.Lpad;
+    const int p = lane % P;
+    const int len = min(R, n - p * R);
+    const int N = n - 1;
+    double Mp[EF], Ml[EF], An[EF];
+#pragma unroll
+    for (int e = 0; e < EF; ++e) { Mp[e] = 0.0; Ml[e] = 0.0; An[e] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Mp[i * D + i] = 1.0; Ml[i * D + i] = 1.0; }
+    // nodes of this segment that take part: s with 1 <= t = p R + s <= N - 1
+    const int s_hi = min(len - 1, N - 1 - p * R), s_lo = (p == 0) ? 1 : 0;
+    if (s_hi >= s_lo) ld_node<EF>(Am, R, s_hi, me, An);
+    for (int s = R - 1; s >= 0; --s) {
+        if (s <= s_hi && s >= s_lo) {
+            double A[EF], t1[EF], t2[EF];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) A[e] = An[e];
+            if (s - 1 >= s_lo) ld_node<EF>(Am, R, s - 1, me, An);
+            gemm<D>(Mp, A, t1);
+            gemm<D>(A, Ml, t2);
+#pragma unroll
+            for (int e = 0; e < EF; ++e) {
+                Mp[e] -= 2.0 * pr.dt * t1[e];
+                Ml[e] -= pr.dt * t2[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EF; ++e) {
+        seg[(size_t)e * Lp + lane] = Mp[e];
+        seg[(size_t)(2 * EF + e) * Lp + lane] = Ml[e];
     }
 }
 
