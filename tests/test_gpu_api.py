@@ -942,7 +942,10 @@ def test_variational_markov_gp_stabilized(amd, rng):
         assert_close(host(plan.unpack(amd.FULL, g.A, T - 1))[0], o.A)
         assert_close(host(plan.unpack(amd.VEC, g.b, T - 1))[0], o.b)
     assert clipped                                   # the scenario does exercise the clipping
-    # the clipped transitions T_t, read back from the sub-diagonal precision blocks -W T_t of the last forward pass (W = 1 / (dt q))
+    # the clipped transitions T_t, read back from the sub-diagonal precision blocks -W T_t of a forward pass over the precision
+    # route (W = 1 / (dt q))
+    g.forward_mode = "precision"
+    g._forward_packed()
     sub = host(plan.unpack(amd.FULL, g._fw["nat"][2], T - 1))
     ssm_A = np.abs(sub * (g.dt * np.asarray(g.prior_sde.q_diag))[:, None]).max()
     assert ssm_A <= 1.0 + 1e-12
@@ -1133,3 +1136,44 @@ def test_site_update_and_obs_ve_kernels(amd, rng, d, B, T, n_obs):
     np.testing.assert_array_equal(host(oc), host(gc))
     ref = lik.variational_expectations(gm, gc, y).reshape(B, n_obs).sum(-1)
     np.testing.assert_allclose(host(ve), host(ref), rtol=1e-12)
+
+
+@pytest.mark.parametrize("d,B,T,stab", [(1, 2, 60, False), (2, 3, 700, False), (3, 2, 141, True), (6, 2, 90, False)])
+def test_vdp_forward_pass_routes_agree(amd, rng, d, B, T, stab):
+    """forward_pass as the partitioned moment recursion, over precision blocks + factorisation + selected inverse, and over explicit
+    SSM arrays: the same marginals (per-trajectory q(x0), random contractive drifts, ragged last segment, > 64 segments)."""
+    import torch
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    dt = 0.01
+    grid = np.arange(T) * dt
+    idx = np.arange(5, T - 1, 9)
+    y = rng.normal(size=(B, len(idx), d))
+    g = VariationalMarkovGP((grid[idx], dev(y)), gsde.OrnsteinUhlenbeckSDE(0.9, torch.eye(d, dtype=torch.float64)), grid,
+                            MultivariateGaussian(dev(0.5 * np.eye(d))), prior_initial_state=(np.zeros(d), 0.5 * np.eye(d)),
+                            stabilize_system=stab, plan=amd.Plan(B, T, d, R0=8, Rup=3))
+    A = 3.0 * rng.normal(size=(B, T, d, d)) + 4.0 * np.eye(d)
+    b = (120.0 if stab else 2.0) * rng.normal(size=(B, T, d))          # stabilised: offsets dt b beyond [-1, 1] are clipped
+    if stab:
+        # some strictly upper-triangular entries of I - dt A leave [-1, 1] and are clipped, a few are NaN and become 1e-8; the
+        # transitions stay (non-normal but) contractive, as a chain the clipping is meant to rescue
+        A = np.triu(A)
+        mask = np.triu(rng.random((B, T, d, d)) < 0.15, 1)
+        A = np.where(mask, 150.0 * np.sign(rng.normal(size=A.shape)), A)
+        A = np.where(np.triu(rng.random((B, T, d, d)) < 0.02, 1), np.nan, A)
+    g.plan.pack(amd.FULL, dev(A), out=g.A)
+    g.plan.pack(amd.VEC, dev(b), out=g.b)
+    g.q0_mu = dev(rng.normal(size=(B, d)))
+    L0 = np.tril(rng.normal(size=(B, d, d)), -1) * 0.2 + np.eye(d) * (0.5 + rng.random((B, d, 1)))
+    g.q0_chol = dev(L0)
+    out = {}
+    for mode in ("moments", "precision", "ssm"):
+        g.forward_mode = mode
+        m, S = g.forward_pass
+        g.plan.check_info()
+        out[mode] = (host(m), host(S))
+    for mode in ("precision", "ssm"):
+        for xa, xb in zip(out["moments"], out[mode]):
+            assert np.isfinite(xa).all()
+            np.testing.assert_allclose(xa, xb, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(xb).max()))

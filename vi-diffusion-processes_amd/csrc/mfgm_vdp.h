@@ -22,6 +22,13 @@ struct VdpParams {
     double clip;           // > 0: NaN scrubbing and clipping of the Lagrange sweep's inputs (stabilize_system)
 };
 
+// value of x in lane `src` (uniform) of the wavefront
+MFGM_DEV double vdp_bcast(double x, int src) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 MFGM_DEV double vdp_stab(double x, double c) {
     x = (x != x) ? 1e-8 : x;
     return fmin(fmax(x, -c), c);
@@ -253,6 +260,217 @@ __global__ __launch_bounds__(64) void k_vdp_to_naturals(LevelDesc lv, VdpParams 
     }
 }
 
+// ---- forward_pass as the moment recursion it is in the reference (vi_sde.py:171-204: the marginals of the SSM) --------------------
+//   m_{t+1} = T_t m_t + o_{t+1},   S_{t+1} = T_t S_t T_t^T + Q        (T_t = I - dt A_t, o_{t+1} = dt b_t, Q = diag(dt q))
+// is an affine recurrence for m and a linear one for S, so it partitions like the Lagrange sweep: PASS 1 composes a segment's
+// transitions into (Phi, Qacc, macc) with  value(first node of segment p+1) = Phi value(first node of p) Phi^T + Qacc  (and
+// Phi m + macc), a wavefront per chain chains the segment maps from q(x0), PASS 3 sweeps each segment from its first node.
+// 42 doubles read twice and 27 written per node, against 348 for the route over precision blocks, factorisation and selected
+// inverse; and a sum of positive semi-definite terms instead of an inverse.
+template <int D>
+MFGM_DEV void vdp_transition(const VdpParams& pr, double (&A)[D * D], double (&o)[D]) {
+    // in: A_t, b_t; out: T_t = I - dt A_t, o_{t+1} = dt b_t (stabilize_system: NaN -> 1e-8, clipped to [-1, 1])
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A[e] = -pr.dt * A[e];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { A[i * D + i] += 1.0; o[i] = pr.dt * o[i]; }
+    if (pr.clip > 0.0) {
+#pragma unroll
+        for (int e = 0; e < D * D; ++e) A[e] = vdp_stab(A[e], 1.0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) o[i] = vdp_stab(o[i], 1.0);
+    }
+}
+// S <- Phi S Phi^T + Qd  (S, result: packed lower triangles; Qd added on the diagonal when given)
+template <int D>
+MFGM_DEV void vdp_congruence(const double (&Phi)[D * D], double (&S)[MFGM_NTRI(D)]) {
+    double PS[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t = __builtin_fma(Phi[i * D + k], S[six(k, j)], t);
+            PS[i * D + j] = t;
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t = __builtin_fma(PS[i * D + k], Phi[j * D + k], t);
+            S[tix(i, j)] = t;
+        }
+}
+template <int D>
+MFGM_DEV void vdp_advance(const VdpParams& pr, const double (&T)[D * D], const double (&o)[D], double (&m)[D],
+                          double (&S)[MFGM_NTRI(D)]) {
+    double t[D];
+    gemv<D>(T, m, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = t[i] + o[i];
+    vdp_congruence<D>(T, S);
+#pragma unroll
+    for (int i = 0; i < D; ++i) S[tix(i, i)] += pr.dt * pr.q[i];
+}
+
+// seg layout (doubles per lane, element e at seg[e * Lpad + lane]): Phi [d^2], Qacc [ET], macc [d]; then the boundary values
+// m [d], S [ET] at the segment's first node.
+template <int D, int PASS>
+__global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
+                                                     const double* __restrict__ bm, double* __restrict__ mug,
+                                                     double* __restrict__ Sigg, double* __restrict__ seg) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const size_t Lp = lv.Lpad;
+    const int p = lane % P;
+    const int len = min(R, n - p * R);
+    const int nt = min(len, n - 1 - p * R);        // transitions that start in this segment: nodes s < nt
+    double m[D], S[ET], Phi[EF];
+    if (PASS == 1) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Phi[e] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) { Phi[i * D + i] = 1.0; m[i] = 0.0; }
+#pragma unroll
+        for (int e = 0; e < ET; ++e) S[e] = 0.0;
+    } else {
+        const double* bnd = seg + (size_t)MAP * Lp;
+#pragma unroll
+        for (int i = 0; i < D; ++i) m[i] = bnd[(size_t)i * Lp + lane];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) S[e] = bnd[(size_t)(D + e) * Lp + lane];
+    }
+    double An[EF], bn[D];
+    if (nt > 0) {
+        ld_node<EF>(Am, R, 0, me, An);
+        ld_node<D>(bm, R, 0, me, bn);
+    }
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            if (PASS == 3) {
+                st_node<D>(mug, R, s, me, m);
+                st_node<ET>(Sigg, R, s, me, S);
+            }
+            if (s < nt) {
+                double T[EF], o[D];
+#pragma unroll
+                for (int e = 0; e < EF; ++e) T[e] = An[e];
+#pragma unroll
+                for (int i = 0; i < D; ++i) o[i] = bn[i];
+                if (s + 1 < nt) {
+                    ld_node<EF>(Am, R, s + 1, me, An);
+                    ld_node<D>(bm, R, s + 1, me, bn);
+                }
+                vdp_transition<D>(pr, T, o);
+                vdp_advance<D>(pr, T, o, m, S);
+                if (PASS == 1) {
+                    double t[EF];
+                    gemm<D>(T, Phi, t);
+#pragma unroll
+                    for (int e = 0; e < EF; ++e) Phi[e] = t[e];
+                }
+            }
+        }
+    }
+    if (PASS == 1) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) seg[(size_t)e * Lp + lane] = Phi[e];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) seg[(size_t)(EF + e) * Lp + lane] = S[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) seg[(size_t)(EF + ET + i) * Lp + lane] = m[i];
+    }
+}
+
+// value at the first node of segment p+1 = map_p(value at the first node of segment p), from q(x0) = N(q0_mu[b], q0_cov[b]):
+// one wavefront per chain, as k_vdp_lagrange_scan_wave (lane j composes K = ceil(P / 64) consecutive maps, readlane chain, replay).
+template <int D>
+__global__ __launch_bounds__(64) void k_vdp_marginals_scan(LevelDesc lv, const double* __restrict__ q0_mu,
+                                                          const double* __restrict__ q0_cov, double* __restrict__ seg) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D;
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int P = lv.P;
+    const size_t Lp = lv.Lpad;
+    const int K = (P + 63) / 64;
+    const int lo = j * K;                          // this lane's segments: lo, lo+1, ..., min(lo+K, P) - 1
+    double* bnd = seg + (size_t)MAP * Lp;
+    auto load_map = [&](int p, double (&Ph)[EF], double (&Qa)[ET], double (&ma)[D]) {
+        const size_t lane = (size_t)b * P + p;
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Ph[e] = seg[(size_t)e * Lp + lane];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) Qa[e] = seg[(size_t)(EF + e) * Lp + lane];
+#pragma unroll
+        for (int i = 0; i < D; ++i) ma[i] = seg[(size_t)(EF + ET + i) * Lp + lane];
+    };
+    auto apply = [&](const double (&Ph)[EF], const double (&Qa)[ET], const double (&ma)[D], double (&m)[D], double (&S)[ET]) {
+        double t[D];
+        gemv<D>(Ph, m, t);
+#pragma unroll
+        for (int i = 0; i < D; ++i) m[i] = t[i] + ma[i];
+        vdp_congruence<D>(Ph, S);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) S[e] += Qa[e];
+    };
+    // the lane's composed map (Phi, Qacc, macc): identity when it has no segment
+    double Phi[EF], Qc[ET], mc[D];
+#pragma unroll
+    for (int e = 0; e < EF; ++e) Phi[e] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Phi[i * D + i] = 1.0; mc[i] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < ET; ++e) Qc[e] = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const int p = lo + k;
+        if (p < P) {
+            double Ph[EF], Qa[ET], ma[D], t[EF];
+            load_map(p, Ph, Qa, ma);
+            apply(Ph, Qa, ma, mc, Qc);             // (Phi_p Phi, Phi_p Qc Phi_p^T + Q_p, Phi_p mc + m_p)
+            gemm<D>(Ph, Phi, t);
+#pragma unroll
+            for (int e = 0; e < EF; ++e) Phi[e] = t[e];
+        }
+    }
+    double rm[D], rS[ET], mym[D], myS[ET];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { rm[i] = q0_mu[(size_t)b * D + i]; mym[i] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < ET; ++e) { rS[e] = q0_cov[(size_t)b * ET + e]; myS[e] = 0.0; }
+    for (int jj = 0; jj < 64; ++jj) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) mym[i] = (jj == j) ? rm[i] : mym[i];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) myS[e] = (jj == j) ? rS[e] : myS[e];
+        double Pb[EF], Qb[ET], mb[D];
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Pb[e] = vdp_bcast(Phi[e], jj);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) Qb[e] = vdp_bcast(Qc[e], jj);
+#pragma unroll
+        for (int i = 0; i < D; ++i) mb[i] = vdp_bcast(mc[i], jj);
+        apply(Pb, Qb, mb, rm, rS);
+    }
+    for (int k = 0; k < K; ++k) {
+        const int p = lo + k;
+        if (p < P) {
+            const size_t lane = (size_t)b * P + p;
+#pragma unroll
+            for (int i = 0; i < D; ++i) bnd[(size_t)i * Lp + lane] = mym[i];
+#pragma unroll
+            for (int e = 0; e < ET; ++e) bnd[(size_t)(D + e) * Lp + lane] = myS[e];
+            double Ph[EF], Qa[ET], ma[D];
+            load_map(p, Ph, Qa, ma);
+            apply(Ph, Qa, ma, mym, myS);
+        }
+    }
+}
+
 // ---- E_sde value (per-lane partials; times dt on the host) and optional gradient arrays --------------------------
 template <int D, bool GRAD>
 __global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
@@ -453,11 +671,6 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_products(LevelDesc lv, VdpP
 // lane j composes the maps of K = ceil(P / 64) consecutive segments, the 64 composed maps are chained through v_readlane
 // broadcasts, and each lane then replays its own K segments from the value that enters them.
 //   PART 0: psi (value X, maps X -> X M + C);  PART 1: lambda (value v, maps v -> M v + C)
-MFGM_DEV double vdp_bcast(double x, int src) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 
 template <int D, int PART>
 __global__ __launch_bounds__(64) void k_vdp_lagrange_scan_wave(LevelDesc lv, double* __restrict__ seg) {

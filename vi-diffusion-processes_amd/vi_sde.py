@@ -9,6 +9,7 @@ Prior / initial distributions are (mean [d], covariance [d, d]) pairs.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -93,7 +94,10 @@ class VariationalMarkovGP:
         pl = self.plan
         prm = self._params()
         if pl.d <= 8 and pl.T > 1:
-            return self._forward_packed_direct(prm)
+            if self.forward_mode == "moments":
+                return self._forward_packed_moments(prm)
+            if self.forward_mode == "precision":
+                return self._forward_packed_direct(prm)
         if self._ssm_bufs is None:
             self._ssm_bufs = (pl.empty(FULL), pl.empty(VEC), pl.empty(TRI))
         A, off, chol = self._ssm_bufs
@@ -109,6 +113,25 @@ class VariationalMarkovGP:
         f = pl.factor(pr["diag"], pr["sub"], pr["lin"], want_logdet=False)
         s = pl.selinv(f["L"], f["G"], f["y"], want_sub=False)
         self._mS = (s["x"], s["Sig"])
+        return self._mS
+
+    # how forward_pass obtains the marginals (d <= 8): "moments" = the partitioned moment recursion (mfgm_packed_vdp_marginals, what
+    # the reference's forward_pass computes); "precision" = precision blocks + factorisation + selected inverse; "ssm" = the same over
+    # explicit SSM arrays.  VIDP_VDP_FORWARD selects; the three agree to rounding (tests/test_gpu_api.py).
+    forward_mode = os.environ.get("VIDP_VDP_FORWARD", "moments")
+
+    def _forward_packed_moments(self, prm):
+        pl, d = self.plan, self.state_dim
+        if getattr(self, "_q0_key", None) is None or self._q0_key[0] is not self.q0_mu or self._q0_key[1] is not self.q0_chol:
+            cov = self.q0_chol @ self.q0_chol.transpose(-1, -2)
+            il = torch.tril_indices(d, d, device=self.device)
+            self._q0_dev = (self.q0_mu.contiguous(), cov[:, il[0], il[1]].contiguous())
+            self._q0_key = (self.q0_mu, self.q0_chol)
+        mu, Sig = pl.empty(VEC), pl.empty(SYM)        # fresh outputs: callers keep the marginals of earlier passes
+        _lib.check(self.lib.mfgm_packed_vdp_marginals(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(self._q0_dev[0]),
+                                                      _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig), _ptr(self._seg), _stream()),
+                   "mfgm_packed_vdp_marginals")
+        self._mS = (mu, Sig)
         return self._mS
 
     def _forward_packed_direct(self, prm):
