@@ -257,9 +257,12 @@ int mfgm_packed_vdp_to_naturals(const mfgm_plan* plan, const mfgm_vdp_params* pr
 /* forward_pass as the moment recursion of the reference (vi_sde.py:171-204), partitioned over the segments of the plan: marginal
  * means mu (VEC) and covariances Sig (SYM) of the Euler chain of the drift (-A, b) started at q(x0) = N(q0_mu[b], q0_cov[b])
  * (q0_mu [B][d], q0_cov [B][d(d+1)/2] packed lower triangles).  No factorisation: 42 doubles read twice and 27 written per node.
+ * e_over_dt (optional, [B]): E_sde / dt of these marginals under (Am, bm), what mfgm_packed_vdp_esde would return, accumulated by
+ * the final sweep while the blocks are in registers (ws: the plan workspace, needed then).
  * seg: scratch of mfgm_vdp_workspace_doubles(plan) doubles. */
 int mfgm_packed_vdp_marginals(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
-                              const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* seg, void* stream);
+                              const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* e_over_dt, double* seg,
+                              void* ws, void* stream);
 
 /* update_lagrange (vi_sde.py:289-347): psi (FULL) and lambda (VEC) on nodes 0..T-2.  yR (VEC) = R^{-1} y and dobsS (SYM) =
  * -1/2 R^{-1} at the observation nodes, zero elsewhere (jump conditions of a Gaussian likelihood, vi_sde.py:262-287).

@@ -1177,3 +1177,32 @@ def test_vdp_forward_pass_routes_agree(amd, rng, d, B, T, stab):
         for xa, xb in zip(out["moments"], out[mode]):
             assert np.isfinite(xa).all()
             np.testing.assert_allclose(xa, xb, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(xb).max()))
+
+
+def test_vdp_esde_from_the_forward_sweep(amd, rng):
+    """E_sde returned by the forward pass's final sweep equals the stand-alone kernel on the same marginals, and the cached value is
+    dropped when (A, b) or the drift parameters change."""
+    import torch
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    d, B, T, dt = 3, 3, 150, 0.01
+    grid = np.arange(T) * dt
+    idx = np.arange(5, T - 1, 9)
+    y = rng.normal(size=(B, len(idx), d))
+    g = VariationalMarkovGP((grid[idx], dev(y)), gsde.DoubleWellSDE(torch.eye(d, dtype=torch.float64)), grid,
+                            MultivariateGaussian(dev(0.5 * np.eye(d))), prior_initial_state=(np.zeros(d), 0.5 * np.eye(d)),
+                            plan=amd.Plan(B, T, d, R0=8, Rup=3))
+    g.plan.pack(amd.FULL, dev(3.0 * rng.normal(size=(B, T, d, d)) + 4.0 * np.eye(d)), out=g.A)
+    g.plan.pack(amd.VEC, dev(rng.normal(size=(B, T, d))), out=g.b)
+    mS = g._forward_packed()
+    fused = host(g.E_sde(mS))
+    g._esde_of = None
+    np.testing.assert_allclose(fused, host(g.E_sde(mS)), rtol=1e-12)
+    # a parameter update invalidates the by-product: E_sde of the OLD marginals under the NEW (A, b) is recomputed
+    mS = g._forward_packed()
+    g.update_lagrange_and_param(mS, lr=0.05)
+    after = host(g.E_sde(mS))
+    g._esde_of = None
+    np.testing.assert_allclose(after, host(g.E_sde(mS)), rtol=1e-12)
+    assert np.abs(after - fused).max() > 1e-6 * np.abs(fused).max()

@@ -45,7 +45,7 @@ EXPORTS = {
     "mfgm_vdp_workspace_doubles": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_packed_vdp_to_ssm": (ctypes.c_int, [ctypes.c_void_p] * 8),
     "mfgm_packed_vdp_to_naturals": (ctypes.c_int, [ctypes.c_void_p] * 10),
-    "mfgm_packed_vdp_marginals": (ctypes.c_int, [ctypes.c_void_p] * 10),
+    "mfgm_packed_vdp_marginals": (ctypes.c_int, [ctypes.c_void_p] * 12),
     "mfgm_packed_vdp_esde": (ctypes.c_int, [ctypes.c_void_p] * 11),
     "mfgm_packed_vdp_lagrange": (ctypes.c_int, [ctypes.c_void_p] * 12),
     "mfgm_packed_vdp_update_param": (ctypes.c_int, [ctypes.c_void_p] * 9),

@@ -37,11 +37,17 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         else hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
     } else if (what == 6) {
         // forward_pass as the partitioned moment recursion: a2 = q0_mu [B, d], a3 = q0_cov [B, ET]; o0 = mu, o1 = Sig, o2 = seg
-        hipLaunchKernelGGL((k_vdp_marginals<D, 1>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2);
+        // a4 (optional) = E_sde / dt per trajectory [B], then ws holds the per-lane partials
+        double* part = a4 ? ws + P.off_part[0] : nullptr;
+        hipLaunchKernelGGL((k_vdp_marginals<D, 1>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, (double*)nullptr);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_marginals_scan<D>), dim3(P.B), block, 0, st, lv, a2, a3, o2);
         MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((k_vdp_marginals<D, 3>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2);
+        hipLaunchKernelGGL((k_vdp_marginals<D, 3>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, part);
+        if (part) {
+            MFGM_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, const_cast<double*>(a4), (double*)nullptr);
+        }
     } else if (what == 4) {
         hipLaunchKernelGGL((k_vdp_to_naturals<D>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, o0, o1, o2);
     } else {
@@ -79,12 +85,13 @@ int mfgm_packed_vdp_to_naturals(const mfgm_plan* plan, const mfgm_vdp_params* pr
 }
 
 int mfgm_packed_vdp_marginals(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
-                              const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* seg, void* stream) {
-    if (!plan || !prm || !Am || !bm || !q0_mu || !q0_cov || !mu || !Sig || !seg) return 1;
+                              const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* e_over_dt, double* seg,
+                              void* ws, void* stream) {
+    if (!plan || !prm || !Am || !bm || !q0_mu || !q0_cov || !mu || !Sig || !seg || (e_over_dt && !ws)) return 1;
     const Plan& P = plan->p;
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
-    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(6, P, pr, Am, bm, q0_mu, q0_cov, nullptr, nullptr, mu, Sig, seg, nullptr, st)));
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(6, P, pr, Am, bm, q0_mu, q0_cov, e_over_dt, nullptr, mu, Sig, seg, (double*)ws, st)));
 }
 
 int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, const double* Am,

@@ -321,7 +321,8 @@ MFGM_DEV void vdp_advance(const VdpParams& pr, const double (&T)[D * D], const d
 template <int D, int PASS>
 __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
                                                      const double* __restrict__ bm, double* __restrict__ mug,
-                                                     double* __restrict__ Sigg, double* __restrict__ seg) {
+                                                     double* __restrict__ Sigg, double* __restrict__ seg,
+                                                     double* __restrict__ part /* PASS 3, optional: per-lane sum of the E_sde terms */) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
         for (int e = 0; e < ET; ++e) S[e] = bnd[(size_t)(D + e) * Lp + lane];
     }
     double An[EF], bn[D];
+    double esde = 0.0;
     if (nt > 0) {
         ld_node<EF>(Am, R, 0, me, An);
         ld_node<D>(bm, R, 0, me, bn);
@@ -367,6 +369,11 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
                     ld_node<EF>(Am, R, s + 1, me, An);
                     ld_node<D>(bm, R, s + 1, me, bn);
                 }
+                if (PASS == 3 && part) {
+                    // E_sde term of this transition (k_vdp_esde) while (m_t, S_t, A_t, b_t) are in registers
+                    double dm[D], dS[ET];
+                    esde += vdp_energy<D, false>(pr, m, S, T, o, dm, dS);
+                }
                 vdp_transition<D>(pr, T, o);
                 vdp_advance<D>(pr, T, o, m, S);
                 if (PASS == 1) {
@@ -378,6 +385,7 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
             }
         }
     }
+    if (PASS == 3 && part) part[lane] = esde;
     if (PASS == 1) {
 #pragma unroll
         for (int e = 0; e < EF; ++e) seg[(size_t)e * Lp + lane] = Phi[e];

@@ -123,6 +123,7 @@ def load_vi_gp_model(path, model, restore_lagrange=True, restore_initial_state=T
         pl.pack(kind, dev(np.concatenate([arr, pad], axis=1)), out=out)
     put(FULL, A, model.A)
     put(VEC, b, model.b)
+    model._param_version = getattr(model, "_param_version", 0) + 1      # cached by-products of the old (A, b) are stale
     if restore_lagrange:
         put(VEC, _batched(z["lambda_lagrange"], B, 2), model.lambda_lagrange)
         if "psi_lagrange" in z.files:
@@ -145,4 +146,5 @@ def warm_start_vdp_from_cvi(vdp_model, cvi_model):
     pad_v = torch.zeros((B, 1, d), dtype=At.dtype, device=At.device)
     pl.pack(FULL, torch.cat([-(At - eye) / dt, pad_m], dim=1).contiguous(), out=vdp_model.A)
     pl.pack(VEC, torch.cat([bt / dt, pad_v], dim=1).contiguous(), out=vdp_model.b)
+    vdp_model._param_version = getattr(vdp_model, "_param_version", 0) + 1
     return vdp_model

@@ -69,6 +69,7 @@ class VariationalMarkovGP:
         self._prm.clip = 5000.0 if self.stabilize_system else 0.0        # CLIP_MAX, vi_sde.py:59-60
         self._ssm_bufs = None
         self.dist_q_ssm = None
+        self._param_version = 0        # bumped by every method that changes (A, b) or the drift parameters (see E_sde)
 
     def _reset_lagrange(self):
         """lambda = 0, psi = 1e-10 I on every transition (vi_sde.py:102-103, 328-329)."""
@@ -128,10 +129,14 @@ class VariationalMarkovGP:
             self._q0_dev = (self.q0_mu.contiguous(), cov[:, il[0], il[1]].contiguous())
             self._q0_key = (self.q0_mu, self.q0_chol)
         mu, Sig = pl.empty(VEC), pl.empty(SYM)        # fresh outputs: callers keep the marginals of earlier passes
+        e = torch.empty(self.B, dtype=torch.float64, device=self.device)
         _lib.check(self.lib.mfgm_packed_vdp_marginals(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(self._q0_dev[0]),
-                                                      _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig), _ptr(self._seg), _stream()),
-                   "mfgm_packed_vdp_marginals")
+                                                      _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig), _ptr(e), _ptr(self._seg),
+                                                      _ptr(pl.ws), _stream()), "mfgm_packed_vdp_marginals")
         self._mS = (mu, Sig)
+        # E_sde of exactly these marginals under the current (A, b), a by-product of the final sweep; valid until the variational or
+        # drift parameters change (self._esde_of is compared by identity in E_sde)
+        self._esde_of = (mu, Sig, e * self.dt, self._param_version)
         return self._mS
 
     def _forward_packed_direct(self, prm):
@@ -163,6 +168,9 @@ class VariationalMarkovGP:
         """E_sde per trajectory [B] (vi_sde.py:422-434)."""
         pl = self.plan
         m, S = mS if mS is not None else self._forward_packed()
+        c = getattr(self, "_esde_of", None)
+        if c is not None and c[0] is m and c[1] is S and c[3] == self._param_version:
+            return c[2]
         out = torch.empty(self.B, dtype=torch.float64, device=self.device)
         _lib.check(self.lib.mfgm_packed_vdp_esde(pl.h, ctypes.byref(self._params()), _ptr(m), _ptr(S), _ptr(self.A), _ptr(self.b),
                                                  _ptr(out), None, None, _ptr(pl.ws), _stream()), "mfgm_packed_vdp_esde")
@@ -183,6 +191,7 @@ class VariationalMarkovGP:
         af, bf = self.prior_sde.drift_cubic()
         for i in range(self.state_dim):
             self._prm.af[i], self._prm.bf[i] = af, bf
+        self._param_version += 1
 
     def set_prior_initial_state(self, mean, cov):
         self.p0_mu = np.asarray(mean, dtype=np.float64).reshape(self.state_dim)
@@ -246,6 +255,7 @@ class VariationalMarkovGP:
 
     def update_param(self, mS=None, lr=0.1):
         """A <- (1-lr) A + lr A~, b <- (1-lr) b + lr b~ (vi_sde.py:377-414)."""
+        self._param_version += 1
         pl = self.plan
         m, S = mS if mS is not None else self._mS
         # stabilize_system (vi_sde.py:393-397): psi / lambda are scrubbed and clipped in place by the kernel (prm.clip > 0)
@@ -258,6 +268,7 @@ class VariationalMarkovGP:
         update_lagrange(mS) followed by update_param(mS, lr), as the trainer calls them (vi_markov_gp_trainer.py:56-57), in one
         set of sweeps: the final Lagrange sweep makes the parameter update node by node (mfgm_packed_vdp_lagrange_update).
         """
+        self._param_version += 1
         pl = self.plan
         m, S = mS if mS is not None else self._mS
         _lib.check(self.lib.mfgm_packed_vdp_lagrange_update(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
