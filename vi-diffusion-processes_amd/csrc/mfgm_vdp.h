@@ -316,19 +316,19 @@ MFGM_DEV void vdp_advance(const VdpParams& pr, const double (&T)[D * D], const d
     for (int i = 0; i < D; ++i) S[tix(i, i)] += pr.dt * pr.q[i];
 }
 
-// seg layout (doubles per lane, element e at seg[e * Lpad + lane]): Phi [d^2], Qacc [ET], macc [d]; then the boundary values
-// m [d], S [ET] at the segment's first node.
+// seg: one record per lane (segment), contiguous -- Phi [d^2], Qacc [ET], macc [d], then the boundary values m [d], S [ET] at the
+// segment's first node -- so that the scan kernel reads the consecutive segments of a lane as one run (with one array per element,
+// strided by the lane count, every load of the scan was a cache line of its own: 0.29 ms, 0.16 ms like this).
 template <int D, int PASS>
 __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
                                                      const double* __restrict__ bm, double* __restrict__ mug,
                                                      double* __restrict__ Sigg, double* __restrict__ seg,
                                                      double* __restrict__ part /* PASS 3, optional: per-lane sum of the E_sde terms */) {
-    constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D;
+    constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
     const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = lv.P, R = lv.R, n = lv.n;
-    const size_t Lp = lv.Lpad;
     const int p = lane % P;
     const int len = min(R, n - p * R);
     const int nt = min(len, n - 1 - p * R);        // transitions that start in this segment: nodes s < nt
@@ -341,11 +341,11 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
 #pragma unroll
         for (int e = 0; e < ET; ++e) S[e] = 0.0;
     } else {
-        const double* bnd = seg + (size_t)MAP * Lp;
+        const double* bnd = seg + MAP;                  // boundary values follow the map in the lane's record
 #pragma unroll
-        for (int i = 0; i < D; ++i) m[i] = bnd[(size_t)i * Lp + lane];
+        for (int i = 0; i < D; ++i) m[i] = bnd[(size_t)lane * STR + i];
 #pragma unroll
-        for (int e = 0; e < ET; ++e) S[e] = bnd[(size_t)(D + e) * Lp + lane];
+        for (int e = 0; e < ET; ++e) S[e] = bnd[(size_t)lane * STR + (D + e)];
     }
     double An[EF], bn[D];
     double esde = 0.0;
@@ -388,11 +388,11 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
     if (PASS == 3 && part) part[lane] = esde;
     if (PASS == 1) {
 #pragma unroll
-        for (int e = 0; e < EF; ++e) seg[(size_t)e * Lp + lane] = Phi[e];
+        for (int e = 0; e < EF; ++e) seg[(size_t)lane * STR + e] = Phi[e];
 #pragma unroll
-        for (int e = 0; e < ET; ++e) seg[(size_t)(EF + e) * Lp + lane] = S[e];
+        for (int e = 0; e < ET; ++e) seg[(size_t)lane * STR + (EF + e)] = S[e];
 #pragma unroll
-        for (int i = 0; i < D; ++i) seg[(size_t)(EF + ET + i) * Lp + lane] = m[i];
+        for (int i = 0; i < D; ++i) seg[(size_t)lane * STR + (EF + ET + i)] = m[i];
     }
 }
 
@@ -401,21 +401,20 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
 template <int D>
 __global__ __launch_bounds__(64) void k_vdp_marginals_scan(LevelDesc lv, const double* __restrict__ q0_mu,
                                                           const double* __restrict__ q0_cov, double* __restrict__ seg) {
-    constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D;
+    constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
     const int b = blockIdx.x, j = threadIdx.x;
     const int P = lv.P;
-    const size_t Lp = lv.Lpad;
     const int K = (P + 63) / 64;
     const int lo = j * K;                          // this lane's segments: lo, lo+1, ..., min(lo+K, P) - 1
-    double* bnd = seg + (size_t)MAP * Lp;
+    double* bnd = seg + MAP;
     auto load_map = [&](int p, double (&Ph)[EF], double (&Qa)[ET], double (&ma)[D]) {
         const size_t lane = (size_t)b * P + p;
 #pragma unroll
-        for (int e = 0; e < EF; ++e) Ph[e] = seg[(size_t)e * Lp + lane];
+        for (int e = 0; e < EF; ++e) Ph[e] = seg[(size_t)lane * STR + e];
 #pragma unroll
-        for (int e = 0; e < ET; ++e) Qa[e] = seg[(size_t)(EF + e) * Lp + lane];
+        for (int e = 0; e < ET; ++e) Qa[e] = seg[(size_t)lane * STR + (EF + e)];
 #pragma unroll
-        for (int i = 0; i < D; ++i) ma[i] = seg[(size_t)(EF + ET + i) * Lp + lane];
+        for (int i = 0; i < D; ++i) ma[i] = seg[(size_t)lane * STR + (EF + ET + i)];
     };
     auto apply = [&](const double (&Ph)[EF], const double (&Qa)[ET], const double (&ma)[D], double (&m)[D], double (&S)[ET]) {
         double t[D];
@@ -469,9 +468,9 @@ __global__ __launch_bounds__(64) void k_vdp_marginals_scan(LevelDesc lv, const d
         if (p < P) {
             const size_t lane = (size_t)b * P + p;
 #pragma unroll
-            for (int i = 0; i < D; ++i) bnd[(size_t)i * Lp + lane] = mym[i];
+            for (int i = 0; i < D; ++i) bnd[(size_t)lane * STR + i] = mym[i];
 #pragma unroll
-            for (int e = 0; e < ET; ++e) bnd[(size_t)(D + e) * Lp + lane] = myS[e];
+            for (int e = 0; e < ET; ++e) bnd[(size_t)lane * STR + (D + e)] = myS[e];
             double Ph[EF], Qa[ET], ma[D];
             load_map(p, Ph, Qa, ma);
             apply(Ph, Qa, ma, mym, myS);
@@ -526,11 +525,12 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                                                     const double* __restrict__ dobsS, double* __restrict__ psig,
                                                     double* __restrict__ lamg, double* __restrict__ seg /* per-lane summaries */) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
-    constexpr int SEG = 2 * EF + EF + D;   // Mpsi, Cpsi, Mlam, Clam per lane; boundary values reuse the first EF + D slots of a 2nd block
+    constexpr int SEG = 2 * EF + EF + D;   // a lane's record: Mpsi, Cpsi, Mlam, Clam, then the boundary values psi [d^2], lambda [d]
+    constexpr int STR = SEG + EF + D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
     const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
-    const int P = lv.P, R = lv.R, n = lv.n, Lp = lv.Lpad;
+    const int P = lv.P, R = lv.R, n = lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
     (void)b;
@@ -544,11 +544,11 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
         for (int i = 0; i < D; ++i) lam[i] = 0.0;
     } else {
         // boundary value at this segment's last node (slot layout: seg2[(e)*Lpad + lane])
-        const double* bnd = seg + (size_t)SEG * Lp;
+        const double* bnd = seg + SEG;                  // boundary values follow the map in the lane's record
 #pragma unroll
-        for (int e = 0; e < EF; ++e) psi[e] = bnd[(size_t)e * Lp + lane];
+        for (int e = 0; e < EF; ++e) psi[e] = bnd[(size_t)lane * STR + e];
 #pragma unroll
-        for (int i = 0; i < D; ++i) lam[i] = bnd[(size_t)(EF + i) * Lp + lane];
+        for (int i = 0; i < D; ++i) lam[i] = bnd[(size_t)lane * STR + (EF + i)];
     }
     for (int s = R - 1; s >= 0; --s) {
         if (s < len) {
@@ -624,9 +624,9 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
     if (PASS == 1) {
         // psi / lam now hold the affine offsets (C) of the segment map: value entering the previous segment's last node
 #pragma unroll
-        for (int e = 0; e < EF; ++e) seg[(size_t)(EF + e) * Lp + lane] = psi[e];
+        for (int e = 0; e < EF; ++e) seg[(size_t)lane * STR + (EF + e)] = psi[e];
 #pragma unroll
-        for (int i = 0; i < D; ++i) seg[(size_t)(3 * EF + i) * Lp + lane] = lam[i];
+        for (int i = 0; i < D; ++i) seg[(size_t)lane * STR + (3 * EF + i)] = lam[i];
     }
 }
 
@@ -636,11 +636,11 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
 template <int D>
 __global__ __launch_bounds__(64) void k_vdp_lagrange_products(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
                                                              double* __restrict__ seg) {
-    constexpr int EF = D * D;
+    constexpr int EF = D * D, STR = 4 * EF + 2 * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
     const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
-    const int P = lv.P, R = lv.R, n = lv.n, Lp = lv.Lpad;
+    const int P = lv.P, R = lv.R, n = lv.n;
     const int p = lane % P;
     const int len = min(R, n - p * R);
     const int N = n - 1;
@@ -669,8 +669,8 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_products(LevelDesc lv, VdpP
     }
 #pragma unroll
     for (int e = 0; e < EF; ++e) {
-        seg[(size_t)e * Lp + lane] = Mp[e];
-        seg[(size_t)(2 * EF + e) * Lp + lane] = Ml[e];
+        seg[(size_t)lane * STR + e] = Mp[e];
+        seg[(size_t)lane * STR + (2 * EF + e)] = Ml[e];
     }
 }
 
@@ -682,15 +682,14 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_products(LevelDesc lv, VdpP
 
 template <int D, int PART>
 __global__ __launch_bounds__(64) void k_vdp_lagrange_scan_wave(LevelDesc lv, double* __restrict__ seg) {
-    constexpr int EF = D * D, SEG = 3 * EF + D, NV = PART == 0 ? EF : D;
+    constexpr int EF = D * D, SEG = 3 * EF + D, STR = SEG + EF + D, NV = PART == 0 ? EF : D;
     const int b = blockIdx.x, j = threadIdx.x;
     const int P = lv.P;
-    const size_t Lp = lv.Lpad;
     const int K = (P + 63) / 64;
     const int hi = P - j * K;                      // this lane's segments: hi-1, hi-2, ..., max(hi-K, 0)
-    const double* Mg = seg + (size_t)(PART == 0 ? 0 : 2 * EF) * Lp;
-    const double* Cg = seg + (size_t)(PART == 0 ? EF : 3 * EF) * Lp;
-    double* bnd = seg + (size_t)SEG * Lp + (size_t)(PART == 0 ? 0 : EF) * Lp;
+    const double* Mg = seg + (PART == 0 ? 0 : 2 * EF);
+    const double* Cg = seg + (PART == 0 ? EF : 3 * EF);
+    double* bnd = seg + SEG + (PART == 0 ? 0 : EF);
 
     auto apply = [&](double (&val)[NV], const double (&Mm)[EF], const double (&Cc)[NV]) {
         double t[NV];
@@ -701,9 +700,9 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_scan_wave(LevelDesc lv, dou
     auto load_map = [&](int p, double (&Mm)[EF], double (&Cc)[NV]) {
         const size_t lane = (size_t)b * P + p;
 #pragma unroll
-        for (int e = 0; e < EF; ++e) Mm[e] = Mg[(size_t)e * Lp + lane];
+        for (int e = 0; e < EF; ++e) Mm[e] = Mg[(size_t)lane * STR + e];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) Cc[e] = Cg[(size_t)e * Lp + lane];
+        for (int e = 0; e < NV; ++e) Cc[e] = Cg[(size_t)lane * STR + e];
     };
 
     // the lane's composed map
@@ -749,7 +748,7 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_scan_wave(LevelDesc lv, dou
         if (p >= 0) {
             const size_t lane = (size_t)b * P + p;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) bnd[(size_t)e * Lp + lane] = mine[e];
+            for (int e = 0; e < NV; ++e) bnd[(size_t)lane * STR + e] = mine[e];
             double Mm[EF], Cc[NV];
             load_map(p, Mm, Cc);
             apply(mine, Mm, Cc);
