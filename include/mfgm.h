@@ -270,13 +270,17 @@ int mfgm_packed_vdp_marginals(const mfgm_plan* plan, const mfgm_vdp_params* prm,
 size_t mfgm_vdp_workspace_doubles(const mfgm_plan* plan);
 int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
                              const double* Am, const double* bm, const double* yR, const double* dobsS, double* psi,
-                             double* lam, double* seg, void* stream);
+                             double* lam, double* seg, const int* obs_count, const double* dobs_const, void* stream);
+/* obs_count / dobs_const (both or neither): when every observation contributes the same block (one Gaussian likelihood), dobsS =
+ * obs_count[node] * dobs_const with obs_count one int per node in the packed order [tile][step][64 lanes] (index
+ * ((lane / 64) * R + step) * 64 + lane % 64, R and the lane of a node as in mfgm_plan_describe) and dobs_const [d(d+1)/2] on the
+ * device; dobsS is then not read and may be NULL (d(d+1)/2 doubles per node that are zero almost everywhere). */
 /* mfgm_packed_vdp_lagrange immediately followed by mfgm_packed_vdp_update_param on the same (mu, Sig), as the trainer calls them
  * (vi_markov_gp_trainer.py:56-57), in the same three passes: the final sweep replaces (Am, bm) node by node as soon as psi_t and
  * lambda_t are known.  psi / lam end up as update_param leaves them (clipped when prm->clip > 0). */
 int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
                                     double* bm, const double* yR, const double* dobsS, double* psi, double* lam, double* seg,
-                                    void* stream);
+                                    const int* obs_count, const double* dobs_const, void* stream);
 /* update_param (vi_sde.py:377-414): A <- (1-lr) A + lr (-E f' + 2 q psi), b <- (1-lr) b + lr (E f + A~ m - q lambda).
  * With prm->clip > 0 psi and lam are overwritten by their clipped values (they are not const then). */
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

@@ -1007,6 +1007,7 @@ def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind)
 
     def run(fused):
         q = torch.eye(d, dtype=torch.float64)
+        VariationalMarkovGP.dense_jumps = not fused      # the two-call form also reads the dense jump-condition array
         g = VariationalMarkovGP((grid[idx], dev(y)), gsde.DoubleWellSDE(q) if kind == "dw" else gsde.OrnsteinUhlenbeckSDE(0.9, q), grid,
                                 MultivariateGaussian(dev(lik_chol)), prior_initial_state=(np.zeros(d), 0.5 * np.eye(d)),
                                 stabilize_system=stab, plan=amd.Plan(B, T, d, R0=8, Rup=3))
@@ -1023,7 +1024,11 @@ def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind)
                         host(pl.unpack(amd.FULL, g.psi_lagrange, T - 1)), host(pl.unpack(amd.VEC, g.lambda_lagrange, T - 1))])
         return out
 
-    for sa, sb in zip(run(True), run(False)):
+    try:
+        ra, rb = run(True), run(False)
+    finally:
+        VariationalMarkovGP.dense_jumps = False
+    for sa, sb in zip(ra, rb):
         for xa, xb in zip(sa, sb):
             assert np.isfinite(xb).all()
             np.testing.assert_allclose(xa, xb, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(xb).max()))

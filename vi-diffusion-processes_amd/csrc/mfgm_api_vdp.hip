@@ -10,7 +10,8 @@ static_assert(sizeof(mfgm_vdp_params) == sizeof(mfgm::VdpParams), "public and in
 namespace {
 template <int D>
 int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, const double* a1, const double* a2, const double* a3,
-             const double* a4, const double* a5, double* o0, double* o1, double* o2, double* ws, hipStream_t st) {
+             const double* a4, const double* a5, double* o0, double* o1, double* o2, double* ws, hipStream_t st,
+             const int* obs_count = nullptr, const double* dobs_const = nullptr) {
     const LevelDesc& lv = P.lv[0];
     dim3 grid(lv.Lpad / 64), block(64);
     if (what == 0) {
@@ -27,14 +28,14 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         double* bw = const_cast<double*>(a3);
         hipLaunchKernelGGL((k_vdp_lagrange_products<D>), grid, block, 0, st, lv, pr, a2, o2);
         MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
+        hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 0>), dim3(P.B), block, 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 1>), dim3(P.B), block, 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
-        if (what == 2) hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
-        else hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2);
+        if (what == 2) hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
+        else hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
     } else if (what == 6) {
         // forward_pass as the partitioned moment recursion: a2 = q0_mu [B, d], a3 = q0_cov [B, ET]; o0 = mu, o1 = Sig, o2 = seg
         // a4 (optional) = E_sde / dt per trajectory [B], then ws holds the per-lane partials
@@ -105,22 +106,24 @@ int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, cons
 
 int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
                              const double* Am, const double* bm, const double* yR, const double* dobsS, double* psi, double* lam,
-                             double* seg, void* stream) {
-    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !dobsS || !psi || !lam || !seg) return 1;
+                             double* seg, const int* obs_count, const double* dobs_const, void* stream) {
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !psi || !lam || !seg) return 1;
+    if ((obs_count != nullptr) != (dobs_const != nullptr) || (!obs_count && !dobsS)) return 1;
     const Plan& P = plan->p;
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
-    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(2, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st)));
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(2, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st, obs_count, dobs_const)));
 }
 
 int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
                                     double* bm, const double* yR, const double* dobsS, double* psi, double* lam, double* seg,
-                                    void* stream) {
-    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !dobsS || !psi || !lam || !seg) return 1;
+                                    const int* obs_count, const double* dobs_const, void* stream) {
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !psi || !lam || !seg) return 1;
+    if ((obs_count != nullptr) != (dobs_const != nullptr) || (!obs_count && !dobsS)) return 1;
     const Plan& P = plan->p;
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
-    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(5, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st)));
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(5, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st, obs_count, dobs_const)));
 }
 
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

@@ -512,7 +512,8 @@ __global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, con
 
 // ---- update_lagrange ------------------------------------------------------------------------------------------------
 // yR (VEC) = R^{-1} y at observation nodes (zero elsewhere), dobsS (SYM) = -1/2 R^{-1} at observation nodes: the jump
-// conditions d_obs_m = yR + 2 dobsS m, d_obs_S = dobsS (vi_sde.py:262-287 for a Gaussian likelihood).
+// conditions d_obs_m = yR + 2 dobsS m, d_obs_S = dobsS (vi_sde.py:262-287 for a Gaussian likelihood).  With obs_count (one int per
+// node, packed [tile][step][64]) and dobs_const [ET] given, dobsS is taken as obs_count * dobs_const and not read.
 // PASS 1: the offsets (Cpsi, Clam) of the per-segment affine maps, i.e. the sweep with zero input (their linear parts Mpsi, Mlam come
 // from k_vdp_lagrange_products); PASS 3: the sweep from the known value
 // at the segment's last node (bpsi, blam: [lanes] arrays written by k_vdp_lagrange_scan_wave).
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                                                     const double* __restrict__ Sigg, double* Am,
                                                     double* bm, const double* __restrict__ yR,
                                                     const double* __restrict__ dobsS, double* __restrict__ psig,
-                                                    double* __restrict__ lamg, double* __restrict__ seg /* per-lane summaries */) {
+                                                    double* __restrict__ lamg, double* __restrict__ seg /* per-lane summaries */,
+                                                    const int* __restrict__ obs_count, const double* __restrict__ dobs_const) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     constexpr int SEG = 2 * EF + EF + D;   // a lane's record: Mpsi, Cpsi, Mlam, Clam, then the boundary values psi [d^2], lambda [d]
     constexpr int STR = SEG + EF + D;
@@ -594,7 +596,15 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                 if (t >= 1) {
                     double dm[D], dS[ET], yr[D], dob[ET];
                     ld_node<D>(yR, R, s, me, yr);
-                    ld_node<ET>(dobsS, R, s, me, dob);
+                    if (obs_count) {
+                        // every observation contributes the same block: dobsS = count * dobs_const, one int per node read instead of
+                        // d (d + 1) / 2 doubles that are zero at all but the observation nodes
+                        const double cnt = (double)obs_count[((size_t)me.tile * R + s) * 64 + me.l];
+#pragma unroll
+                        for (int e = 0; e < ET; ++e) dob[e] = cnt * dobs_const[e];
+                    } else {
+                        ld_node<ET>(dobsS, R, s, me, dob);
+                    }
                     vdp_energy<D, true>(pr, m, S, A, bb, dm, dS);
                     if (pr.clip > 0.0) {        // vi_sde.py:312-323
 #pragma unroll

@@ -60,6 +60,15 @@ class VariationalMarkovGP:
         self._yR, self._dobsS = pl.zeros(VEC), pl.zeros(SYM)
         pl.scatter_nodes(VEC, self._yR, self.obs_node_ids, (self.observations.reshape(n, d) @ Rinv), accumulate=True)
         pl.scatter_nodes(SYM, self._dobsS, self.obs_node_ids, (-0.5 * Rinv).expand(n, d, d).contiguous(), accumulate=True)
+        # every observation contributes the same block -1/2 R^{-1}: the sweeps read one count per node (packed order [tile][step][64])
+        # and that block instead of the dense array, which is zero at all but the observation nodes
+        ids = self.obs_node_ids
+        lane = (ids // self.num_states) * pl.P + (ids % self.num_states) // pl.R
+        slot = ((lane // 64) * pl.R + (ids % self.num_states) % pl.R) * 64 + lane % 64
+        self._obs_count = torch.zeros(pl.Lpad * pl.R, dtype=torch.int32, device=self.device)
+        self._obs_count.index_add_(0, slot, torch.ones_like(slot, dtype=torch.int32))
+        il = torch.tril_indices(d, d, device=self.device)
+        self._dobs_const = (-0.5 * Rinv)[il[0], il[1]].contiguous()
         self._seg = torch.empty(self.lib.mfgm_vdp_workspace_doubles(pl.h), dtype=torch.float64, device=self.device)
         af, bf = prior_sde.drift_cubic()
         self._prm = _lib.VdpParams()
@@ -244,13 +253,19 @@ class VariationalMarkovGP:
         return g_loc, g_scale
 
     # -- updates -----------------------------------------------------------------------------------------------
+    # VIDP_VDP_DENSE_JUMPS=1: the sweeps read the dense d_obs_S array instead of (count per node) x (constant block)
+    dense_jumps = os.environ.get("VIDP_VDP_DENSE_JUMPS", "0") == "1"
+
+    def _jump_args(self):
+        return (None, None) if self.dense_jumps else (_ptr(self._obs_count), _ptr(self._dobs_const))
+
     def update_lagrange(self, mS=None):
         """Backward sweep with jump conditions for (psi, lambda) (vi_sde.py:289-347)."""
         pl = self.plan
         m, S = mS if mS is not None else self._mS
         _lib.check(self.lib.mfgm_packed_vdp_lagrange(pl.h, ctypes.byref(self._params()), _ptr(m), _ptr(S), _ptr(self.A), _ptr(self.b),
                                                      _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
-                                                     _ptr(self.lambda_lagrange), _ptr(self._seg), _stream()),
+                                                     _ptr(self.lambda_lagrange), _ptr(self._seg), *self._jump_args(), _stream()),
                    "mfgm_packed_vdp_lagrange")
 
     def update_param(self, mS=None, lr=0.1):
@@ -273,7 +288,7 @@ class VariationalMarkovGP:
         m, S = mS if mS is not None else self._mS
         _lib.check(self.lib.mfgm_packed_vdp_lagrange_update(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
                                                             _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
-                                                            _ptr(self.lambda_lagrange), _ptr(self._seg), _stream()),
+                                                            _ptr(self.lambda_lagrange), _ptr(self._seg), *self._jump_args(), _stream()),
                    "mfgm_packed_vdp_lagrange_update")
 
     def update_initial_statistics(self, lr):
