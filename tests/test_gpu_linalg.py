@@ -80,7 +80,7 @@ def test_not_positive_definite(rng):
 
 def test_stiff_no_smoothing_round_trip(rng):
     """The two-component Matern-5/2 case on which the vendor batched LAPACK behind torch.linalg mis-solved
-    (tests/diag/acc_diag8.py): natural parameters -> SSM parameters, per-step maps only."""
+    (round-1 accuracy diagnosis): natural parameters -> SSM parameters, per-step maps only."""
     import torch
     from oracle import np_kernels, np_transforms
     from vidp_amd import ssm_gaussian_transformations as tr
