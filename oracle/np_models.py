@@ -106,9 +106,13 @@ class CVISitesSDE(CVISitesSSM):
     """
 
     def __init__(self, prior_sde, time_grid, obs_index, observations, likelihood, init_mu, init_cov, stabilize_ssm=True,
-                 clip=(-1.0, 1.0)):
+                 clip=(-1.0, 1.0), closed_form=False):
+        """closed_form: every expectation under q (E f, E f', the Girsanov KL) from the cubic drift's Gaussian moments instead of
+        the reference's H^d-point Gauss-Hermite grids -- the same numbers (both are exact for a cubic; pinned against each other at
+        d <= 2 in tests/test_oracle_sde.py and tests/test_oracle_models.py), tractable at d = 6."""
         from . import np_sde
         self._np_sde = np_sde
+        self.closed_form = bool(closed_form)
         self.sde = prior_sde
         self.init_mu, self.init_cov = np.asarray(init_mu, dtype=np.float64), np.asarray(init_cov, dtype=np.float64)
         self.stabilize_ssm, self.clip = stabilize_ssm, clip
@@ -117,7 +121,8 @@ class CVISitesSDE(CVISitesSSM):
         self.set_linearized_prior()
 
     def set_linearized_prior(self):
-        lin = self._np_sde.linearize_sde(self.sde, self.time_grid, self.fx_mus[1:], self.fx_covs[1:], self.init_mu, self.init_cov)
+        lin = self._np_sde.linearize_sde(self.sde, self.time_grid, self.fx_mus[1:], self.fx_covs[1:], self.init_mu, self.init_cov,
+                                         closed_form=self.closed_form)
         self.dist_p_linearized = lin
         if self.stabilize_ssm:
             self.dist_p = StateSpaceModel(lin.mu0, lin.cholP0, np.clip(lin.A, *self.clip), np.clip(lin.b, *self.clip), lin.cholQ)
@@ -136,6 +141,11 @@ class CVISitesSDE(CVISitesSSM):
     def KL_q_p(self):
         q = self.dist_q
         mu, cov = q.marginals
+        if self.closed_form:
+            alpha, beta = self.sde.cubic(self.dt)
+            return self._np_sde.sde_ssm_kl_closed_form(mu, cov, q.subsequent_covariances(cov), alpha, beta, np.diag(self.sde.q),
+                                                       self.dt, self.dist_p.mu0, self.dist_p.cholP0 @ self.dist_p.cholP0.T,
+                                                       want_grads=False)
         Qq = q.cholQ @ np.swapaxes(q.cholQ, -1, -2)
         N, D = q.b.shape
         Qp = np.broadcast_to(self.dt * self.sde.q, (N, D, D))
@@ -237,9 +247,12 @@ class VariationalMarkovGP:
 
     CLIP_MIN, CLIP_MAX = -5000.0, 5000.0          # vi_sde.py:59-60
 
-    def __init__(self, obs_index, observations, sde, grid, likelihood, init_mu, init_cov, stabilize_system=False):
+    def __init__(self, obs_index, observations, sde, grid, likelihood, init_mu, init_cov, stabilize_system=False, closed_form=False):
+        """closed_form: E_sde, E f and E f' from the cubic drift's Gaussian moments instead of the 20^d / 10^d-point grids (the same
+        numbers, see CVISitesSDE; tractable at d = 6)."""
         from . import np_sde
         self._np_sde = np_sde
+        self.closed_form = bool(closed_form)
         self.stabilize_system = stabilize_system
         self.obs_index, self.y = np.asarray(obs_index), np.asarray(observations, dtype=np.float64)
         self.sde, self.grid, self.lik = sde, np.asarray(grid, dtype=np.float64), likelihood
@@ -267,6 +280,9 @@ class VariationalMarkovGP:
         if m is None:
             m, S = self.forward_pass()
             m, S = m[:-1], S[:-1]
+        if self.closed_form:
+            af, bf = self._np_sde.drift_cubic(self.sde)
+            return self._np_sde.e_sde_closed_form(af, bf, np.diag(self.sde.q), -self.A, self.b, m, S, self.dt, want_grads=False)
         return self._np_sde.squared_drift_difference_along_gaussian_path(self.sde, -self.A, self.b, m, S, self.dt)
 
     def _grad_E_sde(self, m, S):
@@ -304,8 +320,12 @@ class VariationalMarkovGP:
             self.psi = np.clip(np.where(np.isnan(self.psi), 1e-8, self.psi), self.CLIP_MIN, self.CLIP_MAX)
             self.lam = np.clip(np.where(np.isnan(self.lam), 1e-8, self.lam), self.CLIP_MIN, self.CLIP_MAX)
         q = self.sde.q
-        Egrad = -self.sde.expected_gradient_drift(m[None], S[None])[0]
-        Ef = self.sde.expected_drift(m[None], S[None])[0]
+        if self.closed_form:
+            Ef, Jf = self._np_sde.expected_drift_closed_form(self.sde, m, S)
+            Egrad = -Jf
+        else:
+            Egrad = -self.sde.expected_gradient_drift(m[None], S[None])[0]
+            Ef = self.sde.expected_drift(m[None], S[None])[0]
         A_tilde = Egrad[:, :, None] * np.eye(self.d) + 2.0 * q[None] @ self.psi
         b_tilde = Ef + (A_tilde @ m[..., None])[..., 0] - (q[None] @ self.lam[..., None])[..., 0]
         self.A = (1 - lr) * self.A + lr * A_tilde

@@ -72,6 +72,19 @@ class SDE:
         return val.reshape(B, N, D)
 
 
+def expected_drift_closed_form(sde, q_mean, q_covar):
+    """
+    E_q f and E_q f' of a per-dimension cubic drift f_i(x) = af x_i - bf x_i^3 under N(m, S), from the Gaussian moments of each
+    dimension's own marginal (only diag S enters).  Equals SDE.expected_drift / expected_gradient_drift exactly (a 10-point
+    Gauss-Hermite rule integrates the cubic and its derivative exactly: tests/test_oracle_sde.py pins the two at d <= 2); this
+    form is what makes d = 6 tractable for the oracle (the tensor-product rule needs 10^6 points per time step there).
+    """
+    af, bf = drift_cubic(sde)
+    v = np.einsum("...ii->...i", q_covar)
+    Ef, Jf, _, _ = cubic_moments(af, bf, q_mean, v)
+    return Ef, Jf
+
+
 class OrnsteinUhlenbeckSDE(SDE):
     """sde.py:134-176: f(x) = -decay x."""
 
@@ -158,14 +171,18 @@ def linear_drift_to_ssm(A, b, q, transition_times, initial_mean, initial_chol_co
     return StateSpaceModel(initial_mean, initial_chol_covariance, At, bt, cholQ)
 
 
-def linearize_sde(sde, transition_times, path_mu, path_cov, init_mu, init_cov):
+def linearize_sde(sde, transition_times, path_mu, path_cov, init_mu, init_cov, closed_form=False):
     """
     sde_utils.py:119-179.  path_mu [N, D], path_cov [N, D, D] (N = num transitions).
     A_i = E[f'] (as diag for D > 1), b_i = E[f] - A_i E[x]; then LinearDrift.to_ssm.
+    closed_form: the two expectations from the cubic's Gaussian moments instead of the 10^D-point quadrature.
     """
     N, D = path_mu.shape
-    E_f = sde.expected_drift(path_mu[None], path_cov[None])[0]
-    Adiag = sde.expected_gradient_drift(path_mu[None], path_cov[None])[0]
+    if closed_form:
+        E_f, Adiag = expected_drift_closed_form(sde, path_mu, path_cov)
+    else:
+        E_f = sde.expected_drift(path_mu[None], path_cov[None])[0]
+        Adiag = sde.expected_gradient_drift(path_mu[None], path_cov[None])[0]
     A = Adiag[:, :, None] * np.eye(D)
     b = E_f - (A @ path_mu[..., None])[..., 0]
     cq = sde.diffusion(path_mu, None)

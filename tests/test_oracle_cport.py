@@ -75,16 +75,20 @@ def test_c_sde_kl(rng):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10)
 
 
-def test_c_cvi_dp_step(rng):
+@pytest.mark.parametrize("d,T", [(2, 40), (6, 70)])
+def test_c_cvi_dp_step(rng, d, T):
+    """The C port of the bench step against the NumPy oracle model; at d = 6 (the bench's state dimension) the oracle runs its
+    closed-form route (pinned to the quadrature route at d <= 2 in tests/test_oracle_models.py)."""
     from oracle import np_sde
-    B, T, d, n, dt = 2, 40, 2, 5, 0.02
+    B, n, dt = 2, 5, 0.02
     sde = np_sde.DoubleWellSDE(np.eye(d))
     grid = np.arange(T) * dt
     idx = np.sort(rng.choice(np.arange(1, T), size=n, replace=False))
     y = np.sign(rng.normal(size=(B, n, d))) + 0.2 * rng.normal(size=(B, n, d))
     cholR = 0.3 * np.eye(d)
     init = (np.zeros(d), 0.5 * np.eye(d))
-    models = [np_models.CVISitesSDE(sde, grid, idx, y[b], np_models.MultivariateGaussianLik(cholR), *init) for b in range(B)]
+    models = [np_models.CVISitesSDE(sde, grid, idx, y[b], np_models.MultivariateGaussianLik(cholR), *init, closed_form=d > 2)
+              for b in range(B)]
     nats = [np_transforms.ssm_to_naturals(m.dist_p) for m in models]
     al, be = sde.cubic(dt)
     st = c_ref.CviDpStepState(np.stack([n_[0] for n_ in nats]), np.stack([n_[1] for n_ in nats]), np.stack([n_[2] for n_ in nats]),

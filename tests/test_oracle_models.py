@@ -146,3 +146,102 @@ def test_sparse_cvi_and_conditionals(rng):
     mu, var = npc.predict_f(m.dist_q, k, t, tn)
     np.testing.assert_allclose(mu[:, 0], mu_ref, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(var[:, 0], var_ref, rtol=1e-6, atol=1e-8)
+
+
+# ---- round 2: closed-form oracle route (what makes d = 6 checkable) pinned to the quadrature route ------------------------------
+@pytest.mark.parametrize("d", [1, 2])
+def test_cvi_sites_sde_closed_form_equals_quadrature(rng, d):
+    """The oracle CVISitesSDE with closed_form=True (Gaussian moments of the cubic drift) follows the quadrature-route oracle
+    (the reference's mvnquad formulation, H = 10 / 20) through updates, re-linearisation and ELBO: both are exact for a cubic."""
+    from oracle import np_sde
+    T, dt = 24, 0.02
+    sde = np_sde.DoubleWellSDE(np.diag(0.6 + 0.5 * rng.random(d)))
+    idx = np.arange(3, T - 1, 5)
+    y = np.sign(rng.normal(size=(len(idx), d))) + 0.2 * rng.normal(size=(len(idx), d))
+    lik = np_models.MultivariateGaussianLik(0.3 * np.eye(d) + 0.05 * np.tril(np.ones((d, d)), -1))
+    init = (0.1 * np.ones(d), 0.5 * np.eye(d) + 0.1)
+    a, b = (np_models.CVISitesSDE(sde, np.arange(T) * dt, idx, y, lik, *init, closed_form=cf) for cf in (False, True))
+    np.testing.assert_allclose(b.dist_p.A, a.dist_p.A, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(b.dist_p.b, a.dist_p.b, rtol=1e-11, atol=1e-13)
+    for _ in range(2):
+        for m in (a, b):
+            m.update_data_sites(0.5)
+            m.update_girsanov_sites(0.3)
+        np.testing.assert_allclose(b.KL_q_p(), a.KL_q_p(), rtol=1e-10)
+        np.testing.assert_allclose(b.classic_elbo(), a.classic_elbo(), rtol=1e-10)
+        for m in (a, b):
+            m.relinearize()
+        np.testing.assert_allclose(b.dist_p.A, a.dist_p.A, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(b.classic_elbo(), a.classic_elbo(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_vdp_closed_form_equals_quadrature(rng, d):
+    """The same for the VDP oracle: E_sde, E f, E f' from Gaussian moments vs the reference's 20^d / 10^d-point grids."""
+    from oracle import np_sde
+    T, dt = 30, 0.01
+    sde = np_sde.DoubleWellSDE(np.diag(0.8 + 0.4 * rng.random(d)))
+    idx = np.arange(4, T - 1, 6)
+    y = np.sign(rng.normal(size=(len(idx), d))) + 0.1 * rng.normal(size=(len(idx), d))
+    lik = np_models.MultivariateGaussianLik(0.5 * np.eye(d))
+    init = (np.zeros(d), 0.5 * np.eye(d))
+    a, b = (np_models.VariationalMarkovGP(idx, y, sde, np.arange(T) * dt, lik, *init, closed_form=cf) for cf in (False, True))
+    for it in range(3):
+        for m in (a, b):
+            mm, S = m.forward_pass()
+            m.update_lagrange(mm, S)
+            m.update_param(mm, S, 0.05)
+        np.testing.assert_allclose(b.A, a.A, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(b.b, a.b, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(b.elbo(), a.elbo(), rtol=1e-10)
+
+
+def config1_closed_form_log_marginal(time_grid, obs_index, y, decay, q, sigma):
+    """
+    KA11 target for BASELINE config 1, independent of every block-tri-diagonal routine: the log marginal likelihood of the
+    observations under the Euler-discretised OU chain x_{t+1} = a x_t + N(0, q dt), a = 1 - decay dt, x_0 ~ N(0, q / (2 decay))
+    (cvi_dp.py:60-65), observed with noise sigma at the grid indices `obs_index`.  Cov(x_s, x_t) = a^{|t-s|} P_{min(s,t)} with
+    P_t = a^2 P_{t-1} + q dt, so K_yy is written down directly and the answer is one dense 32 x 32 Gaussian.
+    """
+    dt = float(time_grid[1] - time_grid[0])
+    a = 1.0 - decay * dt
+    P = np.empty(len(time_grid))
+    P[0] = q / (2.0 * decay)
+    for t in range(1, len(P)):
+        P[t] = a * a * P[t - 1] + q * dt
+    i = np.asarray(obs_index)
+    lo = np.minimum(i[:, None], i[None, :])
+    Kyy = a ** np.abs(i[:, None] - i[None, :]) * P[lo] + sigma ** 2 * np.eye(len(i))
+    yf = np.asarray(y).reshape(-1)
+    return -0.5 * yf @ np.linalg.solve(Kyy, yf) - 0.5 * np.linalg.slogdet(Kyy)[1] - 0.5 * len(yf) * np.log(2 * np.pi)
+
+
+def load_config1():
+    """BASELINE config 1 exactly as SURVEY 8d / docs/diffusion_processes/README.md:43 run it: the reference's shipped
+    data/linear/15/0.npz (T = 1001, dt = 0.01, 32 observations, sigma = 0.1, generated with decay 0.5) under an OU prior with
+    decay 1.2, q = Q, p(x0) = N(0, Q / 2.4)."""
+    import os
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "linear_15_0.npz"))
+    tg, og = z["time_grid"], z["observation_grid"]
+    idx = np.searchsorted(tg, og)
+    assert np.array_equal(tg[idx], og) and tg.shape == (1001,) and og.shape == (32,)
+    return dict(time_grid=tg, obs_index=idx, y=z["observations"], Q=float(z["Q"]), sigma=float(z["sigma"]), decay=1.2,
+                test_grid=z["test_grid"], test_y=z["test_observations"])
+
+
+def test_config1_recipe_oracle():
+    """Config 1 with the reference's own data and schedule (configs/cvi_linear_process.yaml: both learning rates 1, one site
+    iteration): the oracle's ELBO equals the closed-form log marginal likelihood (KA11)."""
+    from oracle import np_sde
+    c = load_config1()
+    sde = np_sde.OrnsteinUhlenbeckSDE(c["decay"], c["Q"] * np.eye(1))
+    P0 = c["Q"] / (2 * c["decay"]) * np.eye(1)
+    m = np_models.CVISitesSDE(sde, c["time_grid"], c["obs_index"], c["y"], np_models.MultivariateGaussianLik(c["sigma"] * np.eye(1)),
+                              np.zeros(1), P0)
+    m.update_data_sites(1.0)
+    m.update_girsanov_sites(1.0)
+    target = config1_closed_form_log_marginal(c["time_grid"], c["obs_index"], c["y"], c["decay"], c["Q"], c["sigma"])
+    np.testing.assert_allclose(m.classic_elbo(), target, rtol=1e-6)
+    np.testing.assert_allclose(m.d1, c["y"] / c["sigma"] ** 2, rtol=1e-10)
+    np.testing.assert_allclose(m.g1, 0.0, atol=1e-5)

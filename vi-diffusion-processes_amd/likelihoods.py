@@ -6,6 +6,7 @@ Observation counts are tiny next to the time grid (n_obs << T), so these run as 
 the gathered observation nodes.
 """
 import math
+import weakref
 
 import torch
 
@@ -17,10 +18,22 @@ class MultivariateGaussian:
 
     def __init__(self, chol_covariance):
         self.chol_covariance = chol_covariance
+
+    @property
+    def chol_covariance(self):
+        return self._chol
+
+    @chol_covariance.setter
+    def chol_covariance(self, chol_covariance):
+        """Everything derived from the factor is rebuilt when it is replaced (no stale inverse / constant / gradient cache)."""
+        self._chol = chol_covariance
         self.obs_dim = chol_covariance.shape[-1]
         # one d x d inverse, reused by every call (no per-observation triangular solves)
         self.inv_covariance = linalg.spd_inverse(chol=chol_covariance)
         self.log_det_chol = torch.log(torch.diagonal(chol_covariance)).sum()
+        # additive constant of the variational expectations, as a host scalar (one synchronisation, here)
+        self.ve_constant = -float(self.log_det_chol) - 0.5 * self.obs_dim * math.log(2.0 * math.pi)
+        self._g_cache = None
 
     def variational_expectations(self, f_means, f_covariances, observations):
         """-1/2 tr(S^{-1} S_i) + log N(y_i; mu_i, S) (multivariate_gaussian.py:80-115); shape [..., n]."""
@@ -37,14 +50,16 @@ class MultivariateGaussian:
         d/dmu = S^{-1}(y - mu), d/dS = -1/2 S^{-1}, then gradient_transformation_mean_var_to_expectation
         (variational_cvi.py:448-462): g1 = d/dmu - 2 (d/dS) mu = S^{-1} y,  g2 = -1/2 S^{-1}.
         """
-        # both gradients depend on the observations only: computed once per observation tensor
-        key = (observations.data_ptr(), tuple(observations.shape), tuple(f_covariances.shape))
-        if getattr(self, "_g_cache", (None,))[0] != key:
+        # both gradients depend on the observations only: computed once per observation TENSOR OBJECT and version (a raw address
+        # is no key: the caching allocator hands freed blocks back at the same address with the same shape)
+        c = self._g_cache
+        if (c is None or c[0]() is not observations or c[1] != observations._version or c[2] != tuple(f_covariances.shape)
+                or c[3] != self.inv_covariance._version):
             Sinv = self.inv_covariance
             g1 = (Sinv * observations[..., None, :]).sum(-1)           # S^{-1} y (S symmetric)
             g2 = (-0.5 * Sinv).expand(f_covariances.shape).contiguous()
-            self._g_cache = (key, g1, g2)
-        return self._g_cache[1], self._g_cache[2]
+            c = self._g_cache = (weakref.ref(observations), observations._version, tuple(f_covariances.shape), Sinv._version, g1, g2)
+        return c[4], c[5]
 
 
 class Gaussian:

@@ -106,18 +106,19 @@ class CVISitesTrainer:
             new = self.prior_sde_optim.step([sde.get(n) for n in names], [a + b for a, b in zip(grads_kl, grads_ve)])
             for n, v in zip(names, new):
                 sde.assign(n, v)
-            if isinstance(sde, OrnsteinUhlenbeckSDE):
-                # stationary initial state q / (2 decay) (cvi_dp_trainer.py:231-235)
-                d = model.state_dim
-                cov = torch.diag(torch.tensor(sde.q_diag, dtype=torch.float64)) / (2.0 * sde.decay)
-                model.set_prior_initial_state(torch.zeros(d, dtype=torch.float64).numpy(), cov.numpy())
-            else:
-                model._refresh_sde_params()
+            # the reference's sequence (cvi_dp_trainer.py:221-235): the iteration's ELBO / NLPD / RMSE are taken with the new drift
+            # parameters but the OLD p(x0); only then is p(x0) reset to the stationary OU covariance
+            model._refresh_sde_params()
             elbo_vals.append(float(model.classic_elbo()))
             nl, rm = self._nlpd_rmse()
             nlpd_vals.append(nl)
             rmse_vals.append(rm)
             self.store_prior_param_vals()
+            if isinstance(sde, OrnsteinUhlenbeckSDE):
+                # stationary initial state q / (2 decay) (cvi_dp_trainer.py:231-235)
+                d = model.state_dim
+                cov = torch.diag(torch.tensor(sde.q_diag, dtype=torch.float64)) / (2.0 * sde.decay)
+                model.set_prior_initial_state(torch.zeros(d, dtype=torch.float64).numpy(), cov.numpy())
             if elbo_vals[-1] < elbo_vals[-2]:
                 logger.info("Decaying the LR!!!")
                 self.prior_sde_optim.lr /= 2

@@ -211,7 +211,10 @@ class CVISitesSSM:
 
     # -- updates -------------------------------------------------------------------------------------------
     def _obs_flat(self):
-        return self._observations.reshape(self.B * self.n_obs, self.state_dim)
+        # one view object for the model's lifetime: the likelihood keys its gradient cache on the tensor object and its version
+        if getattr(self, "_obs_flat_view", None) is None:
+            self._obs_flat_view = self._observations.view(self.B * self.n_obs, self.state_dim)
+        return self._obs_flat_view
 
     def _obs_marginals(self):
         """(mu, Sigma) at the observation times for the current sites (the reference's self.fx_mus / fx_covs gathered)."""
@@ -270,10 +273,8 @@ class CVISitesSSM:
             # multivariate Gaussian likelihood: gather, element-wise arithmetic and per-trajectory sum in one launch (it also
             # refreshes the gathered marginals)
             q = self._refresh()
-            if getattr(lik, "_ve_cst", None) is None:
-                lik._ve_cst = -float(lik.log_det_chol) - 0.5 * lik.obs_dim * math.log(2.0 * math.pi)
             ve = self.plan.mvn_obs_ve(q["mu"], q["Sig"], self.obs_node_ids, self.n_obs, self._obs_flat(), lik.inv_covariance,
-                                      lik._ve_cst, out_mu=self.fx_mus_obs, out_cov=self.fx_covs_obs)
+                                      lik.ve_constant, out_mu=self.fx_mus_obs, out_cov=self.fx_covs_obs)
             self._obs_fresh = True
             return ve
         if self._q is None or not getattr(self, "_obs_fresh", False):
