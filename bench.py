@@ -1,7 +1,9 @@
 """
 bench.py -- ELBO steps/sec of the CVI site-update loop on the block-tri-diagonal Gauss-Markov path.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1: either the caller starts the N ranks (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...), or,
+      when no torch.distributed environment is present, bench.py starts them itself as a child job and relays rank 0's line.
 
 One "step" = one iteration of the reference's inner training loop (docs/diffusion_processes/cvi_dp_trainer.py:72-75):
     model.update_data_sites(lr); model.update_girsanov_sites(lr); model.classic_elbo()
@@ -15,14 +17,39 @@ Prints ONE JSON line (rank 0) with the contract fields plus
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def launch_ranks(n):
+    """
+    `python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks as a CHILD
+    `python -m torch.distributed.run` job (one process per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  This
+    process has not touched the GPU (nothing but the standard library is imported yet) and never replaces itself.
+    """
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank job failed (exit code {proc.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    print(lines[-1])
+    sys.exit(0)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 
@@ -95,6 +122,7 @@ def vdp_step_rate(B, T, d, dt, noise, idx, ys, device, steps=10):
     (Lagrange sweep + parameter update, forward pass, ELBO), stabilize_system on, q started at the OU drift -4 x (from A = 0 the
     marginal variance of a chain this long reaches T dt and the sixth-order moments overflow the first update).
     """
+    import torch
     import vidp_amd
     from vidp_amd.likelihoods import MultivariateGaussian
     from vidp_amd.sde import DoubleWellSDE
@@ -152,8 +180,19 @@ def main():
     ap.add_argument("--obs-every", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vdp", action="store_true", help="skip the secondary VDP step measurement")
+    ap.add_argument("--data-rank", type=int, default=None,
+                    help="generate the synthetic trajectories of this rank (default: the process's own rank); lets a single-rank run "
+                         "reproduce one shard of a multi-rank run")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)          # does not return
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != env_world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {env_world} rank(s); refusing to report a mislabelled number",
+              file=sys.stderr)
+        sys.exit(2)
 
+    import torch
     import vidp_amd
     from vidp_amd import distributed as vdist
     # "nccl" is RCCL on ROCm; VIDP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path only)
@@ -171,7 +210,8 @@ def main():
 
     B, T, d = args.B, args.T, args.d
     dt, noise = 0.01, 0.1
-    idx, ys = synth_double_well(B, T, d, dt, args.obs_every, noise, seed=71892305 + 3 + rank)
+    data_rank = rank if args.data_rank is None else args.data_rank
+    idx, ys = synth_double_well(B, T, d, dt, args.obs_every, noise, seed=71892305 + 3 + data_rank)
     plan = vidp_amd.Plan(B, T, d, device=device)
     grid = np.arange(T) * dt
     lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))

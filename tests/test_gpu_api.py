@@ -1286,3 +1286,31 @@ def test_likelihood_gradient_cache_is_not_keyed_on_addresses(amd, rng):
     lik.chol_covariance = dev(0.5 * np.eye(d))            # replacing the factor rebuilds the inverse and drops the cache
     y = dev(rng.normal(size=(n, d)))
     np.testing.assert_allclose(host(lik.ve_gradients_expectation(mu, cov, y)[0]), host(y) / 0.25, rtol=1e-12)
+
+
+def test_bench_gpus_2_launches_two_ranks(amd):
+    """`python bench.py --gpus 2` (no torch.distributed environment) starts two ranks itself -- here over gloo on the one GPU of the
+    box, VIDP_DIST_BACKEND=gloo -- reports n_gpus == 2, and its all-reduced ELBO is the sum of two single-rank runs on the same two
+    shards of trajectories."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VIDP_DIST_BACKEND"] = "gloo"
+    common = ["--steps", "2", "--warmup", "1", "--B", "4", "--T", "2000", "--no-cpu-baseline", "--no-vdp"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra + common, env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+
+    two = run(["--gpus", "2"])
+    assert two["n_gpus"] == 2 and two["config"]["total_trajectories"] == 8 and two["scaling"] == "weak"
+    singles = [run(["--gpus", "1", "--data-rank", str(r)]) for r in range(2)]
+    assert all(s["n_gpus"] == 1 for s in singles)
+    np.testing.assert_allclose(two["elbo_last"], sum(s["elbo_last"] for s in singles), rtol=1e-12)

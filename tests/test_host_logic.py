@@ -92,3 +92,15 @@ def test_shard_bounds_cover_every_segment():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(10, 3, 3)
+
+
+def test_bench_refuses_a_mislabelled_world_size():
+    """`bench.py --gpus N` must never print an n_gpus the launcher did not provide: with a torch.distributed environment of another
+    size it exits non-zero before touching the GPU (and with none, it starts the N ranks itself: tests/test_gpu_api.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()

@@ -27,10 +27,13 @@ def init_from_env(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
+        local = int(os.environ.get("LOCAL_RANK", "0"))
         if backend == "nccl":
-            local = int(os.environ.get("LOCAL_RANK", "0"))
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
+        elif torch.cuda.is_available():
+            # gloo rehearsal of the multi-rank path: ranks share the GPUs that exist (several ranks per card on a one-GPU box)
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend, **kw)
     return rank, world
 
