@@ -38,9 +38,19 @@ int launch_forward(const SweepArgs& a, bool has_rhs, bool has_corr, bool has_up,
 }
 
 template <int D>
-int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub, hipStream_t st) {
+int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub, hipStream_t st, bool coarse = false) {
     dim3 grid(a.lv.Lpad / 64), block(64);
     const bool mom = (a.momg != nullptr);
+    if (coarse) {
+        // a level above the finest one: node-major arrays, marginals only
+        if (want_sub || mom || a.Gg == nullptr) return 1;
+#define BWC(R_, U_) hipLaunchKernelGGL((k_backward<D, R_, U_, false, false, false, true>), grid, block, 0, st, a)
+        if (has_rhs) { if (has_up) BWC(true, true); else BWC(true, false); }
+        else { if (has_up) BWC(false, true); else BWC(false, false); }
+#undef BWC
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
 #define BW(R_, U_, S_, M_) hipLaunchKernelGGL((k_backward<D, R_, U_, S_, M_>), grid, block, 0, st, a)
     if (a.Gg == nullptr && a.Sg != nullptr) {
         // level 0 rebuilt from the input sub-diagonal blocks (the forward pass stored no L_{t+1,t}); means wanted, no Sub
@@ -68,36 +78,24 @@ int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub
     return 0;
 }
 
-// fills the coarse-level pointers of `a` for level l from the workspace
-void bind_level_inputs(const Plan& P, int l, double* ws, SweepArgs& a) {
-    // inputs of level l >= 1 are the reduced system written by reduce(l-1)
-    a.Dg = ws + P.off_Dhat[l];
-    a.Dcorr = ws + P.off_Rsub[l];
-    a.Sg = ws + P.off_S[l];
-    a.rg = ws + P.off_rhat[l];
-    a.rcorr = ws + P.off_rho[l];
-    a.aD = a.aS = a.aR = 1.0;
-    a.Lg = ws + P.off_L[l];
-    a.Gg = ws + P.off_G[l];
-    a.yg = ws + P.off_y[l];
-    a.Sigg = ws + P.off_Sig[l];
-    a.Subg = nullptr;
-    a.mug = ws + P.off_mu[l];
-    a.part = nullptr;
+// First level handled by the fused coarse-level kernels (k_coarse_factor / k_coarse_backward): the lowest level >= 1 whose chains
+// have at most `MFGM_FUSE_P` (default 256 = one lane per segment in a 256-thread workgroup) segments; nlevels when fusing is off
+// (MFGM_COARSE_FUSED=0) or no such level exists.  Levels 1 .. l0-1 keep one launch per level and pass.
+int coarse_fuse_from(const Plan& P) {
+    static const int enabled = [] { const char* e = getenv("MFGM_COARSE_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    static const int maxp = [] { const char* e = getenv("MFGM_FUSE_P"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    if (!enabled || P.nlevels < 2) return P.nlevels;
+    for (int l = 1; l < P.nlevels; ++l)
+        if (P.lv[l].P <= maxp) return l;
+    return P.nlevels;
 }
 
-void bind_up(const Plan& P, int l, double* ws, SweepArgs& a) {
-    // coarser level l+1
-    a.up = P.lv[l + 1];
-    a.uDhat = ws + P.off_Dhat[l + 1];
-    a.uRsub = ws + P.off_Rsub[l + 1];
-    a.uS = ws + P.off_S[l + 1];
-    a.urhat = ws + P.off_rhat[l + 1];
-    a.urho = ws + P.off_rho[l + 1];
-    a.uL = ws + P.off_L[l + 1];
-    a.uy = ws + P.off_y[l + 1];
-    a.uSig = ws + P.off_Sig[l + 1];
-    a.umu = ws + P.off_mu[l + 1];
+template <int D>
+int launch_coarse_backward(const Plan& P, int lf, bool has_rhs, double* ws, hipStream_t st) {
+    if (has_rhs) hipLaunchKernelGGL((k_coarse_backward<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws);
+    else hipLaunchKernelGGL((k_coarse_backward<D, false>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws);
+    MFGM_CHECK_LAUNCH();
+    return 0;
 }
 
 template <int D>
@@ -121,13 +119,20 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
         if (l < K) bind_up(P, l, ws, a);
         return a;
     };
-    for (int l = 0; l < K; ++l) {
+    // levels lf .. K in one launch (reduce lf .. K-1, forward K .. lf); single-kernel profiling calls keep one launch per level
+    const int lf = (only_stage >= 0) ? P.nlevels : coarse_fuse_from(P);
+    for (int l = 0; l < K && l < lf; ++l) {
         if (only_stage >= 0 && !(only_stage == 0 && only_level == l)) continue;
         SweepArgs a = make(l);
         int rc = launch_reduce<D>(a, has_rhs, l > 0, st);
         if (rc) return rc;
     }
-    for (int l = K; l >= 0; --l) {
+    if (lf <= K) {
+        if (has_rhs) hipLaunchKernelGGL((k_coarse_factor<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info);
+        else hipLaunchKernelGGL((k_coarse_factor<D, false>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info);
+        MFGM_CHECK_LAUNCH();
+    }
+    for (int l = std::min(K, lf - 1); l >= 0; --l) {
         if (only_stage >= 0 && !(only_stage == 1 && only_level == l)) continue;
         SweepArgs a = make(l);
         int rc = launch_forward<D>(a, has_rhs, l > 0, l < K, st);
@@ -147,7 +152,12 @@ int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double*
                 double aS = 1.0) {
     const bool has_rhs = (yg != nullptr);
     const int K = P.nlevels - 1;
-    for (int l = K; l >= 0; --l) {
+    const int lf = (only_level >= 0) ? P.nlevels : coarse_fuse_from(P);
+    if (lf <= K) {
+        int rc = launch_coarse_backward<D>(P, lf, has_rhs, ws, st);
+        if (rc) return rc;
+    }
+    for (int l = std::min(K, lf - 1); l >= 0; --l) {
         if (only_level >= 0 && only_level != l) continue;
         SweepArgs a;
         memset(&a, 0, sizeof(a));
@@ -160,7 +170,7 @@ int selinv_impl(const Plan& P, const double* Lg, const double* Gg, const double*
             bind_level_inputs(P, l, ws, a);
         }
         if (l < K) bind_up(P, l, ws, a);
-        int rc = launch_backward<D>(a, has_rhs, l < K, l == 0 && Sub != nullptr, st);
+        int rc = launch_backward<D>(a, has_rhs, l < K, l == 0 && Sub != nullptr, st, l > 0);
         if (rc) return rc;
     }
     return 0;
@@ -171,14 +181,19 @@ int selinv_girsanov_impl(const Plan& P, const double* Lg, const double* Sg, doub
                          const GirsanovArgs& g, double* ws, hipStream_t st, int only_level) {
     // coarser levels exactly as in a plain selected inverse, then the fused level-0 sweep
     const int K = P.nlevels - 1;
-    for (int l = K; l >= 1; --l) {
+    const int lf = (only_level >= 0) ? P.nlevels : coarse_fuse_from(P);
+    if (lf <= K) {
+        int rc = launch_coarse_backward<D>(P, lf, true, ws, st);
+        if (rc) return rc;
+    }
+    for (int l = std::min(K, lf - 1); l >= 1; --l) {
         if (only_level >= 0 && only_level != l) continue;
         SweepArgs a;
         memset(&a, 0, sizeof(a));
         a.lv = P.lv[l];
         bind_level_inputs(P, l, ws, a);
         if (l < K) bind_up(P, l, ws, a);
-        int rc = launch_backward<D>(a, true, l < K, false, st);
+        int rc = launch_backward<D>(a, true, l < K, false, st, true);
         if (rc) return rc;
     }
     if (only_level > 0) return 0;
@@ -201,14 +216,19 @@ template <int D>
 int selinv_kl_impl(const Plan& P, const double* Lg, const double* Sg, double aS, const double* yg, const SdeParams& pr, double* Sig,
                    double* x, double* kl, double* ws, hipStream_t st, int only_level) {
     const int K = P.nlevels - 1;
-    for (int l = K; l >= 1; --l) {
+    const int lf = (only_level >= 0) ? P.nlevels : coarse_fuse_from(P);
+    if (lf <= K) {
+        int rc = launch_coarse_backward<D>(P, lf, true, ws, st);
+        if (rc) return rc;
+    }
+    for (int l = std::min(K, lf - 1); l >= 1; --l) {
         if (only_level >= 0 && only_level != l) continue;
         SweepArgs a;
         memset(&a, 0, sizeof(a));
         a.lv = P.lv[l];
         bind_level_inputs(P, l, ws, a);
         if (l < K) bind_up(P, l, ws, a);
-        int rc = launch_backward<D>(a, true, l < K, false, st);
+        int rc = launch_backward<D>(a, true, l < K, false, st, true);
         if (rc) return rc;
     }
     if (only_level > 0) return 0;

@@ -170,10 +170,11 @@ MFGM_DEV void up_moments(const SweepArgs& a, int b, int q, double (&m)[D], doubl
     constexpr int ET = MFGM_NTRI(D);
     const int uP = a.up.P, uR = a.up.R, ul = b * uP + q / uR, us = q % uR;
     const LaneRef uw = LaneRef::of(ul);
-    ld_node<D>(a.umu, uR, us, uw, m);
-    const double* ps = a.uSig + ((size_t)uw.tile * uR + us) * (size_t)(ET * 64);
+    ld_node<D, true>(a.umu, uR, us, uw, m);
+    const size_t node = (size_t)ul * uR + us;                      // node-major layout of the coarser level
+    const double* ps = a.uSig + ((node >> 6) * ET) * 64 + (node & 63);
 #pragma unroll
-    for (int i = 0; i < D; ++i) v[i] = ps[tix(i, i) * 64 + uw.l];
+    for (int i = 0; i < D; ++i) v[i] = ps[tix(i, i) * 64];
 }
 
 // Level-0 backward sweep (always below a coarser level, means wanted, L_{t+1,t} rebuilt from theta_sub: the USE_S variant of
@@ -194,8 +195,8 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov(SweepArgs a, Sd
     double Sn[ET], xn[D];
     {
         const int ul = b * uP + p / uR, us = p % uR;
-        ld_node<ET>(a.uSig, uR, us, LaneRef::of(ul), Sn);
-        ld_node<D>(a.umu, uR, us, LaneRef::of(ul), xn);
+        ld_node<ET, true>(a.uSig, uR, us, LaneRef::of(ul), Sn);
+        ld_node<D, true>(a.umu, uR, us, LaneRef::of(ul), xn);
     }
     double pend[D];     // theta~_lin of the node one step ahead, still waiting for the pair of the node about to be visited
 #pragma unroll
@@ -338,8 +339,8 @@ static __global__ __launch_bounds__(64) void k_backward_kl(SweepArgs a, SdeParam
     double Sn[ET], xn[D];
     {
         const int ul = b * uP + p / uR, us = p % uR;
-        ld_node<ET>(a.uSig, uR, us, LaneRef::of(ul), Sn);
-        ld_node<D>(a.umu, uR, us, LaneRef::of(ul), xn);
+        ld_node<ET, true>(a.uSig, uR, us, LaneRef::of(ul), Sn);
+        ld_node<D, true>(a.umu, uR, us, LaneRef::of(ul), xn);
     }
     st_node<ET>(a.Sigg, R, se, me, Sn);
     st_node<D>(a.mug, R, se, me, xn);

@@ -9,6 +9,7 @@
 
 #define MFGM_NTRI(D) ((D) * ((D) + 1) / 2)
 #define MFGM_DEV __device__ __forceinline__
+#define MFGM_HD __host__ __device__ inline
 
 namespace mfgm {
 

@@ -22,23 +22,49 @@ struct LaneRef {
     int tile, l;
     MFGM_DEV static LaneRef of(int lane) { return LaneRef{lane >> 6, lane & 63}; }
 };
-template <int E>
+// NM ("node-major") is the layout of the levels above the finest one: node = lane * R + s of the level, element e at
+//   ((node / 64) * E + e) * 64 + node % 64
+// so that the separators written by consecutive lanes of the level below (one node each) are contiguous, and a lane of this level
+// reads its R consecutive nodes from the same few cache lines.  (In the lane-interleaved layout of level 0 those hand-overs
+// touch one 64-byte sector per lane and element.)  Same array sizes as the lane-interleaved layout.
+template <int E, bool NM = false>
 MFGM_DEV void ld_node(const double* __restrict__ base, int R, int s, LaneRef w, double (&out)[E]) {
-    const double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+    if constexpr (NM) {
+        const size_t node = (size_t)(w.tile * 64 + w.l) * R + s;
+        const double* p = base + ((node >> 6) * E) * 64 + (node & 63);
 #pragma unroll
-    for (int e = 0; e < E; ++e) out[e] = p[e * 64 + w.l];
+        for (int e = 0; e < E; ++e) out[e] = p[e * 64];
+    } else {
+        const double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[e] = p[e * 64 + w.l];
+    }
 }
-template <int E>
+template <int E, bool NM = false>
 MFGM_DEV void st_node(double* __restrict__ base, int R, int s, LaneRef w, const double (&v)[E]) {
-    double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+    if constexpr (NM) {
+        const size_t node = (size_t)(w.tile * 64 + w.l) * R + s;
+        double* p = base + ((node >> 6) * E) * 64 + (node & 63);
 #pragma unroll
-    for (int e = 0; e < E; ++e) p[e * 64 + w.l] = v[e];
+        for (int e = 0; e < E; ++e) p[e * 64] = v[e];
+    } else {
+        double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e * 64 + w.l] = v[e];
+    }
 }
-template <int E>
+template <int E, bool NM = false>
 MFGM_DEV void st_node_zero(double* __restrict__ base, int R, int s, LaneRef w) {
-    double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+    if constexpr (NM) {
+        const size_t node = (size_t)(w.tile * 64 + w.l) * R + s;
+        double* p = base + ((node >> 6) * E) * 64 + (node & 63);
 #pragma unroll
-    for (int e = 0; e < E; ++e) p[e * 64 + w.l] = 0.0;
+        for (int e = 0; e < E; ++e) p[e * 64] = 0.0;
+    } else {
+        double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e * 64 + w.l] = 0.0;
+    }
 }
 
 struct SweepArgs {
@@ -69,29 +95,28 @@ struct SweepArgs {
 };
 
 // ---- reduce -------------------------------------------------------------------------------------
+// The bodies are device functions of (lane, me): the per-level kernels call them with the wave's uniform tile (me = {blockIdx.x,
+// threadIdx.x}: scalar node pointers), the fused coarse-level kernels (k_coarse_*) with arbitrary lanes of one chain.
 template <int D, bool HAS_RHS, bool HAS_CORR>
-static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
+MFGM_DEV void reduce_body(const SweepArgs& a, const int lane, const LaneRef me) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
-    const int lane = blockIdx.x * 64 + threadIdx.x;
-    if (lane >= a.lv.L) return;
-    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, a.lv.n - p * R);
     int bad = 0;
 
     double F[ET], W[EF], h[D], Racc[ET], rho[D];
-    ld_node<ET>(a.Dg, R, 0, me, F);
+    ld_node<ET, HAS_CORR>(a.Dg, R, 0, me, F);
 #pragma unroll
     for (int e = 0; e < ET; ++e) F[e] *= a.aD;
     if (HAS_CORR) {
         double c[ET];
-        ld_node<ET>(a.Dcorr, R, 0, me, c);
+        ld_node<ET, HAS_CORR>(a.Dcorr, R, 0, me, c);
 #pragma unroll
         for (int e = 0; e < ET; ++e) F[e] -= c[e];
     }
     if (p > 0) {
-        ld_node<EF>(a.Sg, R, R - 1, LaneRef::of(lane - 1), W);
+        ld_node<EF, HAS_CORR>(a.Sg, R, R - 1, LaneRef::of(lane - 1), W);
 #pragma unroll
         for (int e = 0; e < EF; ++e) W[e] *= a.aS;
     } else {
@@ -99,12 +124,12 @@ static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
         for (int e = 0; e < EF; ++e) W[e] = 0.0;
     }
     if (HAS_RHS) {
-        ld_node<D>(a.rg, R, 0, me, h);
+        ld_node<D, HAS_CORR>(a.rg, R, 0, me, h);
 #pragma unroll
         for (int e = 0; e < D; ++e) h[e] *= a.aR;
         if (HAS_CORR) {
             double c[D];
-            ld_node<D>(a.rcorr, R, 0, me, c);
+            ld_node<D, HAS_CORR>(a.rcorr, R, 0, me, c);
 #pragma unroll
             for (int e = 0; e < D; ++e) h[e] -= c[e];
         }
@@ -122,9 +147,9 @@ static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
     // simpler same-step loads: the correction arrays would not fit the register file next to a second buffer.)
     double Gn[EF], Dn[ET], rn[D];
     auto load_step = [&](int s, double (&Go)[EF], double (&Do)[ET], double (&ro)[D]) {
-        ld_node<EF>(a.Sg, R, s, me, Go);
-        ld_node<ET>(a.Dg, R, s + 1, me, Do);
-        if (HAS_RHS) ld_node<D>(a.rg, R, s + 1, me, ro);
+        ld_node<EF, HAS_CORR>(a.Sg, R, s, me, Go);
+        ld_node<ET, HAS_CORR>(a.Dg, R, s + 1, me, Do);
+        if (HAS_RHS) ld_node<D, HAS_CORR>(a.rg, R, s + 1, me, ro);
     };
     if (!HAS_CORR && len > 1) load_step(0, Gn, Dn, rn);
     for (int s = 0; s < R - 1; ++s) {
@@ -132,8 +157,8 @@ static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
             double G[EF], Dc_[ET], rc_[D], Dcur[ET], rcur[D];
             if (HAS_CORR) {
                 load_step(s, G, Dcur, rcur);
-                ld_node<ET>(a.Dcorr, R, s + 1, me, Dc_);
-                if (HAS_RHS) ld_node<D>(a.rcorr, R, s + 1, me, rc_);
+                ld_node<ET, HAS_CORR>(a.Dcorr, R, s + 1, me, Dc_);
+                if (HAS_RHS) ld_node<D, HAS_CORR>(a.rcorr, R, s + 1, me, rc_);
             } else {
 #pragma unroll
                 for (int e = 0; e < EF; ++e) G[e] = Gn[e];
@@ -187,30 +212,33 @@ static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
     const int uP = a.up.P, uR = a.up.R;
     {
         const int q = p, ul = b * uP + q / uR, us = q % uR;
-        st_node<ET>(a.uDhat, uR, us, LaneRef::of(ul), F);
-        st_node<D>(a.urhat, uR, us, LaneRef::of(ul), h);
+        st_node<ET, true>(a.uDhat, uR, us, LaneRef::of(ul), F);
+        st_node<D, true>(a.urhat, uR, us, LaneRef::of(ul), h);
         if (p == P - 1) {
-            st_node_zero<ET>(a.uRsub, uR, us, LaneRef::of(ul));
-            st_node_zero<D>(a.urho, uR, us, LaneRef::of(ul));
-            st_node_zero<EF>(a.uS, uR, us, LaneRef::of(ul));
+            st_node_zero<ET, true>(a.uRsub, uR, us, LaneRef::of(ul));
+            st_node_zero<D, true>(a.urho, uR, us, LaneRef::of(ul));
+            st_node_zero<EF, true>(a.uS, uR, us, LaneRef::of(ul));
         }
     }
     if (p > 0) {
         const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
-        st_node<EF>(a.uS, uR, us, LaneRef::of(ul), W);      // couples separator p-1 -> p
-        st_node<ET>(a.uRsub, uR, us, LaneRef::of(ul), Racc);
-        st_node<D>(a.urho, uR, us, LaneRef::of(ul), rho);
+        st_node<EF, true>(a.uS, uR, us, LaneRef::of(ul), W);      // couples separator p-1 -> p
+        st_node<ET, true>(a.uRsub, uR, us, LaneRef::of(ul), Racc);
+        st_node<D, true>(a.urho, uR, us, LaneRef::of(ul), rho);
     }
     if (bad) atomicMax(a.info, 1);
+}
+template <int D, bool HAS_RHS, bool HAS_CORR>
+static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    reduce_body<D, HAS_RHS, HAS_CORR>(a, lane, LaneRef{(int)blockIdx.x, (int)threadIdx.x});
 }
 
 // ---- forward ------------------------------------------------------------------------------------
 template <int D, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
-static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
+MFGM_DEV void forward_body(const SweepArgs& a, const int lane, const LaneRef me) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
-    const int lane = blockIdx.x * 64 + threadIdx.x;
-    if (lane >= a.lv.L) return;
-    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -228,8 +256,8 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
         const int uP = a.up.P, uR = a.up.R;
         const int q = p - 1, ul = b * uP + q / uR, us = q % uR;
         double Lt[ET], Fa[ET], ha[D], invd[D];
-        ld_node<ET>(a.uL, uR, us, LaneRef::of(ul), Lt);
-        ld_node<ET>(a.uRsub, uR, us, LaneRef::of(ul), Fa);
+        ld_node<ET, true>(a.uL, uR, us, LaneRef::of(ul), Lt);
+        ld_node<ET, true>(a.uRsub, uR, us, LaneRef::of(ul), Fa);
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -241,8 +269,8 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
             }
         if (HAS_RHS) {
             double yt[D];
-            ld_node<D>(a.uy, uR, us, LaneRef::of(ul), yt);
-            ld_node<D>(a.urho, uR, us, LaneRef::of(ul), ha);
+            ld_node<D, true>(a.uy, uR, us, LaneRef::of(ul), yt);
+            ld_node<D, true>(a.urho, uR, us, LaneRef::of(ul), ha);
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 double t = ha[i];
@@ -257,7 +285,7 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
         chol_inplace<D>(Fa, invd, bad);
         trsv_lower<D>(Fa, invd, ha);
         double Ga[EF];
-        ld_node<EF>(a.Sg, R, R - 1, LaneRef::of(lane - 1), Ga);
+        ld_node<EF, HAS_CORR>(a.Sg, R, R - 1, LaneRef::of(lane - 1), Ga);
 #pragma unroll
         for (int e = 0; e < EF; ++e) Ga[e] *= a.aS;
         trsm_right_lower_t<D>(Fa, invd, Ga);
@@ -275,17 +303,17 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
     // scales / corrections are applied at the point of use so no wait is forced at the load.
     double Fn[ET], Gn[EF], rn[D], Fc[HAS_CORR ? ET : 1], rc[HAS_CORR ? D : 1];
     auto load_step = [&](int s) {
-        ld_node<ET>(a.Dg, R, s, me, Fn);
-        if constexpr (HAS_CORR) ld_node<ET>(a.Dcorr, R, s, me, reinterpret_cast<double(&)[ET]>(Fc));
+        ld_node<ET, HAS_CORR>(a.Dg, R, s, me, Fn);
+        if constexpr (HAS_CORR) ld_node<ET, HAS_CORR>(a.Dcorr, R, s, me, reinterpret_cast<double(&)[ET]>(Fc));
         if (p * R + s + 1 < n) {
-            ld_node<EF>(a.Sg, R, s, me, Gn);
+            ld_node<EF, HAS_CORR>(a.Sg, R, s, me, Gn);
         } else {
 #pragma unroll
             for (int e = 0; e < EF; ++e) Gn[e] = 0.0;
         }
         if (HAS_RHS) {
-            ld_node<D>(a.rg, R, s, me, rn);
-            if constexpr (HAS_CORR) ld_node<D>(a.rcorr, R, s, me, reinterpret_cast<double(&)[D]>(rc));
+            ld_node<D, HAS_CORR>(a.rg, R, s, me, rn);
+            if constexpr (HAS_CORR) ld_node<D, HAS_CORR>(a.rcorr, R, s, me, reinterpret_cast<double(&)[D]>(rc));
         }
     };
     load_step(0);
@@ -304,9 +332,9 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
             chol_inplace<D>(F, invd, bad);
             if (HAS_RHS) trsv_lower<D>(F, invd, h);
             trsm_right_lower_t<D>(F, invd, G);
-            st_node<ET>(a.Lg, R, s, me, F);
-            if (a.Gg) st_node<EF>(a.Gg, R, s, me, G);     // callers that rebuild H from S in the backward pass skip this store
-            if (HAS_RHS) st_node<D>(a.yg, R, s, me, h);
+            st_node<ET, HAS_CORR>(a.Lg, R, s, me, F);
+            if (a.Gg) st_node<EF, HAS_CORR>(a.Gg, R, s, me, G);     // callers that rebuild H from S in the backward pass skip this store
+            if (HAS_RHS) st_node<D, HAS_CORR>(a.yg, R, s, me, h);
             syrk_set<D>(G, C);
             if (HAS_RHS) gemv<D>(G, h, c);
 #pragma unroll
@@ -322,18 +350,21 @@ static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
     }
     if (bad) atomicMax(a.info, 1);
 }
+template <int D, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
+static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    forward_body<D, HAS_RHS, HAS_CORR, HAS_UP>(a, lane, LaneRef{(int)blockIdx.x, (int)threadIdx.x});
+}
 
 // ---- backward -----------------------------------------------------------------------------------
 // USE_S: the forward pass did not store L_{t+1,t} = S L^{-T}; with P = L^{-T} L^{-1} the same quantities follow from the input
 // sub-diagonal block S (scaled by aS):  H = L_{t+1,t} L^{-1} = S P,  L_{t+1,t}^T x = L^{-1} (S^T x).  Same bytes read here (S for
 // L_{t+1,t}), d^2 doubles per node fewer written by the forward pass.
-template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM, bool USE_S = false>
-static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
+template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM, bool USE_S = false, bool CL = false>
+MFGM_DEV void backward_body(const SweepArgs& a, const int lane, const LaneRef me) {
     const double* __restrict__ Gsrc = USE_S ? a.Sg : a.Gg;
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
-    const int lane = blockIdx.x * 64 + threadIdx.x;
-    if (lane >= a.lv.L) return;
-    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -343,17 +374,17 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     if (HAS_UP) {
         const int uP = a.up.P, uR = a.up.R;
         const int q = p, ul = b * uP + q / uR, us = q % uR;
-        ld_node<ET>(a.uSig, uR, us, LaneRef::of(ul), Sn);
-        if (HAS_RHS) ld_node<D>(a.umu, uR, us, LaneRef::of(ul), xn);
+        ld_node<ET, true>(a.uSig, uR, us, LaneRef::of(ul), Sn);
+        if (HAS_RHS) ld_node<D, true>(a.umu, uR, us, LaneRef::of(ul), xn);
     } else {
         double Lt[ET], invd[D], X[ET];
-        ld_node<ET>(a.Lg, R, se, me, Lt);
+        ld_node<ET, CL>(a.Lg, R, se, me, Lt);
 #pragma unroll
         for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
         tri_inverse<D>(Lt, invd, X);
         tri_t_tri<D>(X, Sn);
         if (HAS_RHS) {
-            ld_node<D>(a.yg, R, se, me, xn);
+            ld_node<D, CL>(a.yg, R, se, me, xn);
             trsv_lower_t<D>(Lt, invd, xn);
         }
     }
@@ -361,9 +392,9 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 #pragma unroll
         for (int e = 0; e < D; ++e) xn[e] = 0.0;
     }
-    st_node<ET>(a.Sigg, R, se, me, Sn);
-    if (HAS_RHS) st_node<D>(a.mug, R, se, me, xn);
-    if (WANT_SUB && (p * R + se == n - 1)) st_node_zero<EF>(a.Subg, R, se, me);
+    st_node<ET, CL>(a.Sigg, R, se, me, Sn);
+    if (HAS_RHS) st_node<D, CL>(a.mug, R, se, me, xn);
+    if (WANT_SUB && (p * R + se == n - 1)) st_node_zero<EF, CL>(a.Subg, R, se, me);
     if (WANT_MOM) {
         // (mu, diag Sigma) of the separator now; diag Sigma_{t+1,t} of the separator is written by the lane on its right
         double mm[3 * D];
@@ -380,9 +411,9 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 
     double Ln[ET], Gn[EF], yn[D];
     if (len > 1) {
-        ld_node<ET>(a.Lg, R, se - 1, me, Ln);
-        ld_node<EF>(Gsrc, R, se - 1, me, Gn);
-        if (HAS_RHS) ld_node<D>(a.yg, R, se - 1, me, yn);
+        ld_node<ET, CL>(a.Lg, R, se - 1, me, Ln);
+        ld_node<EF, CL>(Gsrc, R, se - 1, me, Gn);
+        if (HAS_RHS) ld_node<D, CL>(a.yg, R, se - 1, me, yn);
     }
     for (int s = R - 2; s >= 0; --s) {
         if (s < len - 1) {
@@ -394,9 +425,9 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 #pragma unroll
             for (int e = 0; e < D; ++e) x[e] = HAS_RHS ? yn[e] : 0.0;
             if (s > 0) {
-                ld_node<ET>(a.Lg, R, s - 1, me, Ln);
-                ld_node<EF>(Gsrc, R, s - 1, me, Gn);
-                if (HAS_RHS) ld_node<D>(a.yg, R, s - 1, me, yn);
+                ld_node<ET, CL>(a.Lg, R, s - 1, me, Ln);
+                ld_node<EF, CL>(Gsrc, R, s - 1, me, Gn);
+                if (HAS_RHS) ld_node<D, CL>(a.yg, R, s - 1, me, yn);
             }
             double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET];
 #pragma unroll
@@ -439,17 +470,17 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
 #pragma unroll
                 for (int e = 0; e < D; ++e) x[e] -= t[e];
                 trsv_lower_t<D>(Lt, invd, x);
-                st_node<D>(a.mug, R, s, me, x);
+                st_node<D, CL>(a.mug, R, s, me, x);
 #pragma unroll
                 for (int e = 0; e < D; ++e) xn[e] = x[e];
             }
-            st_node<ET>(a.Sigg, R, s, me, Sig);
-            if (WANT_SUB) st_node<EF>(a.Subg, R, s, me, Ssub);
+            st_node<ET, CL>(a.Sigg, R, s, me, Sig);
+            if (WANT_SUB) st_node<EF, CL>(a.Subg, R, s, me, Ssub);
             if (WANT_MOM) {
                 double mm[3 * D];
 #pragma unroll
                 for (int i = 0; i < D; ++i) { mm[i] = x[i]; mm[D + i] = Sig[tix(i, i)]; mm[2 * D + i] = Ssub[i * D + i]; }
-                st_node<3 * D>(a.momg, R, s, me, mm);
+                st_node<3 * D, CL>(a.momg, R, s, me, mm);
             }
 #pragma unroll
             for (int e = 0; e < ET; ++e) Sn[e] = Sig[e];
@@ -458,8 +489,8 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     if ((WANT_SUB || WANT_MOM) && p > 0) {
         // S_{t0, t0-1} for the separator on the left, whose own blocks belong to lane-1
         double Lt[ET], G[EF], invd[D], X[ET], H[EF], Ssub[EF];
-        ld_node<ET>(a.Lg, R, R - 1, LaneRef::of(lane - 1), Lt);
-        ld_node<EF>(Gsrc, R, R - 1, LaneRef::of(lane - 1), G);
+        ld_node<ET, CL>(a.Lg, R, R - 1, LaneRef::of(lane - 1), Lt);
+        ld_node<EF, CL>(Gsrc, R, R - 1, LaneRef::of(lane - 1), G);
 #pragma unroll
         for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
         tri_inverse<D>(Lt, invd, X);
@@ -481,13 +512,120 @@ static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
         gemm_sym_full<D>(Sn, H, Ssub);
 #pragma unroll
         for (int e = 0; e < EF; ++e) Ssub[e] = -Ssub[e];
-        if (WANT_SUB) st_node<EF>(a.Subg, R, R - 1, LaneRef::of(lane - 1), Ssub);
+        if (WANT_SUB) st_node<EF, CL>(a.Subg, R, R - 1, LaneRef::of(lane - 1), Ssub);
         if (WANT_MOM) {
             const LaneRef left = LaneRef::of(lane - 1);
             double* pm = a.momg + ((size_t)left.tile * R + (R - 1)) * (size_t)(3 * D * 64);
 #pragma unroll
             for (int i = 0; i < D; ++i) pm[(2 * D + i) * 64 + left.l] = Ssub[i * D + i];
         }
+    }
+}
+
+// CL: the level's own arrays are in the node-major layout (every level above the finest one)
+template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM, bool USE_S = false, bool CL = false>
+static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    backward_body<D, HAS_RHS, HAS_UP, WANT_SUB, WANT_MOM, USE_S, CL>(a, lane, LaneRef{(int)blockIdx.x, (int)threadIdx.x});
+}
+
+// ---- coarse levels in one launch per pass ----------------------------------------------------------------------------------------
+// The levels above the finest one are latency-bound (few lanes, a handful of dependent steps each): launched one kernel per level
+// they cost a launch boundary and a cold start apiece (five levels x three passes per factorisation + selected inverse at the
+// headline size).  Here ONE workgroup owns one chain and walks the levels l0 .. top itself: lane p of the workgroup is segment p of
+// the chain at every level, levels are separated by a workgroup barrier, and the level data stay in the plan workspace (written and
+// re-read by the same CU, so they are served from its L1 / the XCD's L2).  The level bodies are the same device functions the
+// per-level kernels run, so both routes produce identical numbers.
+MFGM_HD void bind_level_inputs(const Plan& P, int l, double* ws, SweepArgs& a) {
+    // inputs of level l >= 1 are the reduced system written by reduce(l-1)
+    a.Dg = ws + P.off_Dhat[l];
+    a.Dcorr = ws + P.off_Rsub[l];
+    a.Sg = ws + P.off_S[l];
+    a.rg = ws + P.off_rhat[l];
+    a.rcorr = ws + P.off_rho[l];
+    a.aD = a.aS = a.aR = 1.0;
+    a.Lg = ws + P.off_L[l];
+    a.Gg = ws + P.off_G[l];
+    a.yg = ws + P.off_y[l];
+    a.Sigg = ws + P.off_Sig[l];
+    a.Subg = nullptr;
+    a.mug = ws + P.off_mu[l];
+    a.part = nullptr;
+}
+MFGM_HD void bind_up(const Plan& P, int l, double* ws, SweepArgs& a) {
+    // coarser level l+1
+    a.up = P.lv[l + 1];
+    a.uDhat = ws + P.off_Dhat[l + 1];
+    a.uRsub = ws + P.off_Rsub[l + 1];
+    a.uS = ws + P.off_S[l + 1];
+    a.urhat = ws + P.off_rhat[l + 1];
+    a.urho = ws + P.off_rho[l + 1];
+    a.uL = ws + P.off_L[l + 1];
+    a.uy = ws + P.off_y[l + 1];
+    a.uSig = ws + P.off_Sig[l + 1];
+    a.umu = ws + P.off_mu[l + 1];
+}
+MFGM_HD SweepArgs coarse_level_args(const Plan& P, int l, double* ws, int* info) {
+    SweepArgs a = {};
+    a.lv = P.lv[l];
+    a.info = info;
+    bind_level_inputs(P, l, ws, a);
+    if (l < P.nlevels - 1) bind_up(P, l, ws, a);
+    return a;
+}
+
+constexpr int kCoarseBlock = 256;     // one wavefront per SIMD: the level bodies need the whole register file
+
+// reduce l0 .. top-1, then forward top .. l0 (l0 >= 1); grid = B workgroups
+template <int D, bool HAS_RHS>
+static __global__ __launch_bounds__(kCoarseBlock) void k_coarse_factor(Plan P, int l0, double* ws, int* info) {
+    const int K = P.nlevels - 1, b = blockIdx.x;
+    for (int l = l0; l < K; ++l) {
+        const SweepArgs a = coarse_level_args(P, l, ws, info);
+        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
+            const int lane = b * a.lv.P + p;
+            reduce_body<D, HAS_RHS, true>(a, lane, LaneRef::of(lane));
+        }
+        __syncthreads();
+    }
+    {
+        const SweepArgs a = coarse_level_args(P, K, ws, info);
+        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
+            const int lane = b * a.lv.P + p;
+            forward_body<D, HAS_RHS, true, false>(a, lane, LaneRef::of(lane));
+        }
+        __syncthreads();
+    }
+    for (int l = K - 1; l >= l0; --l) {
+        const SweepArgs a = coarse_level_args(P, l, ws, info);
+        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
+            const int lane = b * a.lv.P + p;
+            forward_body<D, HAS_RHS, true, true>(a, lane, LaneRef::of(lane));
+        }
+        __syncthreads();
+    }
+}
+
+// backward top .. l0
+template <int D, bool HAS_RHS>
+static __global__ __launch_bounds__(kCoarseBlock) void k_coarse_backward(Plan P, int l0, double* ws) {
+    const int K = P.nlevels - 1, b = blockIdx.x;
+    {
+        const SweepArgs a = coarse_level_args(P, K, ws, nullptr);
+        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
+            const int lane = b * a.lv.P + p;
+            backward_body<D, HAS_RHS, false, false, false, false, true>(a, lane, LaneRef::of(lane));
+        }
+        __syncthreads();
+    }
+    for (int l = K - 1; l >= l0; --l) {
+        const SweepArgs a = coarse_level_args(P, l, ws, nullptr);
+        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
+            const int lane = b * a.lv.P + p;
+            backward_body<D, HAS_RHS, true, false, false, false, true>(a, lane, LaneRef::of(lane));
+        }
+        __syncthreads();
     }
 }
 
