@@ -269,11 +269,10 @@ def main():
         from vidp_amd.packed import _ptr, _stream
         import ctypes
         f, s = model._bufs["f"], model._bufs["s"]
-        tq, sp = model.full_sites(), getattr(model, "_theta_spare", None)
-        fused = sp is not None
         ET, EF = d * (d + 1) // 2, d * d
         null = ctypes.c_void_p(0)
         klbuf = torch.empty(B, dtype=torch.float64, device=device)
+        cq = model._cq
 
         def timed(fn, reps=20):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -286,42 +285,77 @@ def main():
             torch.cuda.synchronize()
             return ev[0].elapsed_time(ev[1]) / reps
 
-        def stage(st):
-            # level-0 reduce (0) / forward (1) of the model's own factorisation (L_{t+1,t} not stored: G = NULL)
-            assert lib.mfgm_packed_factor_stage(plan.h, st, 0, _ptr(tq.diag), _ptr(tq.sub), _ptr(tq.lin), -2.0, -1.0, 1.0, _ptr(f["L"]),
-                                                null, _ptr(f["y"]), _ptr(plan.ws), _ptr(plan.info), _stream()) == 0
+        if cq is not None:
+            # structured posterior naturals (csrc/mfgm_cq.h): 3 d doubles per node + an int observation slot; the dense blocks are
+            # rebuilt in registers.  Level-0 kernels alone, on the model's own state (outputs overwritten with identical values).
+            cst = cq.struct()
+            out["config"]["state_layout"] = ("cq: (theta_lin, diag theta_diag, diag theta_sub) per node + uniform off-diagonals; the data "
+                                             "sites are added inside the sweeps (csrc/mfgm_cq.h)")
 
-        def backward():
-            # level-0 backward of the refresh before the ELBO: reads theta_sub in place of L_{t+1,t}; fused: the KL sum is taken in
-            # the sweep and no moment array is written
+            def stage(st):
+                assert lib.mfgm_cq_factor_stage(plan.h, st, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), _ptr(plan.ws), _ptr(plan.info),
+                                                _stream()) == 0
+
+            def backward():
+                assert lib.mfgm_cq_selinv_kl(plan.h, 0, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), ctypes.byref(model._sde_prm),
+                                             _ptr(s["Sig"]), _ptr(s["x"]), _ptr(klbuf), _ptr(model.fx_mus_obs), _ptr(model.fx_covs_obs),
+                                             _ptr(plan.ws), _stream()) == 0
+
+            def girsanov():
+                assert lib.mfgm_cq_selinv_girsanov(plan.h, 0, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), ctypes.byref(model._sde_prm),
+                                                   _ptr(cq.spare), _ptr(plan.ws), _stream()) == 0
+
+            E3, slot = 3 * d, 0.5      # the int slot per node counts as half a double
+            cand = [
+                (f"void mfgm::k_forward_cq<{d}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot) + (ET + d), lambda: stage(1),
+                 "level 0 forward: block Cholesky + forward substitution; reads the cq record and the slot, writes L and y"),
+                (f"void mfgm::k_reduce_cq<{d}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot), lambda: stage(0),
+                 "level 0 reduce: segment elimination; reads the cq record and the slot"),
+                (f"void mfgm::k_backward_kl_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs)", 1, (ET + d + d + slot) + (ET + d), backward,
+                 "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, y, diag theta_sub, slot; writes Sigma, mu"),
+                (f"void mfgm::k_backward_girsanov_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs, double*)", 1, (ET + d + E3) + E3, girsanov,
+                 "level 0 backward fused with the Girsanov-site update; reads L, y, the cq record, writes the new record"),
+            ]
+        else:
+            tq, sp = model.full_sites(), getattr(model, "_theta_spare", None)
+            fused = sp is not None
+
+            def stage(st):
+                # level-0 reduce (0) / forward (1) of the model's own factorisation (L_{t+1,t} not stored: G = NULL)
+                assert lib.mfgm_packed_factor_stage(plan.h, st, 0, _ptr(tq.diag), _ptr(tq.sub), _ptr(tq.lin), -2.0, -1.0, 1.0, _ptr(f["L"]),
+                                                    null, _ptr(f["y"]), _ptr(plan.ws), _ptr(plan.info), _stream()) == 0
+
+            def backward():
+                # level-0 backward of the refresh before the ELBO: reads theta_sub in place of L_{t+1,t}; fused: the KL sum is taken in
+                # the sweep and no moment array is written
+                if fused:
+                    assert lib.mfgm_packed_selinv_kl(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), ctypes.byref(model._sde_prm),
+                                                     _ptr(s["Sig"]), _ptr(s["x"]), _ptr(klbuf), _ptr(plan.ws), _stream()) == 0
+                else:
+                    assert lib.mfgm_packed_selinv_mom_s(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), _ptr(s["Sig"]), _ptr(s["x"]),
+                                                        _ptr(s["mom"]), _ptr(plan.ws), _stream()) == 0
+
+            def girsanov():
+                # level-0 backward fused with the Girsanov-site update; writes the spare theta_q buffers (the model's state is untouched)
+                assert lib.mfgm_packed_selinv_girsanov(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), ctypes.byref(model._sde_prm),
+                                                       _ptr(tq.lin), _ptr(tq.diag), _ptr(sp.lin), _ptr(sp.diag), _ptr(sp.sub),
+                                                       _ptr(plan.ws), _stream()) == 0
+
+            # (kernel, launches per step, algorithmic doubles per node read + written, launcher)
+            cand = [
+                (f"void mfgm::k_forward<{d}, true, false, true>(mfgm::SweepArgs)", 2, (ET + EF + d) + (ET + d), lambda: stage(1),
+                 "level 0 forward: block Cholesky + forward substitution; reads theta_q, writes L and y"),
+                (f"void mfgm::k_reduce<{d}, true, false>(mfgm::SweepArgs)", 2, (ET + EF + d), lambda: stage(0),
+                 "level 0 reduce: segment elimination; reads theta_q"),
+                ((f"void mfgm::k_backward_kl<{d}>(mfgm::SweepArgs, mfgm::SdeParams)", 1, (ET + EF + d) + (ET + d), backward,
+                  "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, theta_sub, y, writes Sigma, mu") if fused else
+                 (f"void mfgm::k_backward<{d}, true, true, false, true, true>(mfgm::SweepArgs)", 2, (ET + EF + d) + (ET + d + 3 * d), backward,
+                  "level 0 backward: selected inverse + back-substitution; reads L, theta_sub, y, writes Sigma, mu, moments")),
+            ]
             if fused:
-                assert lib.mfgm_packed_selinv_kl(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), ctypes.byref(model._sde_prm),
-                                                 _ptr(s["Sig"]), _ptr(s["x"]), _ptr(klbuf), _ptr(plan.ws), _stream()) == 0
-            else:
-                assert lib.mfgm_packed_selinv_mom_s(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), _ptr(s["Sig"]), _ptr(s["x"]),
-                                                    _ptr(s["mom"]), _ptr(plan.ws), _stream()) == 0
-
-        def girsanov():
-            # level-0 backward fused with the Girsanov-site update; writes the spare theta_q buffers (the model's state is untouched)
-            assert lib.mfgm_packed_selinv_girsanov(plan.h, 0, _ptr(f["L"]), _ptr(tq.sub), -1.0, _ptr(f["y"]), ctypes.byref(model._sde_prm),
-                                                   _ptr(tq.lin), _ptr(tq.diag), _ptr(sp.lin), _ptr(sp.diag), _ptr(sp.sub),
-                                                   _ptr(plan.ws), _stream()) == 0
-
-        # (kernel, launches per step, algorithmic doubles per node read + written, launcher)
-        cand = [
-            (f"void mfgm::k_forward<{d}, true, false, true>(mfgm::SweepArgs)", 2, (ET + EF + d) + (ET + d), lambda: stage(1),
-             "level 0 forward: block Cholesky + forward substitution; reads theta_q, writes L and y"),
-            (f"void mfgm::k_reduce<{d}, true, false>(mfgm::SweepArgs)", 2, (ET + EF + d), lambda: stage(0),
-             "level 0 reduce: segment elimination; reads theta_q"),
-            ((f"void mfgm::k_backward_kl<{d}>(mfgm::SweepArgs, mfgm::SdeParams)", 1, (ET + EF + d) + (ET + d), backward,
-              "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, theta_sub, y, writes Sigma, mu") if fused else
-             (f"void mfgm::k_backward<{d}, true, true, false, true, true>(mfgm::SweepArgs)", 2, (ET + EF + d) + (ET + d + 3 * d), backward,
-              "level 0 backward: selected inverse + back-substitution; reads L, theta_sub, y, writes Sigma, mu, moments")),
-        ]
-        if fused:
-            cand.append((f"void mfgm::k_backward_girsanov<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::GirsanovArgs)", 1,
-                         (ET + EF + d) + (d + ET) + (d + ET + EF), girsanov,
-                         "level 0 backward fused with the Girsanov-site update; reads L, y, theta_q, writes the new theta_q"))
+                cand.append((f"void mfgm::k_backward_girsanov<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::GirsanovArgs)", 1,
+                             (ET + EF + d) + (d + ET) + (d + ET + EF), girsanov,
+                             "level 0 backward fused with the Girsanov-site update; reads L, y, theta_q, writes the new theta_q"))
         rows = []
         for kname, per_step, doubles, fn, what in cand:
             k_ms = timed(fn)
@@ -335,7 +369,8 @@ def main():
         out["roofline"] = dict(rows[0], other_kernels=rows[1:])
         if world == 1 and not args.no_vdp:
             # free the CVI-DP state first: the VDP model keeps its own ~15 GB resident
-            del model, f, s, tq, sp
+            del model, f, s, cand, cq
+            tq = sp = cst = None
             torch.cuda.empty_cache()
             out["vdp"] = vdp_step_rate(B, T, d, dt, noise, idx, ys, device)
         if world == 1 and not args.no_cpu_baseline:

@@ -189,6 +189,55 @@ int mfgm_packed_selinv_girsanov(const mfgm_plan* plan, int only_level, const dou
 int mfgm_packed_selinv_kl(const mfgm_plan* plan, int only_level, const double* L, const double* S, double aS, const double* y,
                           const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, void* ws, void* stream);
 
+/* ---- CVI-DP on the structured posterior naturals ("cq" state; csrc/mfgm_cq.h) ----------------------------------------------------
+ * For a prior whose drift acts per dimension with diagonal diffusion (prm->kind == 0) and data sites that are one block shared by
+ * every observation (Gaussian likelihoods: the site gradient -1/2 R^{-1} does not depend on q, variational_cvi_sde.py:204-220,
+ * 301-317), the posterior naturals of CVISitesSDE (variational_cvi_sde.py:161-174) never hold more than
+ *   dyn [3d per node] = (theta_lin, diag theta_diag, diag theta_sub) of  theta_prior + Girsanov sites  (data sites NOT included),
+ *   one uniform off-diagonal value for theta_diag and one for theta_sub (the initial Girsanov sites, -1e-10 in the reference,
+ *   :141-152, times the running product of (1 - lr)), the block p0_off at node 0 (off-diagonal part of -1/2 P0^{-1}),
+ *   and the data sites given sparsely: slot[node] = observation index or -1 (packed node order: ((lane / 64) * R + step) * 64 +
+ *   lane % 64), site_lin [n, d] = data-site nat1, site_sym [d(d+1)/2] = the data-site nat2 block (packed lower triangle, device).
+ * The sweeps below rebuild the dense blocks in registers; results equal the dense entry points (mfgm_packed_factor with scales
+ * (-2, -1, 1), mfgm_packed_selinv_girsanov, mfgm_packed_selinv_kl) on the equivalent dense naturals.  d <= 8, >= 2 levels. */
+typedef struct mfgm_cq_state {
+    const double* dyn;
+    double d_off, s_off;
+    const double* p0_off;   /* may be NULL */
+    const int* slot;        /* may be NULL: no observation sites */
+    const double* site_lin;
+    const double* site_sym;
+} mfgm_cq_state;
+size_t mfgm_cq_dyn_doubles(const mfgm_plan* plan);   /* doubles of a dyn array */
+size_t mfgm_cq_slot_ints(const mfgm_plan* plan);     /* ints of a slot array */
+/* dense packed naturals (lin VEC, diag SYM, sub FULL) -> dyn; range [4 * Lpad] receives per-lane min / max of the off-diagonal
+ * entries of diag (node 0 of every chain excluded) and of sub, so that the caller can check they are uniform. */
+int mfgm_cq_pack(const mfgm_plan* plan, const double* lin, const double* diag, const double* sub, double* dyn, double* range,
+                 void* stream);
+/* cq state -> dense packed naturals (p0_off included, observation sites not) */
+int mfgm_cq_unpack(const mfgm_plan* plan, const mfgm_cq_state* q, double* lin, double* diag, double* sub, void* stream);
+/* slot array of a list of observation nodes (node_ids[i] = b*T + t); *dup becomes non-zero when two observations share a node */
+int mfgm_cq_slots(const mfgm_plan* plan, const long long* node_ids, int n, int* slot, int* dup, void* stream);
+/* Block Cholesky of the posterior precision + forward substitution (mfgm_packed_factor with G = NULL): L (TRI), y (VEC), logdet /
+ * quad [B] (may be NULL). */
+int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
+                   int* info, void* stream);
+/* one level-0 kernel of it alone (stage 0 reduce, 1 forward), as mfgm_packed_factor_stage */
+int mfgm_cq_factor_stage(const mfgm_plan* plan, int stage, const mfgm_cq_state* q, double* L, double* y, void* ws, int* info,
+                         void* stream);
+/* backward sweep fused with update_girsanov_sites (variational_cvi_sde.py:279-299): dyn_out = (1 - lr) dyn + lr theta~ (out of place;
+ * the caller scales d_off / s_off by (1 - lr)).  only_level 0: the level-0 kernel alone (+ its fix-up), < 0: every level. */
+int mfgm_cq_selinv_girsanov(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
+                            const mfgm_sde_params* prm, double* dyn_out, void* ws, void* stream);
+/* backward sweep with the KL sum (mfgm_packed_selinv_kl): marginals Sig (SYM), x (VEC), kl_part [B]; obs_mu [n, d] / obs_cov
+ * [n, d, d] (both or neither) receive the marginals at the observation nodes, in observation order. */
+int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
+                      const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, double* obs_mu, double* obs_cov, void* ws,
+                      void* stream);
+/* mfgm_mvn_obs_ve on marginals already gathered in observation order (mu [B n_per, d], cov [B n_per, d, d]): ve [B, ceil(n_per/256)] */
+int mfgm_mvn_ve_compact(int B, int n_per, int d, const double* mu, const double* cov, const double* y, const double* Sinv, double cst,
+                        double* ve, void* stream);
+
 /* CVI-DP on the moment array: KL[q||p] = -H[q] - E_q[log p] where E_q[log p] of a per-dimension cubic drift with diagonal
  * diffusion depends on q only through mom, so d KL / d eta = theta_q - theta~(mom) with explicit "effective prior naturals"
  * theta~ (csrc/mfgm_sde.h) and no d x d factorisation:

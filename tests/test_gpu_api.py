@@ -975,26 +975,35 @@ def test_fused_girsanov_update_equals_two_kernel_update(amd, rng, d, kind, B, T,
     y = np.sign(rng.normal(size=(B, 7, d))) + 0.2 * rng.normal(size=(B, 7, d))
     init = (0.3 * rng.normal(size=d), 0.5 * np.eye(d) + 0.1 * np.ones((d, d)))
 
-    def run(fused):
+    cholR = 0.3 * np.eye(d) + 0.1 * np.eye(d, k=-1)          # correlated noise: dense d x d data sites
+
+    def run(fused, cq=True):
         sde = gsde.OrnsteinUhlenbeckSDE(1.2, q) if kind == "ou" else gsde.DoubleWellSDE(q)
-        m = CVISitesSDE(sde, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(0.3 * np.eye(d))), prior_initial_state=init,
+        m = CVISitesSDE(sde, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)), prior_initial_state=init,
                         plan=amd.Plan(B, T, d, R0=R0, Rup=3))
-        m.fused_girsanov = fused
+        m.fused_girsanov, m.cq_enabled = fused, cq
         out = []
-        for lr_d, lr_g in ((0.5, 0.3), (0.3, 0.15)):
+        for it, (lr_d, lr_g) in enumerate(((0.5, 0.3), (0.3, 0.15), (0.4, 0.2))):
             m.update_data_sites(lr_d)
             m.update_girsanov_sites(lr_g)
+            assert (m._cq is not None) == (fused and cq)
             tq = m.full_sites()
             pl = m.plan
             out.append((host(pl.unpack(amd.VEC, tq.lin)), host(pl.unpack(amd.SYM, tq.diag)), host(pl.unpack(amd.FULL, tq.sub, T - 1)),
-                        host(m.classic_elbo_per_trajectory())))
+                        host(m.classic_elbo_per_trajectory()), host(m.fx_mus), host(m.fx_covs), host(m.data_nat1), host(m.data_nat2),
+                        host(m.fx_mus_obs), host(m.fx_covs_obs)))
+            if it == 1:
+                m.relinearize()      # the sites absorb the change of prior: theta_q, hence everything above, is unchanged by it
         return out
 
-    a, b = run(True), run(False)
-    for sa, sb in zip(a, b):
-        for xa, xb in zip(sa, sb):
+    # a: structured (cq) state, the data sites added inside the sweeps; b: two-kernel update on the dense arrays; c: fused sweeps on
+    # the dense arrays
+    a, b, c = run(True), run(False), run(True, cq=False)
+    for sa, sb, sc in zip(a, b, c):
+        for xa, xb, xc in zip(sa, sb, sc):
             assert np.isfinite(xa).all()
             np.testing.assert_allclose(xa, xb, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(xb).max()))
+            np.testing.assert_allclose(xc, xb, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(xb).max()))
 
 
 @pytest.mark.parametrize("d,B,T,stab,kind", [(1, 2, 60, False, "dw"), (2, 2, 700, False, "ou"), (3, 1, 140, True, "dw"), (6, 2, 90, True, "dw")])

@@ -61,6 +61,16 @@ EXPORTS = {
                               + [ctypes.c_void_p] * 7),
     "mfgm_packed_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
                                     + [ctypes.c_void_p] * 9),
+    "mfgm_cq_dyn_doubles": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "mfgm_cq_slot_ints": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "mfgm_cq_pack": (ctypes.c_int, [ctypes.c_void_p] * 7),
+    "mfgm_cq_unpack": (ctypes.c_int, [ctypes.c_void_p] * 6),
+    "mfgm_cq_slots": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "mfgm_cq_factor": (ctypes.c_int, [ctypes.c_void_p] * 9),
+    "mfgm_cq_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6),
+    "mfgm_cq_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),
+    "mfgm_cq_selinv_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11),
+    "mfgm_mvn_ve_compact": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_natural_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_btd_cholesky": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),
     "mfgm_btd_posterior": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 7),
@@ -82,6 +92,12 @@ class SdeParams(ctypes.Structure):
                 ("logdetP0", ctypes.c_double), ("lr", ctypes.c_double), ("clip_lo", ctypes.c_double),
                 ("clip_hi", ctypes.c_double), ("sq_dtq", ctypes.c_double * 8), ("cholP0", ctypes.c_double * 36),
                 ("theta", ctypes.c_double * 8), ("dt", ctypes.c_double), ("kind", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+class CqState(ctypes.Structure):
+    """mfgm_cq_state (include/mfgm.h)."""
+    _fields_ = [("dyn", ctypes.c_void_p), ("d_off", ctypes.c_double), ("s_off", ctypes.c_double), ("p0_off", ctypes.c_void_p),
+                ("slot", ctypes.c_void_p), ("site_lin", ctypes.c_void_p), ("site_sym", ctypes.c_void_p)]
 
 
 class KernelSpec(ctypes.Structure):

@@ -2,6 +2,7 @@
 #include "mfgm_internal.h"
 #include "mfgm_sweeps.h"
 #include "mfgm_girsanov.h"
+#include "mfgm_cq.h"
 
 using namespace mfgm;
 
@@ -246,9 +247,233 @@ int selinv_kl_impl(const Plan& P, const double* Lg, const double* Sg, double aS,
     return 0;
 }
 
+// ---- CVI-DP sweeps on the structured ("cq") state: level 0 from mfgm_cq.h, coarser levels as usual ------------------------------------
+CqArgs cq_args(const mfgm_cq_state* q) {
+    CqArgs c;
+    memset(&c, 0, sizeof(c));
+    c.dyn = q->dyn; c.dOff = q->d_off; c.sOff = q->s_off; c.p0off = q->p0_off;
+    c.slot = q->slot; c.site_lin = q->site_lin; c.site_sym = q->site_sym;
+    return c;
+}
+
+template <int D>
+int cq_factor_impl(const Plan& P, const CqArgs& q, double* Lg, double* yg, double* logdet, double* quad, double* ws, int* info,
+                   hipStream_t st, int only_stage = -1) {
+    const int K = P.nlevels - 1;
+    SweepArgs a0;
+    memset(&a0, 0, sizeof(a0));
+    a0.lv = P.lv[0];
+    a0.info = info;
+    a0.aD = -2.0; a0.aS = -1.0; a0.aR = 1.0;          // natural parameters -> precision
+    a0.Lg = Lg; a0.yg = yg;
+    a0.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
+    bind_up(P, 0, ws, a0);
+    dim3 grid(a0.lv.Lpad / 64), block(64);
+    if (only_stage < 0 || only_stage == 0) {
+        hipLaunchKernelGGL((k_reduce_cq<D>), grid, block, 0, st, a0, q);
+        MFGM_CHECK_LAUNCH();
+    }
+    if (only_stage < 0) {
+        const int lf = coarse_fuse_from(P);
+        for (int l = 1; l < K && l < lf; ++l) {
+            SweepArgs a = coarse_level_args(P, l, ws, info);
+            int rc = launch_reduce<D>(a, true, true, st);
+            if (rc) return rc;
+        }
+        if (lf <= K) {
+            hipLaunchKernelGGL((k_coarse_factor<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info);
+            MFGM_CHECK_LAUNCH();
+        }
+        for (int l = std::min(K, lf - 1); l >= 1; --l) {
+            SweepArgs a = coarse_level_args(P, l, ws, info);
+            int rc = launch_forward<D>(a, true, true, l < K, st);
+            if (rc) return rc;
+        }
+    }
+    if (only_stage < 0 || only_stage == 1) {
+        hipLaunchKernelGGL((k_forward_cq<D>), grid, block, 0, st, a0, q);
+        MFGM_CHECK_LAUNCH();
+    }
+    if (only_stage < 0 && (logdet || quad)) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+template <int D>
+int cq_coarse_backward(const Plan& P, double* ws, hipStream_t st) {
+    const int K = P.nlevels - 1;
+    const int lf = coarse_fuse_from(P);
+    if (lf <= K) {
+        int rc = launch_coarse_backward<D>(P, lf, true, ws, st);
+        if (rc) return rc;
+    }
+    for (int l = std::min(K, lf - 1); l >= 1; --l) {
+        SweepArgs a = coarse_level_args(P, l, ws, nullptr);
+        int rc = launch_backward<D>(a, true, l < K, false, st, true);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+template <int D>
+int cq_selinv_girsanov_impl(const Plan& P, const CqArgs& q, const double* Lg, const double* yg, const SdeParams& pr, double* ws,
+                            hipStream_t st, int only_level) {
+    if (only_level != 0) {
+        int rc = cq_coarse_backward<D>(P, ws, st);
+        if (rc) return rc;
+    }
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lv = P.lv[0];
+    a.Lg = const_cast<double*>(Lg); a.yg = const_cast<double*>(yg); a.aS = -1.0;
+    bind_up(P, 0, ws, a);
+    double* fix = ws + P.off_part[0];
+    dim3 grid(a.lv.Lpad / 64), block(64);
+    hipLaunchKernelGGL((k_backward_girsanov_cq<D>), grid, block, 0, st, a, pr, q, fix);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_girsanov_fixup_cq<D>), grid, block, 0, st, a.lv, q.dyn_out, (const double*)fix);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int D>
+int cq_selinv_kl_impl(const Plan& P, const CqArgs& q, const double* Lg, const double* yg, const SdeParams& pr, double* Sig, double* x,
+                      double* kl, double* ws, hipStream_t st, int only_level) {
+    if (only_level != 0) {
+        int rc = cq_coarse_backward<D>(P, ws, st);
+        if (rc) return rc;
+    }
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lv = P.lv[0];
+    a.Lg = const_cast<double*>(Lg); a.yg = const_cast<double*>(yg); a.aS = -1.0;
+    a.Sigg = Sig; a.mug = x;
+    a.part = ws + P.off_part[0];
+    bind_up(P, 0, ws, a);
+    hipLaunchKernelGGL((k_backward_kl_cq<D>), dim3(a.lv.Lpad / 64), dim3(64), 0, st, a, pr, q);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, a.part, a.lv.P, 0, kl, (double*)nullptr);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int D>
+int cq_pack_impl(const Plan& P, const double* lin, const double* diag, const double* sub, double* dyn, double* range, hipStream_t st) {
+    hipLaunchKernelGGL((k_cq_pack<D>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], lin, diag, sub, dyn, range);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+template <int D>
+int cq_unpack_impl(const Plan& P, const CqArgs& q, double* lin, double* diag, double* sub, hipStream_t st) {
+    hipLaunchKernelGGL((k_cq_unpack<D>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], q, lin, diag, sub);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+template <int D>
+int mvn_ve_compact_impl(int B, int n_per, const double* mu, const double* cov, const double* y, const double* Sinv, double cst,
+                        double* ve, hipStream_t st) {
+    const int nb = (n_per + 255) / 256;
+    hipLaunchKernelGGL((k_mvn_ve_compact<D>), dim3(nb, B), dim3(256), 0, st, n_per, mu, cov, y, Sinv, cst, ve);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+bool cq_ok(const mfgm_plan* plan, const mfgm_cq_state* q) {
+    if (!plan || !q || !q->dyn) return false;
+    const Plan& P = plan->p;
+    if (P.wide || P.nlevels < 2) return false;
+    if (q->slot && (!q->site_lin || !q->site_sym)) return false;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t mfgm_cq_dyn_doubles(const mfgm_plan* plan) {
+    if (!plan || plan->p.wide) return 0;
+    return packed_elems(plan->p.lv[0], 3 * plan->p.d);
+}
+size_t mfgm_cq_slot_ints(const mfgm_plan* plan) {
+    if (!plan || plan->p.wide) return 0;
+    return (size_t)plan->p.lv[0].R * plan->p.lv[0].Lpad;
+}
+
+int mfgm_cq_pack(const mfgm_plan* plan, const double* lin, const double* diag, const double* sub, double* dyn, double* range,
+                 void* stream) {
+    if (!plan || !lin || !diag || !sub || !dyn || !range || plan->p.wide) return 1;
+    const Plan& P = plan->p;
+    MFGM_DISPATCH_D(P.d, (cq_pack_impl<DD>(P, lin, diag, sub, dyn, range, (hipStream_t)stream)));
+}
+
+int mfgm_cq_unpack(const mfgm_plan* plan, const mfgm_cq_state* q, double* lin, double* diag, double* sub, void* stream) {
+    if (!plan || !q || !q->dyn || !lin || !diag || !sub || plan->p.wide) return 1;
+    const Plan& P = plan->p;
+    const CqArgs c = cq_args(q);
+    MFGM_DISPATCH_D(P.d, (cq_unpack_impl<DD>(P, c, lin, diag, sub, (hipStream_t)stream)));
+}
+
+int mfgm_cq_slots(const mfgm_plan* plan, const long long* node_ids, int n, int* slot, int* dup, void* stream) {
+    if (!plan || !node_ids || !slot || !dup || n < 0 || plan->p.wide) return 1;
+    const Plan& P = plan->p;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(slot, 0xFF, mfgm_cq_slot_ints(plan) * sizeof(int), st) != hipSuccess) return 3;
+    if (hipMemsetAsync(dup, 0, sizeof(int), st) != hipSuccess) return 3;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_cq_slots, dim3((n + 255) / 256), dim3(256), 0, st, P.lv[0], P.T, node_ids, n, slot, dup);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
+                   int* info, void* stream) {
+    if (!cq_ok(plan, q) || !L || !y || !ws || !info) return 1;
+    const Plan& P = plan->p;
+    const CqArgs c = cq_args(q);
+    MFGM_DISPATCH_D(P.d, (cq_factor_impl<DD>(P, c, L, y, logdet, quad, (double*)ws, info, (hipStream_t)stream)));
+}
+
+int mfgm_cq_factor_stage(const mfgm_plan* plan, int stage, const mfgm_cq_state* q, double* L, double* y, void* ws, int* info,
+                         void* stream) {
+    if (!cq_ok(plan, q) || !L || !y || !ws || !info || stage < 0 || stage > 1) return 1;
+    const Plan& P = plan->p;
+    const CqArgs c = cq_args(q);
+    MFGM_DISPATCH_D(P.d, (cq_factor_impl<DD>(P, c, L, y, nullptr, nullptr, (double*)ws, info, (hipStream_t)stream, stage)));
+}
+
+int mfgm_cq_selinv_girsanov(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
+                            const mfgm_sde_params* prm, double* dyn_out, void* ws, void* stream) {
+    if (!cq_ok(plan, q) || !L || !y || !prm || !dyn_out || !ws || dyn_out == q->dyn || prm->kind != 0) return 1;
+    const Plan& P = plan->p;
+    SdeParams pr;
+    memcpy(&pr, prm, sizeof(pr));
+    CqArgs c = cq_args(q);
+    c.dyn_out = dyn_out;
+    MFGM_DISPATCH_D(P.d, (cq_selinv_girsanov_impl<DD>(P, c, L, y, pr, (double*)ws, (hipStream_t)stream, only_level)));
+}
+
+int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
+                      const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, double* obs_mu, double* obs_cov, void* ws,
+                      void* stream) {
+    if (!cq_ok(plan, q) || !L || !y || !prm || !Sig || !x || !kl_part || !ws || prm->kind != 0) return 1;
+    if ((obs_mu != nullptr) != (obs_cov != nullptr)) return 1;
+    const Plan& P = plan->p;
+    SdeParams pr;
+    memcpy(&pr, prm, sizeof(pr));
+    CqArgs c = cq_args(q);
+    c.obs_mu = obs_mu; c.obs_cov = obs_cov;
+    MFGM_DISPATCH_D(P.d, (cq_selinv_kl_impl<DD>(P, c, L, y, pr, Sig, x, kl_part, (double*)ws, (hipStream_t)stream, only_level)));
+}
+
+int mfgm_mvn_ve_compact(int B, int n_per, int d, const double* mu, const double* cov, const double* y, const double* Sinv, double cst,
+                        double* ve, void* stream) {
+    if (B < 1 || n_per < 0 || !mu || !cov || !y || !Sinv || !ve) return 1;
+    MFGM_DISPATCH_D(d, (mvn_ve_compact_impl<DD>(B, n_per, mu, cov, y, Sinv, cst, ve, (hipStream_t)stream)));
+}
+
 
 int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, const double* r, double aD, double aS,
                        double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,

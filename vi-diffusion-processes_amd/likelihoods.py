@@ -16,6 +16,10 @@ from . import linalg
 class MultivariateGaussian:
     """p(y | f) = N(y; f, L L^T) (multivariate_gaussian.py:29-160)."""
 
+    # d VE / d(eta) = (S^{-1} y, -1/2 S^{-1}) does not depend on q, and its second part is the same block for every observation: the
+    # CVI-DP model then keeps the data sites out of the per-node arrays (variational_cvi_sde.CVISitesSDE, cq state)
+    uniform_site_gradient = True
+
     def __init__(self, chol_covariance):
         self.chol_covariance = chol_covariance
 

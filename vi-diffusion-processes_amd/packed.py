@@ -295,8 +295,81 @@ class Plan:
                                                         _ptr(self.ws), _stream()), "mfgm_packed_selinv_girsanov")
         return out
 
+    # -- CVI-DP sweeps on the structured ("cq") state (include/mfgm.h, csrc/mfgm_cq.h) ------------------------------------------------------
+    def cq_pack(self, lin, diag, sub):
+        """Dense packed naturals -> (dyn, (dmin, dmax), (smin, smax)): the diagonals and the range of the off-diagonal entries."""
+        dyn = torch.empty(self.lib.mfgm_cq_dyn_doubles(self.h), dtype=torch.float64, device=self.device)
+        rng = torch.empty((4, self.Lpad), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_cq_pack(self.h, _ptr(lin), _ptr(diag), _ptr(sub), _ptr(dyn), _ptr(rng), _stream()), "mfgm_cq_pack")
+        lo, hi = rng[0::2].min(dim=1).values.tolist(), rng[1::2].max(dim=1).values.tolist()
+        return dyn, (lo[0], hi[0]), (lo[1], hi[1])
+
+    def cq_unpack(self, cq):
+        """cq state -> dense packed (lin, diag, sub), p0_off included, observation sites not."""
+        lin, diag, sub = self.empty(VEC), self.empty(SYM), self.empty(FULL)
+        _lib.check(self.lib.mfgm_cq_unpack(self.h, ctypes.byref(cq.struct()), _ptr(lin), _ptr(diag), _ptr(sub), _stream()), "mfgm_cq_unpack")
+        return lin, diag, sub
+
+    def cq_slots(self, node_ids):
+        """int32 slot array of the observation nodes, or None when two observations share a node."""
+        slot = torch.empty(self.lib.mfgm_cq_slot_ints(self.h), dtype=torch.int32, device=self.device)
+        dup = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.mfgm_cq_slots(self.h, _ptr(node_ids), node_ids.numel(), _ptr(slot), _ptr(dup), _stream()), "mfgm_cq_slots")
+        return None if int(dup.item()) else slot
+
+    def cq_factor(self, cq, want_logdet=True, out=None):
+        """Block Cholesky + forward substitution of the posterior precision given as a cq state: dict(L, y, logdet)."""
+        out = {} if out is None else out
+        L = out.get("L") if out.get("L") is not None else self.empty(TRI)
+        y = out.get("y") if out.get("y") is not None else self.empty(VEC)
+        self.epoch += 1
+        logdet = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_logdet else None
+        _lib.check(self.lib.mfgm_cq_factor(self.h, ctypes.byref(cq.struct()), _ptr(L), _ptr(y), _ptr(logdet), None, _ptr(self.ws),
+                                           _ptr(self.info), _stream()), "mfgm_cq_factor")
+        return dict(L=L, y=y, logdet=logdet)
+
+    def cq_selinv_girsanov(self, cq, L, y, prm, dyn_out, only_level=-1):
+        _lib.check(self.lib.mfgm_cq_selinv_girsanov(self.h, int(only_level), ctypes.byref(cq.struct()), _ptr(L), _ptr(y), ctypes.byref(prm),
+                                                    _ptr(dyn_out), _ptr(self.ws), _stream()), "mfgm_cq_selinv_girsanov")
+        return dyn_out
+
+    def cq_selinv_kl(self, cq, L, y, prm, out=None, obs_mu=None, obs_cov=None, only_level=-1):
+        out = {} if out is None else out
+        Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
+        x = out.get("x") if out.get("x") is not None else self.empty(VEC)
+        kl = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_cq_selinv_kl(self.h, int(only_level), ctypes.byref(cq.struct()), _ptr(L), _ptr(y), ctypes.byref(prm), _ptr(Sig),
+                                              _ptr(x), _ptr(kl), _ptr(obs_mu), _ptr(obs_cov), _ptr(self.ws), _stream()), "mfgm_cq_selinv_kl")
+        return dict(Sig=Sig, x=x, klpart=kl)
+
+    def mvn_ve_compact(self, mu, cov, n_per, y, Sinv, cst):
+        """mvn_obs_ve on marginals already gathered in observation order; returns ve [B]."""
+        ve = torch.empty((self.B, (int(n_per) + 255) // 256), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_mvn_ve_compact(self.B, int(n_per), self.d, _ptr(mu), _ptr(cov), _ptr(y), _ptr(Sinv), float(cst), _ptr(ve),
+                                                _stream()), "mfgm_mvn_ve_compact")
+        return ve.sum(-1)
+
     def check_info(self):
         """Raise ArithmeticError if a pivot block was not positive definite (synchronises)."""
         if int(self.info.item()) != 0:
             self.info.zero_()
             raise ArithmeticError("block-tri-diagonal matrix is not positive definite")
+
+
+class CqState:
+    """The structured posterior naturals of CVI-DP (mfgm_cq_state): dyn (+ a spare buffer the Girsanov sweep writes), the uniform
+    off-diagonal values, the node-0 block and the observation sites.  Tensors are referenced here so that the pointers handed to the
+    library stay alive."""
+
+    def __init__(self, dyn, d_off, s_off, p0_off=None, slot=None, site_lin=None, site_sym=None):
+        self.dyn, self.spare = dyn, None
+        self.d_off, self.s_off = float(d_off), float(s_off)
+        self.p0_off, self.slot, self.site_lin, self.site_sym = p0_off, slot, site_lin, site_sym
+
+    def struct(self):
+        st = _lib.CqState()
+        st.dyn, st.d_off, st.s_off = self.dyn.data_ptr(), self.d_off, self.s_off
+        st.p0_off = self.p0_off.data_ptr() if self.p0_off is not None else None
+        if self.slot is not None:
+            st.slot, st.site_lin, st.site_sym = self.slot.data_ptr(), self.site_lin.data_ptr(), self.site_sym.data_ptr()
+        return st

@@ -115,8 +115,10 @@ class SSMNaturalGradient:
         """
         gl, gd, gs = g
         T = pl.T
-        tnorm = max(float(nq["diag"].abs().max()), 1e-300)
-        gnorm = max(float(gd.abs().max()), float(gs.abs().max()), float(gl.abs().max()), 1e-300)
+        # norms over the nodes of the chains only: packed arrays carry uninitialised padding lanes
+        vl, vd, vs = pl.unpack(VEC, gl), pl.unpack(SYM, gd), pl.unpack(FULL, gs, T - 1)
+        tnorm = max(float(pl.unpack(SYM, nq["diag"]).abs().max()), 1e-300)
+        gnorm = max(float(vd.abs().max()), float(vs.abs().max()) if vs.numel() else 0.0, float(vl.abs().max()), 1e-300)
         e = rel_step * tnorm / gnorm
         etas = []
         for sgn in (1.0, -1.0):
@@ -129,6 +131,5 @@ class SSMNaturalGradient:
             mu, cov, sub = pl.unpack(VEC, s_["x"]), pl.unpack(SYM, s_["Sig"]), pl.unpack(FULL, s_["Sub"], T - 1)
             etas.append((mu, cov + mu[..., :, None] * mu[..., None, :], sub + mu[:, 1:, :, None] * mu[:, :-1, None, :]))
         (m1, d1, s1), (m0, d0, s0) = etas
-        vl, vd, vs = pl.unpack(VEC, gl), pl.unpack(SYM, gd), pl.unpack(FULL, gs, T - 1)
         tot = (vl * (m1 - m0)).sum() + (vd * (d1 - d0)).sum() + 2.0 * (vs * (s1 - s0)).sum()
         return float(tot) / (2.0 * e)

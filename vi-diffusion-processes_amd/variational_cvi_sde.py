@@ -16,7 +16,7 @@ import os
 import torch
 
 from ._lib import FULL, SYM, VEC
-from .packed import Plan
+from .packed import CqState, Plan
 from .state_space_model import StateSpaceModel
 
 
@@ -79,7 +79,7 @@ class CVISitesSSM:
             self._path = (pl.pack(VEC, mu.reshape(self.B, self.T, d)), pl.pack(SYM, cov.reshape(self.B, self.T, d, d)))
             self.fx_mus_obs = pl.gather_nodes(VEC, self._path[0], self.obs_node_ids)
             self.fx_covs_obs = pl.gather_nodes(SYM, self._path[1], self.obs_node_ids)
-        self._theta_q = PackedBTDNat(pl.empty(VEC), pl.empty(SYM), pl.empty(FULL))
+        self._theta_q = None        # dense posterior naturals, allocated when first built
         self._started = False
         self._bufs = dict(f={}, s={})
         self._q = None          # cached posterior refresh (factor + selected inverse) for the current sites
@@ -88,8 +88,10 @@ class CVISitesSSM:
             self._set_prior(prior_ssm)
 
     # -- prior ---------------------------------------------------------------------------------------
-    def _set_prior(self, ssm: StateSpaceModel):
-        """Cache the prior's natural parameters, marginal means and log-determinant (packed)."""
+    def _set_prior(self, ssm: StateSpaceModel, move_theta_q=True):
+        """Cache the prior's natural parameters, marginal means and log-determinant (packed).  With move_theta_q the posterior
+        naturals follow the prior (the implicit Girsanov sites stay what they are); without, theta_q stays fixed (the sites absorb
+        the change of prior: tranform_girsanov_sites)."""
         if ssm.plan is not self.plan:
             ssm = StateSpaceModel(ssm.initial_mean, ssm.cholesky_initial_covariance, ssm.state_transitions,
                                   ssm.state_offsets, ssm.cholesky_process_covariances, plan=self.plan)
@@ -98,7 +100,7 @@ class CVISitesSSM:
         nat = self.plan.ssm_to_naturals(pk.A, pk.off, pk.chol, precision=False, want_logdet=True)
         old_p, had_q = getattr(self, "_theta_p", None), getattr(self, "_theta_q_valid", False)
         self._theta_p = PackedBTDNat(nat["lin"], nat["diag"], nat["sub"])
-        if had_q and old_p is not None:
+        if had_q and old_p is not None and move_theta_q:
             # the (implicit) Girsanov sites stay what they are: theta_q moves with the prior
             tq = self._theta_q
             for qq, new_, old_ in ((tq.lin, nat["lin"], old_p.lin), (tq.diag, nat["diag"], old_p.diag), (tq.sub, nat["sub"], old_p.sub)):
@@ -109,12 +111,15 @@ class CVISitesSSM:
         s = self.plan.selinv(f["L"], f["G"], f["y"], want_sub=False)
         self._p_mu = s["x"]
         self._q = None
-        self._theta_q_valid = bool(had_q and old_p is not None)
+        self._theta_q_valid = bool(had_q and (old_p is not None or not move_theta_q))
 
     # -- sites -> posterior --------------------------------------------------------------------------------
     def _rebuild_theta_q(self, g=None):
         """theta_q = theta_prior + girsanov sites + scattered data sites (variational_cvi_sde.py:161-174), from scratch."""
-        pl, tq, tp = self.plan, self._theta_q, self._theta_p
+        pl, tp = self.plan, self._theta_p
+        if self._theta_q is None:
+            self._theta_q = PackedBTDNat(pl.empty(VEC), pl.empty(SYM), pl.empty(FULL))
+        tq = self._theta_q
         if g is None:   # initial Girsanov sites
             g = PackedBTDNat(pl.zeros(VEC), pl.zeros(SYM).fill_(-1e-10), pl.zeros(FULL).fill_(-1e-10))
         pl.lincomb(tq.lin, 1.0, tp.lin, 1.0, g.lin)
@@ -315,6 +320,7 @@ class CVISitesSDE(CVISitesSSM):
             prior_initial_state = (torch.zeros(d, dtype=torch.float64).numpy(), q * (torch.ones((d, d), dtype=torch.float64).numpy()))
         self.stabilize_ssm = stabilize_ssm
         self.clip_state_transitions = clip_state_transitions
+        self._cq, self._cq_off, self._cq_dense, self._cq_p0_moved = None, False, None, False
         super().__init__(None, time_grid, input_data, likelihood, prior_initial_state=prior_initial_state,
                          initial_posterior_path=initial_posterior_path, plan=plan)
         self._sde_prm = prior_sde.params(self.dt, prior_initial_state[0], prior_initial_state[1])
@@ -333,7 +339,7 @@ class CVISitesSDE(CVISitesSSM):
         self._path = (mu, pl.pack(SYM, eye))
         return self._path
 
-    def set_linearized_prior(self):
+    def set_linearized_prior(self, move_theta_q=True):
         """Linearise the SDE on the current posterior (variational_cvi_sde.py:408-432) and install it as dist_p."""
         pl = self.plan
         mu, Sig = self._path_packed()
@@ -344,9 +350,9 @@ class CVISitesSDE(CVISitesSSM):
             prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1],
                                         clip=self.clip_state_transitions)
             A, off, chol = pl.linearize_cubic(prm, mu, Sig)
-            self._set_prior(_ssm_from_packed(pl, A, off, chol))
+            self._set_prior(_ssm_from_packed(pl, A, off, chol), move_theta_q=move_theta_q)
         else:
-            self._set_prior(self.dist_p_linearized)
+            self._set_prior(self.dist_p_linearized, move_theta_q=move_theta_q)
 
     def relinearize(self):
         """
@@ -354,16 +360,165 @@ class CVISitesSDE(CVISitesSSM):
         unchanged: the trainer's sequence `dist_p_last = dist_p; set_linearized_prior(); tranform_girsanov_sites(...)`
         (docs/diffusion_processes/cvi_dp_trainer.py:127-134, sde_utils.py:550-568).
         """
-        q_valid = self._q
-        tq = self.full_sites()
-        keep = PackedBTDNat(tq.lin.clone(), tq.diag.clone(), tq.sub.clone())
-        self.set_linearized_prior()
         # tranform_girsanov_sites adds theta(old prior) - theta(new prior) to the sites, i.e. it keeps
-        # theta_q = theta_p + g + data fixed.  The sites are implicit here (theta_q - theta_p - data), so restoring
-        # theta_q under the new prior IS the transformation and the cached posterior stays valid.
-        self._theta_q = keep
-        self._theta_q_valid = True
+        # theta_q = theta_p + g + data fixed.  The sites are implicit here (theta_q - theta_p - data), so leaving
+        # theta_q alone under the new prior IS the transformation and the cached posterior stays valid.
+        q_valid = self._q
+        if self._cq is None:
+            self.full_sites()         # theta_q exists (and is marked valid) before the prior is replaced
+        self.set_linearized_prior(move_theta_q=False)
         self._q = q_valid
+
+    # ---- structured ("cq") posterior naturals: csrc/mfgm_cq.h -------------------------------------------------------------------------
+    # With a per-dimension drift, diagonal diffusion and a likelihood whose site gradient is one block shared by all observations
+    # (MultivariateGaussian), theta_prior + Girsanov sites is, per node, 3 d numbers plus uniform off-diagonals; the data sites stay
+    # in their own small arrays and the sweeps add them on load.  VIDP_CQ=0 keeps the dense arrays (the two routes are held to each
+    # other in tests/test_gpu_api.py).
+    cq_enabled = os.environ.get("VIDP_CQ", "1") != "0"
+
+    def _cq_eligible(self):
+        return (self.cq_enabled and not self._cq_off and self._sweep_fusion()
+                and getattr(self.likelihood, "uniform_site_gradient", False))
+
+    @property
+    def data_nat2(self):
+        """Data-site nat2, [B n_obs, d, d] (in cq mode one block shared by every observation, expanded on demand)."""
+        if self._cq is not None:
+            return self._sym_full(self._cq.site_sym).expand(self.B * self.n_obs, -1, -1).contiguous()
+        return self._data_nat2
+
+    @data_nat2.setter
+    def data_nat2(self, value):
+        if getattr(self, "_cq", None) is not None:
+            self._cq_leave()
+        self._data_nat2 = value
+
+    def _sym_full(self, packed):
+        d = self.state_dim
+        r, c = torch.tril_indices(d, d, device=packed.device)
+        m = torch.zeros((d, d), dtype=torch.float64, device=packed.device)
+        m[r, c] = packed
+        m[c, r] = packed
+        return m
+
+    def _sym_packed(self, full):
+        d = self.state_dim
+        r, c = torch.tril_indices(d, d, device=full.device)
+        return full[r, c].contiguous()
+
+    def _cq_try_enter(self, lin, diag, sub):
+        """Move the dense, DATA-FREE naturals (theta_prior + Girsanov sites) into the cq state.  Returns False (and switches the cq
+        route off for this model) when they do not have the structure: off-diagonals not uniform, observations sharing a node, data
+        sites that differ between observations."""
+        pl, d = self.plan, self.state_dim
+        n2 = self._data_nat2
+        if n2.numel() and float((n2 - n2[:1]).abs().max()) > 0.0:
+            self._cq_off = True
+            return False
+        slot = pl.cq_slots(self.obs_node_ids) if n2.numel() else None
+        if n2.numel() and slot is None:
+            self._cq_off = True
+            return False
+        dyn, (dlo, dhi), (slo, shi) = pl.cq_pack(lin, diag, sub)
+        tol = lambda lo, hi: hi - lo <= 1e-12 * max(abs(lo), abs(hi), 1e-300)
+        # node 0 of every chain: off-diagonal part beyond the uniform value = that of theta_prior (-1/2 P0^{-1}), the same for all chains
+        blk0 = pl.gather_nodes(SYM, diag, pl.node_ids([0]))
+        p0 = blk0 - torch.diag_embed(torch.diagonal(blk0, dim1=-2, dim2=-1))
+        off = (1.0 - torch.eye(d, dtype=torch.float64, device=self.device))
+        p0 = p0 - dlo * off
+        if not (tol(dlo, dhi) and tol(slo, shi)) or float((p0 - p0[:1]).abs().max()) > 1e-9 * max(1.0, float(p0.abs().max())):
+            self._cq_off = True
+            return False
+        cq = CqState(dyn, dlo, slo, p0_off=self._sym_packed(p0[0]))
+        if n2.numel():
+            cq.slot, cq.site_lin, cq.site_sym = slot, self.data_nat1, self._sym_packed(n2[0])
+        self._cq, self._cq_dense = cq, None
+        self._theta_q_valid = True
+        self._theta_q = None          # the dense arrays are materialised on demand only
+        return True
+
+    def _cq_dense_free(self):
+        """Dense packed (lin, diag, sub) of theta_prior + Girsanov sites (no data sites) from the cq state."""
+        return self.plan.cq_unpack(self._cq)
+
+    def _cq_leave(self):
+        """Back to the dense arrays (a caller assigned sites the structured state cannot hold)."""
+        cq, pl = self._cq, self.plan
+        lin, diag, sub = self._cq_dense_free()
+        if cq.site_sym is not None:
+            self._data_nat2 = self._sym_full(cq.site_sym).expand(self.B * self.n_obs, -1, -1).contiguous()
+        self._cq, self._cq_dense = None, None
+        if self._data_nat2.numel():
+            pl.scatter_nodes(VEC, lin, self.obs_node_ids, self.data_nat1, accumulate=True)
+            pl.scatter_nodes(SYM, diag, self.obs_node_ids, self._data_nat2, accumulate=True)
+        self._theta_q = PackedBTDNat(lin, diag, sub)
+        self._theta_q_valid = True
+
+    def _rebuild_theta_q(self, g=None):
+        """theta_q from the prior, the Girsanov sites `g` (default: the initial ones) and the data sites; into the cq state when the
+        model qualifies, else into the dense arrays (variational_cvi_sde.py:161-174)."""
+        if self._cq is not None:
+            self._cq, self._cq_dense = None, None
+        if not self._cq_eligible():
+            return super()._rebuild_theta_q(g)
+        pl, tp = self.plan, self._theta_p
+        if g is None:
+            g = PackedBTDNat(pl.zeros(VEC), pl.zeros(SYM).fill_(-1e-10), pl.zeros(FULL).fill_(-1e-10))
+        free = PackedBTDNat(pl.lincomb(pl.empty(VEC), 1.0, tp.lin, 1.0, g.lin), pl.lincomb(pl.empty(SYM), 1.0, tp.diag, 1.0, g.diag),
+                            pl.lincomb(pl.empty(FULL), 1.0, tp.sub, 1.0, g.sub))
+        if self._cq_try_enter(free.lin, free.diag, free.sub):
+            return
+        pl.scatter_nodes(VEC, free.lin, self.obs_node_ids, self.data_nat1, accumulate=True)
+        pl.scatter_nodes(SYM, free.diag, self.obs_node_ids, self._data_nat2, accumulate=True)
+        self._theta_q, self._theta_q_valid = free, True
+
+    def full_sites(self):
+        """The posterior natural parameters theta_q, dense and packed (variational_cvi_sde.py:161-174); in cq mode they are
+        materialised from the structured state (and cached until the next update)."""
+        if not getattr(self, "_theta_q_valid", False):
+            self._rebuild_theta_q()
+        if self._cq is None:
+            return self._theta_q
+        if self._cq_dense is None:
+            pl = self.plan
+            lin, diag, sub = self._cq_dense_free()
+            if self._cq.slot is not None:
+                pl.scatter_nodes(VEC, lin, self.obs_node_ids, self.data_nat1, accumulate=True)
+                pl.scatter_nodes(SYM, diag, self.obs_node_ids, self.data_nat2, accumulate=True)
+            self._cq_dense = PackedBTDNat(lin, diag, sub)
+        return self._cq_dense
+
+    def _cq_state(self):
+        """The cq state, built on first use; None when the model runs on the dense arrays."""
+        if not getattr(self, "_theta_q_valid", False):
+            self._rebuild_theta_q()
+        return self._cq
+
+    def _set_prior(self, ssm, move_theta_q=True):
+        cq = self._cq
+        if cq is None:
+            return super()._set_prior(ssm, move_theta_q=move_theta_q)
+        if not move_theta_q:
+            # theta_q stays what it is: only the prior-side caches are replaced
+            self._theta_q_valid = False
+            super()._set_prior(ssm, move_theta_q=False)
+            self._theta_q_valid = True
+            return
+        # theta_q follows the prior: through the dense data-free arrays (a rare call: prior-parameter gradients)
+        lin, diag, sub = self._cq_dense_free()
+        if cq.site_sym is not None:
+            self._data_nat2 = self._sym_full(cq.site_sym).expand(self.B * self.n_obs, -1, -1).contiguous()
+        self._theta_q, self._theta_q_valid, self._cq, self._cq_dense = PackedBTDNat(lin, diag, sub), True, None, None
+        super()._set_prior(ssm, move_theta_q=True)
+        tq = self._theta_q
+        keep_sites = (cq.slot, cq.site_lin, cq.site_sym)
+        if not self._cq_try_enter(tq.lin, tq.diag, tq.sub):
+            if self._data_nat2.numel():
+                self.plan.scatter_nodes(VEC, tq.lin, self.obs_node_ids, self.data_nat1, accumulate=True)
+                self.plan.scatter_nodes(SYM, tq.diag, self.obs_node_ids, self._data_nat2, accumulate=True)
+            self._theta_q, self._theta_q_valid = tq, True
+        else:
+            self._cq.slot, self._cq.site_lin, self._cq.site_sym = keep_sites
 
     # the level-0 backward sweep makes the Girsanov-site update / the KL sum itself (VIDP_FUSED_GIRSANOV=0: separate kernels on
     # the moment array)
@@ -374,6 +529,46 @@ class CVISitesSDE(CVISitesSSM):
         return self.fused_girsanov and prm is not None and pl.d <= 8 and pl.nlevels >= 2 and prm.kind == 0
 
     _need_sub = False    # the closed-form SDE KL needs only (mu, diag Sigma, diag Sigma_sub): the moment array
+
+    def update_data_sites(self, lr: float):
+        cq = self._cq_state()
+        if cq is None or cq.slot is None:
+            return super().update_data_sites(lr)
+        # the site gradient of such a likelihood does not depend on the marginals: only the small site arrays move, and the sweeps
+        # read them where they need them (no scatter into per-node arrays)
+        self._started = True
+        g1, g2 = self.likelihood.ve_gradients_expectation(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
+        if getattr(self, "_cq_g2", (None,))[0] is not g2:
+            self._cq_g2 = (g2, self._sym_packed(g2[0]))
+        self.data_nat1.lerp_(g1, lr)                     # (1 - lr) site + lr gradient (variational_cvi_sde.py:301-317)
+        cq.site_sym.lerp_(self._cq_g2[1], lr)
+        self._q, self._cq_dense, self._obs_fresh = None, None, False
+
+    def _refresh(self, want_sub=None, want_mom=None):
+        cq = self._cq_state()
+        want_sub_ = self._need_sub if want_sub is None else want_sub
+        if cq is None or want_sub_ or want_mom:
+            return super()._refresh(want_sub=want_sub, want_mom=want_mom)      # dense route (on the materialised naturals in cq mode)
+        if self._q is None:
+            pl = self.plan
+            f = pl.cq_factor(cq, want_logdet=True, out=self._bufs["f"])
+            self._bufs["f"].update(L=f["L"], y=f["y"])
+            obs = cq.slot is not None
+            s = pl.cq_selinv_kl(cq, f["L"], f["y"], self._sde_prm, out=self._bufs["s"], obs_mu=self.fx_mus_obs if obs else None,
+                                obs_cov=self.fx_covs_obs if obs else None)
+            self._bufs["s"].update(Sig=s["Sig"], x=s["x"])
+            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=None, mom=None, klpart=s["klpart"])
+            self._obs_fresh = obs
+        return self._q
+
+    def variational_expectation(self):
+        cq, lik = self._cq_state(), self.likelihood
+        if cq is None or cq.slot is None:
+            return super().variational_expectation()
+        self._refresh()
+        if not getattr(self, "_obs_fresh", False):
+            self._gather_obs()
+        return self.plan.mvn_ve_compact(self.fx_mus_obs, self.fx_covs_obs, self.n_obs, self._obs_flat(), lik.inv_covariance, lik.ve_constant)
 
     def KL_q_p(self):
         """
@@ -409,6 +604,7 @@ class CVISitesSDE(CVISitesSSM):
         """Replace p(x0) (the trainer re-sets it to the stationary OU covariance after every decay update)."""
         self.prior_initial_state = (mean, cov)
         self._refresh_sde_params()
+        self._cq_p0_moved = True
 
     def grad_KL_wrt_cubic(self):
         """
@@ -473,8 +669,29 @@ class CVISitesSDE(CVISitesSSM):
 
     def update_girsanov_sites(self, lr: float):
         """Fused: g <- g + lr (scatter(data) - dKL/d eta), theta_q moves by the same increment (variational_cvi_sde.py:279-299)."""
-        pl, tq = self.plan, self.full_sites()
+        pl = self.plan
         self._sde_prm.lr = float(lr)
+        cq = self._cq_state()
+        if cq is not None:
+            # reduce -> forward -> backward sweep that writes (1 - lr) dyn + lr theta~ into the spare buffer; the uniform off-diagonals
+            # scale by (1 - lr); the data sites do not enter (they are not part of the resident state)
+            f = pl.cq_factor(cq, want_logdet=False, out=self._bufs["f"])
+            self._bufs["f"].update(L=f["L"], y=f["y"])
+            if cq.spare is None:
+                cq.spare = torch.empty_like(cq.dyn)
+            pl.cq_selinv_girsanov(cq, f["L"], f["y"], self._sde_prm, cq.spare)
+            cq.dyn, cq.spare = cq.spare, cq.dyn
+            cq.d_off *= 1.0 - lr
+            cq.s_off *= 1.0 - lr
+            if self._cq_p0_moved and cq.p0_off is not None:
+                # p(x0) was replaced after the state was built: the node-0 block follows -1/2 P0^{-1} like every other entry
+                P0inv = self._sym_full(torch.tensor(list(self._sde_prm.P0inv)[:self.state_dim * (self.state_dim + 1) // 2],
+                                                    dtype=torch.float64, device=self.device))
+                tgt = -0.5 * (P0inv - torch.diag(torch.diagonal(P0inv)))
+                cq.p0_off.lerp_(self._sym_packed(tgt), lr)
+            self._q, self._cq_dense, self._obs_fresh, self._started = None, None, False, True
+            return
+        tq = self.full_sites()
         if (self._q is None or self._q["mom"] is None) and self._sweep_fusion():
             # no refresh of these sites is cached: the backward sweep of the refresh makes the update itself, without ever
             # writing the marginals (mfgm_girsanov.h); theta_q moves to the spare buffer
