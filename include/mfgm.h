@@ -238,6 +238,30 @@ int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state
 int mfgm_mvn_ve_compact(int B, int n_per, int d, const double* mu, const double* cov, const double* y, const double* Sinv, double cst,
                         double* ve, void* stream);
 
+/* ---- Kalman filter with Gaussian sites and a time-invariant emission matrix (kalman_filter.py:86-107, 184-271, 417-500) ----------------
+ * The path of KalmanFilterWithSites.log_likelihood / CVIGaussianProcess.elbo and of predict_f at the data points
+ * (variational_cvi.py:106-135, 351-379): sites nat1 [Bs, T, o], nat2 [Bs, T, o, o] in natural layout (Bs = 1: shared by all chains,
+ * or B), H [o, d] row-major, Hmu = H mu_prior [B, T, o] (NULL: zero-mean prior).  o <= 2, d <= 8.  One call = assembly of the
+ * posterior precision + right-hand side in the packed layout, the sweeps, and the reductions / projections around them. */
+typedef struct mfgm_kf_sites {
+    double H[32];
+    int o;
+    int site_batch;
+    const double* nat1;
+    const double* nat2;
+    const double* Hmu;
+} mfgm_kf_sites;
+/* log-likelihood terms per chain: t1 = sum_t (y_t - H mu_p)^T R_t^{-1} (y_t - H mu_p), ldR = sum_t log det R_t^{-1}, logdet = log|L| of
+ * the posterior precision, quad = |L^{-1} H^T R^{-1} (y - H mu_p)|^2 (kalman_filter.py:229-251; R^{-1} = -2 nat2, y = site means).
+ * Pd (SYM) / Ps (FULL): packed prior precision blocks; D, r, L, y: packed scratch (SYM, VEC, TRI, VEC). */
+int mfgm_kf_sites_loglik(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, double* D, double* r,
+                         double* L, double* y, double* t1, double* ldR, double* logdet, double* quad, void* ws, int* info, void* stream);
+/* posterior marginals (Sig SYM, x VEC packed) of  precision = prior precision + H^T R^{-1} H,  rhs = plin + H^T nat1  (plin = packed
+ * K^{-1} mu_prior or NULL), and their projections Fmu = H x, Fvar = diag(H Sig H^T), natural [B, T, o]. */
+int mfgm_kf_sites_predict(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, const double* plin,
+                          double* D, double* r, double* L, double* y, double* Sig, double* x, double* Fmu, double* Fvar, void* ws,
+                          int* info, void* stream);
+
 /* CVI-DP on the moment array: KL[q||p] = -H[q] - E_q[log p] where E_q[log p] of a per-dimension cubic drift with diagonal
  * diffusion depends on q only through mom, so d KL / d eta = theta_q - theta~(mom) with explicit "effective prior naturals"
  * theta~ (csrc/mfgm_sde.h) and no d x d factorisation:

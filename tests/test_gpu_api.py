@@ -302,6 +302,9 @@ def test_kalman_filter_sites_golden(amd):
     sites = GaussianSitesNat(dev(g["site_means"] / g["site_covs"][..., 0]), dev(-0.5 / g["site_covs"]))
     kf = KalmanFilterWithSites(ssm, EmissionModel(H), sites)
     np.testing.assert_allclose(float(kf.log_likelihood()), g["log_lik_total"], rtol=1e-7)
+    # the same through the fused entry point (time-invariant emission matrix declared: mfgm_kf_sites_loglik)
+    kf2 = KalmanFilterWithSites(_gpu_ssm_from_golden(g, (), T), EmissionModel(H, constant_matrix=dev(g["H"])), sites)
+    np.testing.assert_allclose(float(kf2.log_likelihood()), g["log_lik_total"], rtol=1e-7)
     post = kf.posterior_state_space_model()
     assert_close(host(post.marginal_means), g["smooth_means"])
     assert_close(host(post.marginal_covariances), g["smooth_covs"])
@@ -1323,3 +1326,34 @@ def test_bench_gpus_2_launches_two_ranks(amd):
     singles = [run(["--gpus", "1", "--data-rank", str(r)]) for r in range(2)]
     assert all(s["n_gpus"] == 1 for s in singles)
     np.testing.assert_allclose(two["elbo_last"], sum(s["elbo_last"] for s in singles), rtol=1e-12)
+
+
+@pytest.mark.parametrize("tag,bs", [("b0", ()), ("b3", (3,))])
+def test_kalman_filter_sites_fused_output_dim_2(amd, tag, bs):
+    """KA2's fixture (T = 8, d = 3, o = 2, non-zero prior mean) as a filter with per-step sites nat1 = R^{-1} y, nat2 = -1/2 R^{-1}
+    through the fused entry points: the log-likelihood equals the reference NumPy filter's, and predict-at-the-data equals
+    (H mu, diag H Sigma H^T) of its smoother."""
+    from tests.conftest import golden
+    from vidp_amd.emission_model import EmissionModel
+    from vidp_amd.kalman_filter import GaussianSitesNat, KalmanFilterWithSites
+    g = golden(f"kalman_filter_{tag}.npz")
+    T = g["y"].shape[-2]
+    Rinv = np.linalg.inv(g["R"])
+    ssm = _gpu_ssm_from_golden(g, bs, T)
+    Hc = dev(g["H"])
+    em = EmissionModel(dev(np.broadcast_to(g["H"], bs + (T,) + g["H"].shape).copy()), constant_matrix=Hc)
+    y = g["y"].reshape((-1, T, 2))
+    B = y.shape[0]
+    sites = GaussianSitesNat(dev((y @ Rinv).reshape(B * T, 2)), dev(np.broadcast_to(-0.5 * Rinv, (B * T, 2, 2)).copy()))
+    kf = KalmanFilterWithSites(ssm, em, sites)
+    np.testing.assert_allclose(float(kf.log_likelihood()), g["log_lik_total"], rtol=1e-7)
+    # posterior marginals projected onto f
+    from vidp_amd.variational_cvi import GaussianProcessWithSitesBase, _predict_f_fused
+    class _M:      # the attributes _predict_f_fused reads
+        pass
+    m = _M()
+    m.dist_p, m.sites, m._emission = ssm, sites, (lambda: em)
+    Fmu, Fvar = _predict_f_fused(m)
+    sm, sc = g["smooth_means"], np.broadcast_to(g["smooth_covs"], bs + g["smooth_covs"].shape)
+    assert_close(host(Fmu), np.einsum("ai,...ti->...ta", g["H"], sm))
+    assert_close(host(Fvar), np.einsum("ai,...tij,aj->...ta", g["H"], sc, g["H"]))

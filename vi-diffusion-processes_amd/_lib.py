@@ -71,6 +71,8 @@ EXPORTS = {
     "mfgm_cq_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mfgm_cq_selinv_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11),
     "mfgm_mvn_ve_compact": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    "mfgm_kf_sites_loglik": (ctypes.c_int, [ctypes.c_void_p] * 15),
+    "mfgm_kf_sites_predict": (ctypes.c_int, [ctypes.c_void_p] * 16),
     "mfgm_natural_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_btd_cholesky": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),
     "mfgm_btd_posterior": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 7),
@@ -98,6 +100,12 @@ class CqState(ctypes.Structure):
     """mfgm_cq_state (include/mfgm.h)."""
     _fields_ = [("dyn", ctypes.c_void_p), ("d_off", ctypes.c_double), ("s_off", ctypes.c_double), ("p0_off", ctypes.c_void_p),
                 ("slot", ctypes.c_void_p), ("site_lin", ctypes.c_void_p), ("site_sym", ctypes.c_void_p)]
+
+
+class KfSites(ctypes.Structure):
+    """mfgm_kf_sites (include/mfgm.h)."""
+    _fields_ = [("H", ctypes.c_double * 32), ("o", ctypes.c_int), ("site_batch", ctypes.c_int), ("nat1", ctypes.c_void_p),
+                ("nat2", ctypes.c_void_p), ("Hmu", ctypes.c_void_p)]
 
 
 class KernelSpec(ctypes.Structure):

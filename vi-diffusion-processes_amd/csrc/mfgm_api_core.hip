@@ -22,7 +22,10 @@ void fill_level(LevelDesc& lv, int B, int n, int R) {
 
 extern "C" {
 
-const char* mfgm_version(void) { return "mfgm 0.1 (gfx950)"; }
+#ifndef MFGM_BUILD_ID
+#define MFGM_BUILD_ID "unknown"
+#endif
+const char* mfgm_version(void) { return "mfgm 0.2 (gfx950) build " MFGM_BUILD_ID; }
 
 int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
     if (!out || B < 1 || T < 1 || d < 1 || d > 32) return 1;

@@ -3,6 +3,7 @@
 #include "mfgm_sweeps.h"
 #include "mfgm_girsanov.h"
 #include "mfgm_cq.h"
+#include "mfgm_kf.h"
 
 using namespace mfgm;
 
@@ -380,6 +381,53 @@ int mvn_ve_compact_impl(int B, int n_per, const double* mu, const double* cov, c
     return 0;
 }
 
+// ---- Kalman filter with sites, time-invariant emission (mfgm_kf.h) ------------------------------------------------------------------
+template <int D, int O>
+int kf_assemble_impl(const Plan& P, const KfArgs& k, const double* Pd, const double* plin, double* Dg, double* rg, double* t1,
+                     double* ldR, double* ws, hipStream_t st) {
+    double* part = (t1 || ldR) ? ws + P.off_part[0] : nullptr;
+    hipLaunchKernelGGL((k_kf_assemble<D, O>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], P.T, k, Pd, plin, Dg, rg, part);
+    MFGM_CHECK_LAUNCH();
+    if (part) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, P.lv[0].P, P.lv[0].Lpad, t1, ldR);
+        MFGM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+template <int D, int O>
+int kf_loglik_impl(const Plan& P, const KfArgs& k, const double* Pd, const double* Ps, double* Dg, double* rg, double* L, double* y,
+                   double* t1, double* ldR, double* logdet, double* quad, double* ws, int* info, hipStream_t st) {
+    int rc = kf_assemble_impl<D, O>(P, k, Pd, nullptr, Dg, rg, t1, ldR, ws, st);
+    if (rc) return rc;
+    return factor_impl<D>(P, Dg, Ps, rg, 1.0, 1.0, 1.0, L, nullptr, y, logdet, quad, ws, info, st);
+}
+template <int D, int O>
+int kf_predict_impl(const Plan& P, const KfArgs& k, const double* Pd, const double* Ps, const double* plin, double* Dg, double* rg,
+                    double* L, double* y, double* Sig, double* x, double* Fmu, double* Fvar, double* ws, int* info, hipStream_t st) {
+    int rc = kf_assemble_impl<D, O>(P, k, Pd, plin, Dg, rg, nullptr, nullptr, ws, st);
+    if (rc) return rc;
+    rc = factor_impl<D>(P, Dg, Ps, rg, 1.0, 1.0, 1.0, L, nullptr, y, nullptr, nullptr, ws, info, st);
+    if (rc) return rc;
+    rc = selinv_impl<D>(P, L, nullptr, y, Sig, nullptr, x, ws, st, -1, nullptr, Ps, 1.0);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_kf_project<D, O>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], P.T, k, (const double*)x,
+                       (const double*)Sig, Fmu, Fvar);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+bool kf_args(const mfgm_plan* plan, const mfgm_kf_sites* sv, int mode, KfArgs& k) {
+    if (!plan || !sv || !sv->nat1 || !sv->nat2 || plan->p.wide) return false;
+    const Plan& P = plan->p;
+    if (sv->o < 1 || sv->o > 2 || (sv->site_batch != 1 && sv->site_batch != P.B)) return false;
+    memset(&k, 0, sizeof(k));
+    memcpy(k.H, sv->H, sizeof(double) * sv->o * P.d);
+    k.nat1 = sv->nat1; k.nat2 = sv->nat2; k.Hmu = sv->Hmu; k.site_batch = sv->site_batch; k.mode = mode;
+    return true;
+}
+#define MFGM_DISPATCH_DO(d, o, CALL)                                      \
+    if ((o) == 1) { constexpr int OO = 1; MFGM_DISPATCH_D(d, CALL); }     \
+    else { constexpr int OO = 2; MFGM_DISPATCH_D(d, CALL); }
+
 bool cq_ok(const mfgm_plan* plan, const mfgm_cq_state* q) {
     if (!plan || !q || !q->dyn) return false;
     const Plan& P = plan->p;
@@ -466,6 +514,27 @@ int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state
     CqArgs c = cq_args(q);
     c.obs_mu = obs_mu; c.obs_cov = obs_cov;
     MFGM_DISPATCH_D(P.d, (cq_selinv_kl_impl<DD>(P, c, L, y, pr, Sig, x, kl_part, (double*)ws, (hipStream_t)stream, only_level)));
+}
+
+int mfgm_kf_sites_loglik(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, double* D, double* r,
+                         double* L, double* y, double* t1, double* ldR, double* logdet, double* quad, void* ws, int* info, void* stream) {
+    KfArgs k;
+    if (!kf_args(plan, sites, 0, k) || !Pd || !D || !r || !L || !y || !t1 || !ldR || !logdet || !quad || !ws || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !Ps) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_DO(P.d, sites->o, (kf_loglik_impl<DD, OO>(P, k, Pd, Ps, D, r, L, y, t1, ldR, logdet, quad, (double*)ws, info, st)));
+}
+
+int mfgm_kf_sites_predict(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, const double* plin,
+                          double* D, double* r, double* L, double* y, double* Sig, double* x, double* Fmu, double* Fvar, void* ws,
+                          int* info, void* stream) {
+    KfArgs k;
+    if (!kf_args(plan, sites, 1, k) || !Pd || !D || !r || !L || !y || !Sig || !x || !Fmu || !Fvar || !ws || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !Ps) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_DO(P.d, sites->o, (kf_predict_impl<DD, OO>(P, k, Pd, Ps, plin, D, r, L, y, Sig, x, Fmu, Fvar, (double*)ws, info, st)));
 }
 
 int mfgm_mvn_ve_compact(int B, int n_per, int d, const double* mu, const double* cov, const double* y, const double* Sinv, double cst,

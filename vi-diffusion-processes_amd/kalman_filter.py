@@ -6,11 +6,12 @@ precision; one block Cholesky (HIP forward sweep) gives the log-determinant and 
 The per-observation algebra (output_dim 1-2) is tiny batched torch work; everything sequential in T runs in the sweeps.
 """
 import math
+import os
 
 import torch
 
 from . import linalg
-from ._lib import FULL, SYM, VEC
+from ._lib import FULL, SYM, TRI, VEC
 from .state_space_model import StateSpaceModel
 
 
@@ -152,6 +153,50 @@ class KalmanFilter(BaseKalmanFilter):
         return -2.0 * self.prior_ssm.T * torch.log(torch.diagonal(self._chol_obs_covariance)).sum()
 
 
+def fused_sites_call(ssm, emission, sites):
+    """(KfSites struct, keep-alive tuple) for the fused Kalman-filter-with-sites entry points (mfgm_kf_sites_*), or None when the
+    problem does not qualify: state_dim <= 8, output_dim <= 2, a time-invariant emission matrix, one site per time point."""
+    import ctypes
+    from . import _lib
+    Hc = getattr(emission, "constant_matrix", None)
+    if Hc is None or ssm.d > 8 or ssm.plan.d != ssm.d or Hc.shape[0] > 2 or os.environ.get("VIDP_FUSED_KF", "1") == "0":
+        return None
+    o, T = int(Hc.shape[0]), ssm.T
+    n1, n2 = sites.nat1, sites.nat2
+    if n1.dim() != 2 or tuple(n1.shape) not in ((T, o), (ssm.B * T, o)) or not n1.is_cuda:
+        return None
+    sv = _lib.KfSites()
+    Hh = Hc.detach().to("cpu", torch.float64).reshape(-1).tolist() if "_kf_H" not in emission.__dict__ else emission._kf_H
+    emission.__dict__["_kf_H"] = Hh
+    for i, v in enumerate(Hh):
+        sv.H[i] = v
+    n1c, n2c = n1.contiguous(), n2.contiguous()
+    sv.o, sv.site_batch = o, (1 if n1.shape[0] == T else ssm.B)
+    sv.nat1, sv.nat2 = n1c.data_ptr(), n2c.data_ptr()
+    # H mu_prior: zero for the kernel priors; computed once per prior otherwise
+    cache = ssm.__dict__.setdefault("_kf_cache", {})
+    if "zero_mean" not in cache:
+        cache["zero_mean"] = bool((ssm._mu0 == 0).all() and (ssm._b == 0).all())
+    hmu = None
+    if not cache["zero_mean"]:
+        key = ("Hmu", tuple(Hh))
+        if key not in cache:
+            mu = ssm.plan.unpack(VEC, ssm._posterior_packed()["s"]["x"])
+            cache[key] = torch.einsum("ai,bti->bta", Hc.to(mu.device), mu).contiguous()
+        hmu = cache[key]
+        sv.Hmu = hmu.data_ptr()
+    return sv, (n1c, n2c, hmu), cache
+
+
+def _kf_scratch(cache, pl, names):
+    bufs = cache.setdefault("bufs", {})
+    kinds = dict(D=SYM, r=VEC, L=TRI, y=VEC, Sig=SYM, x=VEC)
+    for nm in names:
+        if nm not in bufs:
+            bufs[nm] = pl.empty(kinds[nm])
+    return bufs
+
+
 class KalmanFilterWithSites(BaseKalmanFilter):
     """kalman_filter.py:440-500: time-dependent Gaussian likelihood terms (sites) in natural form."""
 
@@ -160,6 +205,29 @@ class KalmanFilterWithSites(BaseKalmanFilter):
             raise ValueError("The shape of the site matrices and the emission matrix are not compatible")
         self.sites = sites
         super().__init__(state_space_model, emission_model)
+
+    def log_likelihood(self):
+        """kalman_filter.py:184-255.  With a time-invariant emission matrix: one library call (assembly of the posterior precision
+        in the packed layout, the forward sweeps, the observation-term sums), a handful of [B]-sized operations here."""
+        import ctypes
+        from .packed import _ptr, _stream
+        from . import _lib
+        ssm, pl = self.prior_ssm, self.prior_ssm.plan
+        call = fused_sites_call(ssm, self.emission, self.sites)
+        if call is None:
+            return super().log_likelihood()
+        sv, keep, cache = call
+        pr = ssm._precision_packed()
+        b = _kf_scratch(cache, pl, ("D", "r", "L", "y"))
+        out = torch.empty((4, ssm.B), dtype=torch.float64, device=pl.device)
+        pl.epoch += 1
+        _lib.check(pl.lib.mfgm_kf_sites_loglik(pl.h, ctypes.byref(sv), _ptr(pr["diag"]), _ptr(pr["sub"]), _ptr(b["D"]), _ptr(b["r"]),
+                                               _ptr(b["L"]), _ptr(b["y"]), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
+                                               _ptr(pl.ws), _ptr(pl.info), _stream()), "mfgm_kf_sites_loglik")
+        pl.check_info()
+        cst = -0.5 * math.log(2 * math.pi) * sv.o * ssm.T
+        # cst + term1 + term2 + term3 (kalman_filter.py:229-255)
+        return (cst - 0.5 * out[0] + 0.5 * out[3] - pr["sumlogchol"] - out[2] + 0.5 * out[1]).sum()
 
     @property
     def _r_inv(self):

@@ -180,7 +180,7 @@ class StationaryKernel:
         for order, _, _ in self._components():
             h[0, off] = 1.0
             off += order
-        return EmissionModel(h.expand(tuple(time_points.shape) + (1, self.state_dim)).contiguous())
+        return EmissionModel(h.expand(tuple(time_points.shape) + (1, self.state_dim)).contiguous(), constant_matrix=h)
 
 
 def _check(lengthscale, variance):

@@ -91,7 +91,9 @@ class GaussianProcessWithSitesBase:
         return self._dist_p
 
     def _emission(self):
-        return self._kernel.generate_emission_model(self._time_points)
+        if getattr(self, "_em", None) is None:       # the time points are fixed: one emission model per model object
+            self._em = self._kernel.generate_emission_model(self._time_points)
+        return self._em
 
     def _posterior_naturals(self):
         """theta = prior naturals + back-projected sites (variational_cvi.py:106-135), packed."""
@@ -127,6 +129,9 @@ class GaussianProcessWithSitesBase:
 
     def predict_f_at_data(self):
         """posterior.predict_f(self.time_points): at the conditioning points this is (H mu, H Sigma H^T) of dist_q."""
+        fused = self._predict_f_fused()
+        if fused is not None:
+            return fused
         pl, lin, diag, sub = self._posterior_naturals()
         f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
         s = pl.selinv(f["L"], f["G"], f["y"], want_sub=False)
@@ -136,6 +141,36 @@ class GaussianProcessWithSitesBase:
         cov = pl.unpack(SYM, s["Sig"]).reshape(ssm.batch_shape + (ssm.T, ssm.d, ssm.d))
         em = self._emission()
         return em.project_state_to_f(mu), em.project_state_covariance_to_f(cov, full_output_cov=False)
+
+
+def _predict_f_fused(self):
+    """predict_f at the data points through mfgm_kf_sites_predict (time-invariant emission, state_dim <= 8): assembly, sweeps and the
+    projection onto f in one library call; None when the model does not qualify."""
+    import ctypes
+    from . import _lib
+    from .kalman_filter import _kf_scratch, fused_sites_call
+    from .packed import _ptr, _stream
+    ssm = self.dist_p
+    call = fused_sites_call(ssm, self._emission(), self.sites)
+    if call is None:
+        return None
+    sv, keep, cache = call
+    pl = ssm.plan
+    pr = ssm._precision_packed()
+    b = _kf_scratch(cache, pl, ("D", "r", "L", "y", "Sig", "x"))
+    o = sv.o
+    Fmu = torch.empty((ssm.B, ssm.T, o), dtype=torch.float64, device=pl.device)
+    Fvar = torch.empty_like(Fmu)
+    pl.epoch += 1
+    _lib.check(pl.lib.mfgm_kf_sites_predict(pl.h, ctypes.byref(sv), _ptr(pr["diag"]), _ptr(pr["sub"]),
+                                            None if cache["zero_mean"] else _ptr(pr["lin"]), _ptr(b["D"]), _ptr(b["r"]), _ptr(b["L"]),
+                                            _ptr(b["y"]), _ptr(b["Sig"]), _ptr(b["x"]), _ptr(Fmu), _ptr(Fvar), _ptr(pl.ws),
+                                            _ptr(pl.info), _stream()), "mfgm_kf_sites_predict")
+    shp = ssm.batch_shape + (ssm.T, o)
+    return Fmu.reshape(shp), Fvar.reshape(shp)
+
+
+GaussianProcessWithSitesBase._predict_f_fused = _predict_f_fused
 
 
 class CVIGaussianProcess(GaussianProcessWithSitesBase):
