@@ -1,18 +1,24 @@
 """
-bench.py -- ELBO steps/sec of the CVI site-update loop on the block-tri-diagonal Gauss-Markov path.
+bench.py -- ELBO steps/sec on the block-tri-diagonal Gauss-Markov path.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config headline|c1|c2|c3|c5]
       N > 1: either the caller starts the N ranks (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...), or,
       when no torch.distributed environment is present, bench.py starts them itself as a child job and relays rank 0's line.
 
-One "step" = one iteration of the reference's inner training loop (docs/diffusion_processes/cvi_dp_trainer.py:72-75):
+--config headline (default; the size BASELINE.json's metric is quoted on): one "step" = one iteration of the reference's inner
+training loop (docs/diffusion_processes/cvi_dp_trainer.py:72-75)
     model.update_data_sites(lr); model.update_girsanov_sites(lr); model.classic_elbo()
-on B independent synthetic double-well trajectories per GPU (T states, state dim d; weak scaling: every rank owns
-its own B trajectories, the only collective is the RCCL all-reduce of the scalar ELBO sum).
+on B = 64 independent synthetic double-well trajectories per GPU (T = 100 000 states, state dim d = 6; weak scaling: every rank
+owns its own B trajectories, the only collective is the RCCL all-reduce of the scalar ELBO sum).
+The other configs are BASELINE.json's `configs` (SURVEY.md 8d recipes), same JSON contract:
+    c1  CVI-DP on a 1-d Ornstein-Uhlenbeck SDE, T = 1001, 32 observations, one trajectory (the reference's own CPU-runnable case)
+    c2  Matern-5/2 kernel, T = 100 000, d = 3, one chain: CVIGaussianProcess.update_sites(); elbo()
+    c3  double-well SDE, VDP model (VariationalMarkovGP), T = 50 000, d = 6, 64 trajectories per GPU (c4 = c3 with --gpus 8)
+    c5  Sum-of-Matern kernel d = 16, 200 000 inducing states, 400 000 observations: SparseCVIGaussianProcess.update_sites(); classic_elbo()
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : the dominant kernel (backward selected-inverse sweep) timed alone with HIP events on its stream
-  cpu_baseline : the plain-C port of the same step (oracle/csrc) on the host cores, bounded sample, N=1 only
+  roofline     : the dominant kernel timed alone with HIP events on its stream (other_kernels: the rest of the level-0 sweeps)
+  cpu_baseline : the CPU port / oracle of the same step on the host cores, bounded sample, N = 1 only
 """
 import argparse
 import json
@@ -106,9 +112,20 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
             break
     per_step_sample = el / n
     value = 1.0 / (per_step_sample * args.B / Bs)
-    out = {"value": value, "unit": "ELBO steps/s", "cores": threads, "kind": "port",
-           "sample": f"{n} steps of {Bs} of the {args.B} trajectories (T={T}, d={d}), OpenMP over trajectories; "
-                     f"{per_step_sample:.3f} s per sampled step, scaled linearly to {args.B} trajectories; "
+    # one thread, one trajectory (the OpenMP loop runs over trajectories: a single trajectory is the single-thread figure)
+    lib.ref_set_num_threads(1)
+    st1 = c_ref.CviDpStepState(lin[None].copy(), diag[None].copy(), sub[None].copy(), idx, ys[:1], Rinv, 2 * np.sum(np.log(np.diag(Lc))),
+                               alpha, beta, np.ones(d), dt, np.zeros(d), np.eye(d))
+    st1.step(args.lr_data, args.lr_girsanov)
+    t1 = time.perf_counter()
+    st1.step(args.lr_data, args.lr_girsanov)
+    one = time.perf_counter() - t1
+    lib.ref_set_num_threads(threads)
+    out = {"value": value, "unit": "ELBO steps/s", "cores": threads, "threads_used": Bs, "kind": "port",
+           "single_thread_value": 1.0 / (one * args.B),
+           "sample": f"{n} steps of {Bs} of the {args.B} trajectories (T={T}, d={d}), OpenMP over trajectories ({Bs} of the {threads} "
+                     f"hardware threads busy: one per trajectory); {per_step_sample:.3f} s per sampled step, scaled linearly to "
+                     f"{args.B} trajectories; single thread: one step of one trajectory {one:.3f} s, scaled to {args.B}; "
                      f"closed-form cubic-drift moments as on the GPU (the reference's 20^d-point quadrature is infeasible at d={d})"}
     if gpu_first_elbo is not None:
         ref = first[:Bs]
@@ -152,19 +169,213 @@ def vdp_step_rate(B, T, d, dt, noise, idx, ys, device, steps=10):
             "workload": f"VDP (VariationalMarkovGP) inference step on the same {B} trajectories, T={T}, d={d}, stabilize_system on"}
 
 
-def pmc_traffic(kernel_name, B, T, d):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc/pmc_traffic.json:
-    separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same bench, read side doubled as the gfx950 guide
-    prescribes); None when no PMC profile exists for this workload size."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc", "pmc_traffic.json")
+def pmc_traffic(kernel_name, B, T, d, build):
+    """(HBM bytes per launch of `kernel_name`, source note) from the committed rocprofv3 PMC passes of this bench
+    (profiles/r02_pmc/pmc_traffic.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, read side doubled as the gfx950 guide
+    prescribes).  The figure is archival, not measured by this run: it is used only when the file was collected on THIS build of the
+    library (mfgm_version()) and this workload size; otherwise (None, why)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc", "pmc_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
-        if prof["workload"] != {"B": B, "T": T, "d": d}:
-            return None
-        return float(prof["kernels"][kernel_name]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    except (OSError, ValueError):
+        return None, "no PMC profile committed"
+    if prof.get("workload") != {"B": B, "T": T, "d": d}:
+        return None, "the committed PMC profile is for another workload size"
+    if prof.get("library_build") != build:
+        return None, f"the committed PMC profile was collected on library build {prof.get('library_build')!r}, this is {build!r}"
+    try:
+        return float(prof["kernels"][kernel_name]["hbm_bytes_per_launch"]), f"profiles/r02_pmc/pmc_traffic.json (build {build})"
+    except KeyError:
+        return None, "kernel not in the committed PMC profile"
+
+
+class Harness:
+    """What every configuration shares: the warm-up / timed loop bracketed by barriers and synchronisation, the maximum over ranks,
+    HIP-event timing of one call, and the contract fields of the JSON line."""
+
+    def __init__(self, args, rank, world, device, dist, vdist):
+        self.args, self.rank, self.world, self.device, self.dist, self.vdist = args, rank, world, device, dist, vdist
+
+    def fence(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, step):
+        """W untimed + K timed steps; returns seconds (maximum over ranks)."""
+        import torch
+        for _ in range(self.args.warmup):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(self.args.steps):
+            step()
+        self.fence()
+        el = time.perf_counter() - t0
+        return float(self.vdist.allreduce_max_(torch.tensor([el], dtype=torch.float64, device=self.device)).item())
+
+    @staticmethod
+    def timed(fn, reps=20):
+        """average milliseconds of fn() by HIP events on torch's current stream (the stream the library launches on)"""
+        import torch
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        fn()
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / reps
+
+    def line(self, elapsed, workload, name, extra_config):
+        a = self.args
+        return {"metric": "ELBO steps/sec (T=100k, d=6) at 1/2/4/8 GPU; HBM GB/s vs roofline", "value": a.steps / elapsed,
+                "unit": "ELBO steps/s", "n_gpus": self.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": dict({"workload": workload, "name": name}, **extra_config)}
+
+    @staticmethod
+    def roofline(kernel, what, k_ms, alg_bytes, per_step, ms_per_step, **more):
+        ach = alg_bytes / (k_ms * 1e-3) / 1e9
+        return dict({"bound": "hbm", "kernel": f"{kernel} ({what})", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": "no PMC profile committed for this configuration",
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": per_step,
+                     "share_of_step": per_step * k_ms / ms_per_step}, **more)
+
+
+def bench_vdp(h, data_rank):
+    """Config 3 (and 4 with --gpus 8): the VDP inference step of VIMarkovGPTrainer.perform_inference (vi_markov_gp_trainer.py:50-75:
+    Lagrange sweep + parameter update, forward pass, ELBO) on 64 double-well trajectories per GPU, T = 50 000, d = 6."""
+    import ctypes
+    import torch
+    import vidp_amd
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.packed import _ptr, _stream
+    from vidp_amd.sde import DoubleWellSDE
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    a, device = h.args, h.device
+    B, T, d, dt, noise = a.B, 50000, 6, 0.01, 0.1
+    idx, ys = synth_double_well(B, T, d, dt, a.obs_every, noise, seed=71892305 + 3 + data_rank)
+    grid = np.arange(T) * dt
+    lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))
+    m = VariationalMarkovGP((grid[idx], torch.from_numpy(ys).to(device)), DoubleWellSDE(q=torch.eye(d, dtype=torch.float64)), grid, lik,
+                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=vidp_amd.Plan(B, T, d, device=device))
+    # q starts at the OU drift -4 x: from A = 0 the marginal variance of a chain this long reaches T dt and the sixth-order moments
+    # overflow the first update
+    eye = (4.0 * torch.eye(d, dtype=torch.float64, device=device)).expand(B, T, d, d).contiguous()
+    m.plan.pack(vidp_amd.FULL, eye, out=m.A)
+    del eye
+    state = {"mS": m._forward_packed(), "e": None}
+
+    def step():
+        m.update_lagrange_and_param(state["mS"], lr=0.01)
+        state["mS"] = m._forward_packed()
+        state["e"] = h.vdist.allreduce_sum_(m.elbo(state["mS"]))
+
+    elapsed = h.run(step)
+    m.plan.check_info()
+    e = float(state["e"])
+    assert np.isfinite(e), "non-finite VDP ELBO"
+    pl = m.plan
+    out = h.line(elapsed, f"VDP (VariationalMarkovGP) inference step (update_lagrange + update_param, forward_pass, elbo) on double-well SDE "
+                          f"trajectories, T={T}, d={d}, {B} trajectories per GPU, stabilize_system on", "c3",
+                 {"trajectories_per_gpu": B, "T": T, "d": d, "total_trajectories": B * h.world,
+                  "partition": {"levels": pl.nlevels, "segment_len": pl.R, "lanes": pl.Lpad}})
+    out["elbo_last"] = e
+    if h.rank == 0:
+        # the final Lagrange sweep (psi, lambda by the partitioned affine recurrence, then the update of (A, b) node by node) alone,
+        # on scratch copies of (A, b): the kernel with the largest share of the step
+        lib = vidp_amd._lib.load()
+        A2, b2 = m.A.clone(), m.b.clone()
+        mS = state["mS"]
+        prm = m._params(lr=0.01)
+
+        def final():
+            assert lib.mfgm_packed_vdp_lagrange_update_final(pl.h, ctypes.byref(prm), _ptr(mS[0]), _ptr(mS[1]), _ptr(A2), _ptr(b2),
+                                                             _ptr(m._yR), _ptr(m._dobsS), _ptr(m.psi_lagrange), _ptr(m.lambda_lagrange),
+                                                             _ptr(m._seg), *m._jump_args(), _stream()) == 0
+        ET = d * (d + 1) // 2
+        # reads m, S, A, b, yR, the observation count (half a double); writes psi, lambda and the new A, b
+        doubles = (d + ET + d * d + d + d + 0.5) + (d * d + d) + (d * d + d)
+        out["roofline"] = h.roofline(f"void mfgm::k_vdp_lagrange<{d}, 4>(...)",
+                                     "final Lagrange sweep with the parameter update: reads m, S, A, b, R^-1 y, writes psi, lambda, A, b",
+                                     h.timed(final), 8 * doubles * B * T, 1, out["ms_per_step"])
+    return out
+
+
+def bench_cvigp(h, data_rank):
+    """Config 2: Matern-5/2 kernel, T = 100 000, d = 3, one chain; one step = CVIGaussianProcess.update_sites(); elbo()
+    (variational_cvi.py:351-379; elbo = the Kalman log-likelihood with sites, kalman_filter.py:184-255)."""
+    import ctypes
+    import torch
+    import vidp_amd
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.packed import _ptr, _stream
+    from vidp_amd.variational_cvi import CVIGaussianProcess
+    a, device = h.args, h.device
+    T, d = 100000, 3
+    rng = np.random.default_rng(71892305 + 2 + data_rank)
+    t = torch.linspace(0, 0.01 * T, T, dtype=torch.float64, device=device)          # rho = dt / lengthscale = 0.05 (SURVEY 8d)
+    y = (torch.sin(12 * t) + 0.1 * torch.from_numpy(rng.normal(size=T)).to(device))[:, None]
+    m = CVIGaussianProcess((t, y), K.Matern52(lengthscale=0.2, variance=1.0), Gaussian(0.01), learning_rate=0.5)
+    state = {"e": None}
+
+    def step():
+        m.update_sites()
+        state["e"] = h.vdist.allreduce_sum_(m.elbo())
+
+    elapsed = h.run(step)
+    e = float(state["e"])
+    assert np.isfinite(e), "non-finite ELBO"
+    pl = m.dist_p.plan
+    out = h.line(elapsed, f"CVI for GP regression (CVIGaussianProcess.update_sites + elbo), Matern-5/2 kernel, T={T}, d={d}, one chain per GPU",
+                 "c2", {"trajectories_per_gpu": 1, "T": T, "d": d, "total_trajectories": h.world,
+                        "partition": {"levels": pl.nlevels, "segment_len": pl.R, "lanes": pl.Lpad}})
+    out["elbo_last"] = e
+    if h.rank == 0:
+        lib = vidp_amd._lib.load()
+        ssm = m.dist_p
+        pr, b = ssm._precision_packed(), ssm._kf_cache["bufs"]
+        null = ctypes.c_void_p(0)
+
+        def fwd():
+            assert lib.mfgm_packed_factor_stage(pl.h, 1, 0, _ptr(b["D"]), _ptr(pr["sub"]), _ptr(b["r"]), 1.0, 1.0, 1.0, _ptr(b["L"]), null,
+                                                _ptr(b["y"]), _ptr(pl.ws), _ptr(pl.info), _stream()) == 0
+        ET = d * (d + 1) // 2
+        out["roofline"] = h.roofline(f"void mfgm::k_forward<{d}, true, false, true>(mfgm::SweepArgs)",
+                                     "level 0 forward sweep; one chain: the step is bound by dependent launches and short sweeps, not by HBM",
+                                     h.timed(fwd), 8 * ((ET + d * d + d) + (ET + d)) * T, 2, out["ms_per_step"])
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_cvigp(t.cpu().numpy(), y.cpu().numpy(), T)
+    return out
+
+
+def cpu_baseline_cvigp(t, y, T, sample=2000):
+    """The NumPy oracle of the same step (oracle/np_models.CVIGaussianProcess: dense per-step loops, one thread) on the first `sample`
+    points, scaled linearly to T (the algorithm is O(T))."""
+    from oracle import np_kernels, np_models
+    o = np_models.CVIGaussianProcess(t[:sample], y[:sample], np_kernels.Matern52(0.2, 1.0), np_models.GaussianLik(0.01), learning_rate=0.5)
+    o.update_sites()
+    o.elbo()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.update_sites()
+        o.elbo()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 10:
+            break
+    per = el / n * (T / sample)
+    return {"value": 1.0 / per, "unit": "ELBO steps/s", "cores": 1, "threads_used": 1, "kind": "port",
+            "sample": f"{n} steps of the NumPy oracle on the first {sample} of the {T} points ({el / n:.3f} s each), scaled linearly to {T}"}
+
+
+OTHER_CONFIGS = {"c3": bench_vdp, "c2": bench_cvigp}
 
 
 def main():
@@ -180,6 +391,8 @@ def main():
     ap.add_argument("--obs-every", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vdp", action="store_true", help="skip the secondary VDP step measurement")
+    ap.add_argument("--config", default="headline", choices=["headline", "c1", "c2", "c3", "c5"],
+                    help="BASELINE.json configuration (default: the size the metric is quoted on)")
     ap.add_argument("--data-rank", type=int, default=None,
                     help="generate the synthetic trajectories of this rank (default: the process's own rank); lets a single-rank run "
                          "reproduce one shard of a multi-rank run")
@@ -205,19 +418,49 @@ def main():
     device = torch.device("cuda", torch.cuda.current_device())
 
     from vidp_amd.likelihoods import MultivariateGaussian
-    from vidp_amd.sde import DoubleWellSDE
+    from vidp_amd.sde import DoubleWellSDE, OrnsteinUhlenbeckSDE
     from vidp_amd.variational_cvi_sde import CVISitesSDE
 
-    B, T, d = args.B, args.T, args.d
-    dt, noise = 0.01, 0.1
     data_rank = rank if args.data_rank is None else args.data_rank
-    idx, ys = synth_double_well(B, T, d, dt, args.obs_every, noise, seed=71892305 + 3 + data_rank)
+    harness = Harness(args, rank, world, device, dist, vdist)
+    if args.config in OTHER_CONFIGS:
+        out = OTHER_CONFIGS[args.config](harness, data_rank)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    dt, noise = 0.01, 0.1
+    if args.config == "c1":
+        # OU process generated with decay 0.5, prior decay 1.2, q = 1, T = 1001, 32 observations at random grid
+        # indices, sigma = 0.1, x0 = 1, both learning rates 1 (configs/cvi_linear_process.yaml)
+        args.B, args.T, args.d, args.lr_data, args.lr_girsanov = 1, 1001, 1, 1.0, 1.0
+        B, T, d = 1, 1001, 1
+        rng = np.random.default_rng(71892305 + 1 + data_rank)
+        x, xs = 1.0, np.empty(T)
+        for t in range(T):
+            xs[t] = x
+            x = x + dt * (-0.5 * x) + np.sqrt(dt) * rng.standard_normal()
+        idx = np.sort(rng.choice(np.arange(1, T), size=32, replace=False))
+        ys = (xs[idx] + noise * rng.standard_normal(32))[None, :, None]
+        sde = OrnsteinUhlenbeckSDE(1.2, torch.eye(1, dtype=torch.float64))
+        lik = MultivariateGaussian(torch.tensor([[noise]], dtype=torch.float64, device=device))
+        init = (np.zeros(1), np.eye(1) / 2.4)
+        what = "CVI-DP on a 1-d Ornstein-Uhlenbeck SDE (config 1: T=1001, 32 observations, prior decay 1.2, lr 1)"
+    else:
+        B, T, d = args.B, args.T, args.d
+        idx, ys = synth_double_well(B, T, d, dt, args.obs_every, noise, seed=71892305 + 3 + data_rank)
+        sde = DoubleWellSDE(q=torch.eye(d, dtype=torch.float64))
+        lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))
+        init = (np.zeros(d), np.eye(d))
+        what = (f"CVI-DP site-update loop (CVISitesSDE: update_data_sites + update_girsanov_sites + classic_elbo) on double-well SDE "
+                f"trajectories, T={T}, d={d}, {B} trajectories per GPU, observation every {args.obs_every} steps, correlated "
+                f"observation noise (full d x d data sites)")
     plan = vidp_amd.Plan(B, T, d, device=device)
     grid = np.arange(T) * dt
-    lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))
-    sde = DoubleWellSDE(q=torch.eye(d, dtype=torch.float64))
-    model = CVISitesSDE(sde, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik,
-                        prior_initial_state=(np.zeros(d), np.eye(d)), plan=plan)
+    model = CVISitesSDE(sde, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik, prior_initial_state=init, plan=plan)
 
     elbos, first_elbo = [], []
 
@@ -255,10 +498,7 @@ def main():
         "value": args.steps / elapsed, "unit": "ELBO steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"CVI-DP site-update loop (CVISitesSDE: update_data_sites + update_girsanov_sites + classic_elbo) "
-                               f"on double-well SDE trajectories, T={T}, d={d}, {B} trajectories per GPU, "
-                               f"observation every {args.obs_every} steps, correlated observation noise (full d x d data sites)",
-                   "trajectories_per_gpu": B, "T": T, "d": d, "total_trajectories": B * world,
+        "config": {"workload": what, "name": args.config, "trajectories_per_gpu": B, "T": T, "d": d, "total_trajectories": B * world,
                    "partition": {"levels": plan.nlevels, "segment_len": plan.R, "lanes": plan.Lpad}},
         "elbo_last": elbo_vals[-1],
     }
@@ -361,19 +601,20 @@ def main():
             k_ms = timed(fn)
             alg_bytes = 8 * doubles * B * T
             ach = alg_bytes / (k_ms * 1e-3) / 1e9
+            traffic, tsrc = pmc_traffic(kname, B, T, d, lib.mfgm_version().decode())
             rows.append({"bound": "hbm", "kernel": f"{kname} ({what})", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(kname, B, T, d), "kernel_ms": k_ms,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": per_step,
                          "share_of_step": per_step * k_ms / ms_per_step})
         rows.sort(key=lambda r: -r["share_of_step"])
         out["roofline"] = dict(rows[0], other_kernels=rows[1:])
-        if world == 1 and not args.no_vdp:
+        if world == 1 and not args.no_vdp and args.config == "headline":
             # free the CVI-DP state first: the VDP model keeps its own ~15 GB resident
             del model, f, s, cand, cq
             tq = sp = cst = None
             torch.cuda.empty_cache()
             out["vdp"] = vdp_step_rate(B, T, d, dt, noise, idx, ys, device)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "headline":
             try:
                 out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise, first_elbo[0].cpu().numpy())
             except OSError as e:  # library not built

@@ -354,6 +354,11 @@ int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, 
 int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
                                     double* bm, const double* yR, const double* dobsS, double* psi, double* lam, double* seg,
                                     const int* obs_count, const double* dobs_const, void* stream);
+/* Profiling / roofline entry point: the LAST kernel of mfgm_packed_vdp_lagrange_update alone (the final sweep that also replaces
+ * (Am, bm)); seg must hold the segment scans of a full call with the same arguments. */
+int mfgm_packed_vdp_lagrange_update_final(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
+                                          double* Am, double* bm, const double* yR, const double* dobsS, double* psi, double* lam,
+                                          double* seg, const int* obs_count, const double* dobs_const, void* stream);
 /* update_param (vi_sde.py:377-414): A <- (1-lr) A + lr (-E f' + 2 q psi), b <- (1-lr) b + lr (E f + A~ m - q lambda).
  * With prm->clip > 0 psi and lam are overwritten by their clipped values (they are not const then). */
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

@@ -41,6 +41,8 @@ def load():
         lib.ref_cvi_dp_step.argtypes = ([ctypes.c_int] * 4 + [_ip, _dp, _dp, ctypes.c_double] + [_dp] * 6 + [ctypes.c_double]
                                         + [_dp] * 7 + [ctypes.c_double, ctypes.c_double, _dp, _dp])
         lib.ref_num_threads.restype = ctypes.c_int
+        lib.ref_set_num_threads.argtypes = [ctypes.c_int]
+        lib.ref_set_num_threads.restype = None
         _lib = lib
     return _lib
 

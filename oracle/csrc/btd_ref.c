@@ -517,6 +517,11 @@ double ref_cvi_dp_step(int B, int T, int d, int n, const int* idx, const double*
     return total;
 }
 
+/* number of OpenMP threads later calls may use (the baseline is timed with all host cores and with one) */
+void ref_set_num_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
+
 int ref_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -1,7 +1,7 @@
 """
 Per-kernel HBM traffic from two rocprofv3 counter passes of bench.py (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE):
 
-    python tools/pmc_summarize.py FETCH.csv WRITE.csv B T d > profiles/r01_pmc/pmc_traffic.json
+    python tools/pmc_summarize.py FETCH.csv WRITE.csv B T d "<mfgm_version() of the library that ran>" > profiles/r02_pmc/pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are KB per dispatch; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so HBM read bytes are
 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section).  Medians over the dispatches of each kernel.
@@ -16,13 +16,14 @@ def medians(path, counter):
     per = {}
     with open(path) as fh:
         for row in csv.DictReader(fh):
-            if row["Counter_Name"] == counter:
+            if row["Counter_Name"] == counter and "mfgm::" in row["Kernel_Name"]:
                 per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
     return {k: (statistics.median(v), len(v)) for k, v in per.items()}
 
 
 def main():
     fetch, write, B, T, d = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    build = sys.argv[6] if len(sys.argv) > 6 else None
     fr, wr = medians(fetch, "FETCH_SIZE"), medians(write, "WRITE_SIZE")
     kernels = {}
     for k, (f_kb, n) in fr.items():
@@ -34,6 +35,7 @@ def main():
         "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                    "(and a second pass with --pmc WRITE_SIZE); summarised by tools/pmc_summarize.py",
         "workload": {"B": B, "T": T, "d": d},
+        "library_build": build,
         "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (median over dispatches); on gfx950 FETCH_SIZE counts 64 B per 128-B "
                  "request, so HBM read bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section)",
         "kernels": kernels}, indent=1))

@@ -36,6 +36,11 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         MFGM_CHECK_LAUNCH();
         if (what == 2) hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
         else hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
+    } else if (what == 7) {
+        // the final Lagrange sweep with the parameter update alone (roofline timing; the segment scans of a full call must be in o2)
+        double* Aw = const_cast<double*>(a2);
+        double* bw = const_cast<double*>(a3);
+        hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
     } else if (what == 6) {
         // forward_pass as the partitioned moment recursion: a2 = q0_mu [B, d], a3 = q0_cov [B, ET]; o0 = mu, o1 = Sig, o2 = seg
         // a4 (optional) = E_sde / dt per trajectory [B], then ws holds the per-lane partials
@@ -124,6 +129,17 @@ int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(5, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st, obs_count, dobs_const)));
+}
+
+int mfgm_packed_vdp_lagrange_update_final(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
+                                          double* Am, double* bm, const double* yR, const double* dobsS, double* psi, double* lam,
+                                          double* seg, const int* obs_count, const double* dobs_const, void* stream) {
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !psi || !lam || !seg) return 1;
+    if ((obs_count != nullptr) != (dobs_const != nullptr) || (!obs_count && !dobsS)) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(7, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st, obs_count, dobs_const)));
 }
 
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,
