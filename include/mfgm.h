@@ -262,6 +262,32 @@ int mfgm_kf_sites_predict(const mfgm_plan* plan, const mfgm_kf_sites* sites, con
                           double* D, double* r, double* L, double* y, double* Sig, double* x, double* Fmu, double* Fvar, void* ws,
                           int* info, void* stream);
 
+/* ---- sparse / inducing-state CVI (markovflow/models/sparse_variational_cvi.py; csrc/mfgm_sparse.h) ----------------------------------------
+ * One chain, M inducing states, N data points sorted in time; natural-layout arrays, d <= 32.  Interval m = 0..M lies between inducing
+ * states m-1 and m (the prior pads both ends); seg [M+2] are the CSR offsets of the data points per interval; w [N, 2d] = H P_i is the
+ * projection of data point i onto the pair of states around it and c [N] = H T_i H^T its conditional variance (conditionals.py:207-256;
+ * functions of the time points and the kernel only).  All pointers are device pointers. */
+typedef struct mfgm_sparse_data {
+    int M, d, N;
+    const int* seg;
+    const double* w;
+    const double* c;
+    const double* prior_mean;   /* [d]    kernel.initial_mean            (sde_kernel.py:402-419) */
+    const double* prior_cov;    /* [d, d] kernel.initial_covariance_matrix */
+} mfgm_sparse_data;
+/* posterior naturals = prior naturals (plin [T, d] or NULL, pdiag / psub [T, d, d]) + the sites nat1 [M+1, 2d], nat2 [M+1, 2d, 2d]
+ * overlap-added into the block-tri-diagonal structure (sparse_variational_cvi.py:140-174); T = M. */
+int mfgm_sparse_theta(int T, int d, const double* nat1, const double* nat2, const double* plin, const double* pdiag, const double* psub,
+                      double* lin, double* diag, double* sub, void* stream);
+/* q(f(t_i)) at the data points (posterior.py:207-260 through conditionals.py:380-470) from the posterior marginals of the inducing
+ * states: mu [M, d], Sig [M, d, d], Sub [M, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N]. */
+int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
+                        void* stream);
+/* update_sites (sparse_variational_cvi.py:176-221): sites <- (1 - lr) sites + lr sum_{i in interval} (g1_i w_i, g2_i w_i w_i^T), in place;
+ * g1, g2 [N] are the likelihood gradients with respect to the expectation parameters of f(t_i). */
+int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2,
+                            void* stream);
+
 /* CVI-DP on the moment array: KL[q||p] = -H[q] - E_q[log p] where E_q[log p] of a per-dimension cubic drift with diagonal
  * diffusion depends on q only through mom, so d KL / d eta = theta_q - theta~(mom) with explicit "effective prior naturals"
  * theta~ (csrc/mfgm_sde.h) and no d x d factorisation:

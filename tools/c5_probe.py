@@ -15,7 +15,7 @@ from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess  # noqa: E4
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-    N = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 400000
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     span = M * 0.01
     kern = K.Sum([K.Matern52(lengthscale=0.02 + 0.01 * i, variance=1.0 / (i + 1)) for i in range(5)] + [K.Matern12(0.05, 0.5)])

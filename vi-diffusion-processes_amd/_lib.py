@@ -74,6 +74,9 @@ EXPORTS = {
     "mfgm_mvn_ve_compact": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_kf_sites_loglik": (ctypes.c_int, [ctypes.c_void_p] * 15),
     "mfgm_kf_sites_predict": (ctypes.c_int, [ctypes.c_void_p] * 16),
+    "mfgm_sparse_theta": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 9),
+    "mfgm_sparse_predict": (ctypes.c_int, [ctypes.c_void_p] * 7),
+    "mfgm_sparse_site_update": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] + [ctypes.c_void_p] * 3),
     "mfgm_natural_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_btd_cholesky": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),
     "mfgm_btd_posterior": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 7),
@@ -101,6 +104,12 @@ class CqState(ctypes.Structure):
     """mfgm_cq_state (include/mfgm.h)."""
     _fields_ = [("dyn", ctypes.c_void_p), ("d_off", ctypes.c_double), ("s_off", ctypes.c_double), ("p0_off", ctypes.c_void_p),
                 ("slot", ctypes.c_void_p), ("site_lin", ctypes.c_void_p), ("site_sym", ctypes.c_void_p)]
+
+
+class SparseData(ctypes.Structure):
+    """mfgm_sparse_data (include/mfgm.h)."""
+    _fields_ = [("M", ctypes.c_int), ("d", ctypes.c_int), ("N", ctypes.c_int), ("seg", ctypes.c_void_p), ("w", ctypes.c_void_p),
+                ("c", ctypes.c_void_p), ("prior_mean", ctypes.c_void_p), ("prior_cov", ctypes.c_void_p)]
 
 
 class KfSites(ctypes.Structure):

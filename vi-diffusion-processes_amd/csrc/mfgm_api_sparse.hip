@@ -1,0 +1,51 @@
+// C-ABI entry points of the sparse / inducing-state CVI local kernels (mfgm_sparse.h).
+#include "mfgm_internal.h"
+#include "mfgm_sparse.h"
+
+using namespace mfgm;
+
+namespace {
+SparseArgs sparse_args(const mfgm_sparse_data* s) {
+    SparseArgs a;
+    a.M = s->M; a.d = s->d; a.N = s->N; a.seg = s->seg; a.w = s->w; a.c = s->c; a.prior_mean = s->prior_mean; a.prior_cov = s->prior_cov;
+    return a;
+}
+bool sparse_ok(const mfgm_sparse_data* s) {
+    return s && s->M >= 1 && s->d >= 1 && s->d <= 32 && s->N >= 0 && s->seg && (s->N == 0 || (s->w && s->c));
+}
+}  // namespace
+
+extern "C" {
+
+int mfgm_sparse_theta(int T, int d, const double* nat1, const double* nat2, const double* plin, const double* pdiag, const double* psub,
+                      double* lin, double* diag, double* sub, void* stream) {
+    if (T < 1 || d < 1 || d > 32 || !nat1 || !nat2 || !pdiag || !psub || !lin || !diag || !sub) return 1;
+    const size_t total = (size_t)T * d * d;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(k_sparse_theta, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T, d, nat1, nat2, plin, pdiag, psub, lin, diag, sub);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
+                        void* stream) {
+    if (!sparse_ok(data) || !mu || !Sig || !Sub || !fmu || !fvar || !data->prior_mean || !data->prior_cov) return 1;
+    if (data->N == 0) return 0;
+    const int d2 = 2 * data->d;
+    const size_t shmem = sizeof(double) * ((size_t)d2 * d2 + 2 * d2);
+    hipLaunchKernelGGL(k_sparse_predict, dim3(data->M + 1), dim3(64), shmem, (hipStream_t)stream, sparse_args(data), mu, Sig, Sub, fmu, fvar);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2,
+                            void* stream) {
+    if (!sparse_ok(data) || !nat1 || !nat2 || (data->N > 0 && (!g1 || !g2))) return 1;
+    const int d2 = 2 * data->d;
+    hipLaunchKernelGGL(k_sparse_sites, dim3(data->M + 1), dim3(256), sizeof(double) * (d2 + 2), (hipStream_t)stream, sparse_args(data), g1,
+                       g2, lr, nat1, nat2);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// Local kernels of the sparse / inducing-state CVI model (markovflow/models/sparse_variational_cvi.py:140-221;
+// conditionals.py:380-470; posterior.py:207-260), on natural-layout arrays, any state dimension d <= 32, one chain:
+//
+//   k_sparse_theta   : posterior naturals = prior naturals + the [M+1, 2d, 2d] sites overlap-added into the block-tri-diagonal
+//                      structure (:160-172), in one pass
+//   k_sparse_predict : q(f(t_i)) at the data points from the pairwise posterior marginals of the two inducing states around t_i
+//                      (pairwise_marginals + base_conditional_predict + the projection onto f), without materialising the
+//                      [M+1, 2d, 2d] pairwise covariances or any per-data-point [2d, 2d] tensor
+//   k_sparse_sites   : data -> site sums  s_m = sum_{i in interval m} (g1_i w_i, g2_i w_i w_i^T)  (the reference's dynamic_partition +
+//                      Python list of reduce_sums, :199-213) fused with the damped site update (:215-221)
+//
+// w_i = H P_i [2d] is the projection of data point i onto the pair of inducing states around it (conditionals.py:207-256); it and
+// c_i = H T_i H^T depend only on the time points and the kernel, and are computed once per data set by the caller.
+// Intervals: m = 0 .. M (M inducing points); interval m lies between inducing states m-1 and m; the data points are sorted in time,
+// seg[m] .. seg[m+1] are those of interval m.  One workgroup per interval.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mfgm {
+
+struct SparseArgs {
+    int M, d, N;
+    const int* seg;          // [M + 2] CSR offsets of the data points per interval
+    const double* w;         // [N, 2d]
+    const double* c;         // [N]
+    const double* prior_mean;  // [d]   the kernel's initial mean (pads the chain at both ends)
+    const double* prior_cov;   // [d, d] the kernel's initial covariance
+};
+
+// theta = prior naturals + overlap-added sites.  nat1 [M+1, 2d], nat2 [M+1, 2d, 2d]; plin [T, d], pdiag / psub [T, d, d] with T = M.
+static __global__ void k_sparse_theta(int T, int d, const double* __restrict__ nat1, const double* __restrict__ nat2,
+                                      const double* __restrict__ plin, const double* __restrict__ pdiag,
+                                      const double* __restrict__ psub, double* __restrict__ lin, double* __restrict__ diag,
+                                      double* __restrict__ sub) {
+    const int d2 = 2 * d, dd = d * d;
+    const size_t total = (size_t)T * dd;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = e / dd;
+        const int r = (int)(e - t * dd), i = r / d, j = r - i * d;
+        const double* n_hi = nat2 + (t + 1) * (size_t)(d2 * d2);       // site t+1: its first state is inducing state t
+        const double* n_lo = nat2 + t * (size_t)(d2 * d2);             // site t:   its second state is inducing state t
+        diag[e] = pdiag[e] + n_hi[i * d2 + j] + n_lo[(d + i) * d2 + (d + j)];
+        sub[e] = (t + 1 < (size_t)T) ? psub[e] + 2.0 * n_hi[(d + i) * d2 + j] : 0.0;
+        if (j == 0) lin[t * d + i] = (plin ? plin[t * d + i] : 0.0) + nat1[(t + 1) * d2 + i] + nat1[t * d2 + d + i];
+    }
+}
+
+// marginals: mu [T, d], Sig [T, d, d] (full symmetric), Sub [T, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N]
+static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, const double* __restrict__ mu, const double* __restrict__ Sig,
+                                                             const double* __restrict__ Sub, double* __restrict__ fmu,
+                                                             double* __restrict__ fvar) {
+    extern __shared__ double sh[];     // PC [2d][2d], pm [2d], w [2d]
+    const int m = blockIdx.x, d = a.d, d2 = 2 * d, lane = threadIdx.x;
+    const int i0 = a.seg[m], i1 = a.seg[m + 1];
+    if (i0 >= i1) return;
+    double* PC = sh;
+    double* pm = sh + d2 * d2;
+    double* w = pm + d2;
+    const bool lo_prior = (m == 0), hi_prior = (m == a.M);
+    const double* S_lo = lo_prior ? a.prior_cov : Sig + (size_t)(m - 1) * d * d;
+    const double* S_hi = hi_prior ? a.prior_cov : Sig + (size_t)m * d * d;
+    const double* C = (lo_prior || hi_prior) ? nullptr : Sub + (size_t)(m - 1) * d * d;       // Cov(x_m, x_{m-1})
+    for (int e = lane; e < d2 * d2; e += 64) {
+        const int r = e / d2, cidx = e - r * d2;
+        double v;
+        if (r < d && cidx < d) v = S_lo[r * d + cidx];
+        else if (r >= d && cidx >= d) v = S_hi[(r - d) * d + (cidx - d)];
+        else if (r >= d) v = C ? C[(r - d) * d + cidx] : 0.0;               // lower-left: Cov(x_hi, x_lo)
+        else v = C ? C[(cidx - d) * d + r] : 0.0;                            // upper-right: its transpose
+        PC[e] = v;
+    }
+    for (int e = lane; e < d2; e += 64) {
+        const bool hi = e >= d;
+        const int k = hi ? e - d : e;
+        pm[e] = hi ? (hi_prior ? a.prior_mean[k] : mu[(size_t)m * d + k]) : (lo_prior ? a.prior_mean[k] : mu[(size_t)(m - 1) * d + k]);
+    }
+    __syncthreads();
+    for (int i = i0; i < i1; ++i) {
+        for (int e = lane; e < d2; e += 64) w[e] = a.w[(size_t)i * d2 + e];
+        __syncthreads();
+        double qm = 0.0, qv = 0.0;
+        if (lane < d2) {
+            double u = 0.0;
+            for (int k = 0; k < d2; ++k) u += PC[lane * d2 + k] * w[k];
+            qv = w[lane] * u;
+            qm = w[lane] * pm[lane];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            qm += __shfl_down(qm, off, 64);
+            qv += __shfl_down(qv, off, 64);
+        }
+        if (lane == 0) {
+            fmu[i] = qm;
+            fvar[i] = a.c[i] + qv;
+        }
+        __syncthreads();
+    }
+}
+
+// sites <- (1 - lr) sites + lr (sum_i g1_i w_i, sum_i g2_i w_i w_i^T), in place; g1, g2 [N]
+static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const double* __restrict__ g1, const double* __restrict__ g2,
+                                                            double lr, double* __restrict__ nat1, double* __restrict__ nat2) {
+    extern __shared__ double sh[];     // w [2d] and (g1, g2) of the current data point
+    const int m = blockIdx.x, d2 = 2 * a.d, tid = threadIdx.x;
+    const int i0 = a.seg[m], i1 = a.seg[m + 1];
+    const int ne = d2 * d2;
+    // each thread owns entries tid, tid + 256, ... of the [2d, 2d] block (at most 16 of them for 2d <= 64)
+    double acc[16];
+    double acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+    for (int i = i0; i < i1; ++i) {
+        __syncthreads();
+        for (int e = tid; e < d2; e += 256) sh[e] = a.w[(size_t)i * d2 + e];
+        if (tid == 0) { sh[d2] = g1[i]; sh[d2 + 1] = g2[i]; }
+        __syncthreads();
+        const double gg = sh[d2 + 1];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + k * 256;
+            if (e < ne) {
+                const int r = e / d2, cidx = e - r * d2;
+                acc[k] += gg * sh[r] * sh[cidx];
+            }
+        }
+        if (tid < d2) acc1 += sh[d2] * sh[tid];
+    }
+    double* n2 = nat2 + (size_t)m * ne;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + k * 256;
+        if (e < ne) n2[e] = (1.0 - lr) * n2[e] + lr * acc[k];
+    }
+    if (tid < d2) nat1[(size_t)m * d2 + tid] = (1.0 - lr) * nat1[(size_t)m * d2 + tid] + lr * acc1;
+}
+
+}  // namespace mfgm

@@ -4,10 +4,12 @@ Host-side mirror of markovflow/models/sparse_variational_cvi.py `SparseCVIGaussi
 [M+1, 2d, 2d] sites into the block-tri-diagonal natural parameters and the data -> site segment sums (a Python list of
 M+1 reduce_sums in the reference, :199-213) are single index_add operations; the posterior refresh runs in the HIP sweeps.
 """
+import os
+
 import torch
 
 from ._lib import FULL, SYM, VEC
-from .conditionals import conditional_statistics
+from .conditionals import _conditional_statistics, conditional_statistics
 from .posterior import ConditionalProcess
 from .ssm_gaussian_transformations import naturals_to_ssm_params_packed
 from .variational_cvi import back_project_nats
@@ -23,6 +25,7 @@ class SparseCVIGaussianProcess:
         self.nat1 = torch.zeros((M + 1, 2 * sd), dtype=dt, device=dev)
         self.nat2 = torch.zeros((M + 1, 2 * sd, 2 * sd), dtype=dt, device=dev)
         self._dist_p = None
+        self._version = 0          # bumped by every site update: keys the cached posterior marginals
 
     @property
     def kernel(self):
@@ -40,21 +43,10 @@ class SparseCVIGaussianProcess:
 
     @property
     def dist_q(self):
-        """Prior naturals + overlap-added site naturals (sparse_variational_cvi.py:140-174)."""
+        """Prior naturals + overlap-added site naturals (sparse_variational_cvi.py:140-174) as a StateSpaceModel."""
         p = self.dist_p
-        pl, sd = p.plan, self._kernel.state_dim
-        if getattr(self, "_p_nat", None) is None:      # the prior does not change between site updates
-            self._p_nat = pl.ssm_to_naturals(p.packed.A, p.packed.off, p.packed.chol)
-        nat = self._p_nat
-        lin = self.nat1[1:, :sd] + self.nat1[:-1, sd:]
-        diag = self.nat2[1:, :sd, :sd] + self.nat2[:-1, sd:, sd:]
-        sub = 2.0 * self.nat2[1:-1, sd:, :sd]
-        tl = pl.pack(VEC, lin[None].contiguous())
-        td = pl.pack(SYM, diag[None].contiguous())
-        ts = pl.pack(FULL, sub[None].contiguous()) if p.T > 1 else pl.zeros(FULL)
-        pl.lincomb(td, 1.0, td, 1.0, nat["diag"])
-        pl.lincomb(ts, 1.0, ts, 1.0, nat["sub"])
-        q = naturals_to_ssm_params_packed(pl, tl, td, ts)
+        lin, diag, sub = (x.clone() for x in self._theta())      # _theta() reuses its buffers
+        q = naturals_to_ssm_params_packed(p.plan, lin, diag, sub)
         q.batch_shape = p.batch_shape
         return q
 
@@ -66,8 +58,128 @@ class SparseCVIGaussianProcess:
         obj = self._likelihood.variational_expectations(Fmu, Fvar, Y).sum()
         return obj, self._likelihood.ve_gradients_expectation(Fmu, Fvar, Y)
 
+    # ---- fused route (csrc/mfgm_sparse.h): sorted data points, one chain ---------------------------------------------------------------
+    def _data(self, input_data):
+        """Per-data-set constants of the fused route: CSR offsets of the data points per inter-inducing interval, w_i = H P_i, c_i = H T_i H^T
+        (conditionals.py:207-256: functions of the time points and the kernel only), the kernel's initial state; or None when the
+        route does not apply (unsorted or batched time points)."""
+        import ctypes
+        import weakref
+        from . import _lib
+        time_points, observations = input_data
+        c = getattr(self, "_data_cache", None)
+        if c is not None and c["ref"]() is time_points and c["ver"] == time_points._version:
+            return c["val"]
+        val = None
+        z = self.inducing_inputs
+        if (time_points.dim() == 1 and z.dim() == 1 and time_points.is_cuda and os.environ.get("VIDP_FUSED_SPARSE", "1") != "0"
+                and (time_points.numel() < 2 or bool((time_points[1:] >= time_points[:-1]).all()))):
+            M, d, N = int(z.shape[0]), self._kernel.state_dim, int(time_points.shape[0])
+            P, Tc, idx = _conditional_statistics(time_points, z, self._kernel)
+            H = self._kernel.generate_emission_model(time_points[:1]).emission_matrix[0]          # [1, d], time-invariant
+            w = (H @ P)[:, 0, :].contiguous()                                                      # [N, 2d]
+            cc = (H @ Tc @ H.transpose(-1, -2))[:, 0, 0].contiguous()                              # [N]
+            seg = torch.zeros(M + 2, dtype=torch.int32, device=z.device)
+            seg[1:] = torch.cumsum(torch.bincount(idx, minlength=M + 1), 0).to(torch.int32)
+            pm = self._kernel.initial_mean(()).to(z.device, torch.float64).contiguous()
+            pc = self._kernel.initial_covariance_matrix().to(z.device, torch.float64).contiguous()
+            sd = _lib.SparseData()
+            sd.M, sd.d, sd.N = M, d, N
+            sd.seg, sd.w, sd.c, sd.prior_mean, sd.prior_cov = seg.data_ptr(), w.data_ptr(), cc.data_ptr(), pm.data_ptr(), pc.data_ptr()
+            val = dict(struct=sd, keep=(seg, w, cc, pm, pc), N=N)
+        self._data_cache = dict(ref=weakref.ref(time_points), ver=time_points._version, val=val)
+        return val
+
+    def _prior_natural(self):
+        """Prior naturals in natural layout ([T, d], [T, d, d] x 2) + their packed form and sum log chol (cached: the prior is fixed)."""
+        if getattr(self, "_pn", None) is None:
+            p = self.dist_p
+            pl = p.plan
+            nat = pl.ssm_to_naturals(p.packed.A, p.packed.off, p.packed.chol, want_logdet=True)
+            T, d = p.T, p.d
+            if pl.d > 8:      # wide plans: the packed arrays are the natural ones
+                lin, diag, sub = nat["lin"].view(T, d), nat["diag"].view(T, d, d), nat["sub"].view(T, d, d)
+            else:
+                lin, diag = pl.unpack(VEC, nat["lin"])[0], pl.unpack(SYM, nat["diag"])[0]
+                sub = torch.zeros((T, d, d), dtype=torch.float64, device=pl.device)
+                sub[:T - 1] = pl.unpack(FULL, nat["sub"], T - 1)[0]
+            self._pn = dict(nat=nat, lin=lin.contiguous(), diag=diag.contiguous(), sub=sub.contiguous(), zeros=pl.zeros(VEC))
+        return self._pn
+
+    def _theta(self):
+        """Posterior naturals of the current sites, packed (lin, diag, sub): one pass over the sites (mfgm_sparse_theta)."""
+        from . import _lib
+        from .packed import _ptr, _stream
+        p = self.dist_p
+        pl, T, d = p.plan, p.T, p.d
+        pn = self._prior_natural()
+        wide = pl.d > 8
+        b = self.__dict__.setdefault("_theta_bufs", {})
+        if not b:
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=pl.device)
+            b.update(lin=mk(T, d), diag=mk(T, d, d), sub=mk(T, d, d))
+        _lib.check(pl.lib.mfgm_sparse_theta(T, d, _ptr(self.nat1), _ptr(self.nat2), _ptr(pn["lin"]), _ptr(pn["diag"]), _ptr(pn["sub"]),
+                                            _ptr(b["lin"]), _ptr(b["diag"]), _ptr(b["sub"]), _stream()), "mfgm_sparse_theta")
+        if wide:
+            return b["lin"].view(-1), b["diag"].view(-1), b["sub"].view(-1)
+        return (pl.pack(VEC, b["lin"][None]), pl.pack(SYM, b["diag"][None]),
+                pl.pack(FULL, b["sub"][None, :T - 1].contiguous()) if T > 1 else pl.zeros(FULL))
+
+    def _marginals(self):
+        """Posterior marginals of the inducing states for the current sites: one factorisation + selected inverse, cached until the
+        sites move.  dict(mu [T, d], Sig [T, d, d], Sub [T, d, d] natural; packed Sig / Sub / x; log|L|)."""
+        m = getattr(self, "_marg", None)
+        if m is not None and m["version"] == self._version:
+            return m
+        p = self.dist_p
+        pl, T, d = p.plan, p.T, p.d
+        lin, diag, sub = self._theta()
+        bufs = self.__dict__.setdefault("_sweep_bufs", dict(f={}, s={}))
+        f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=bufs["f"])
+        bufs["f"].update(L=f["L"], G=f["G"], y=f["y"])
+        s = pl.selinv(f["L"], f["G"], f["y"], want_sub=True, out=bufs["s"])
+        bufs["s"].update(Sig=s["Sig"], Sub=s["Sub"], x=s["x"])
+        if pl.d > 8:
+            mu, Sig, Sub = s["x"].view(T, d), s["Sig"].view(T, d, d), s["Sub"].view(T, d, d)
+        else:
+            mu, Sig = pl.unpack(VEC, s["x"])[0], pl.unpack(SYM, s["Sig"])[0]
+            Sub = torch.zeros((T, d, d), dtype=torch.float64, device=pl.device)
+            if T > 1:
+                Sub[:T - 1] = pl.unpack(FULL, s["Sub"], T - 1)[0]
+        self._marg = dict(version=self._version, mu=mu, Sig=Sig, Sub=Sub, packed=s, logdetL=f["logdet"])
+        return self._marg
+
+    def _predict_f_data(self, data):
+        """(fmu, fvar) [N, 1] at the data points from the cached marginals (mfgm_sparse_predict)."""
+        import ctypes
+        from . import _lib
+        from .packed import _ptr, _stream
+        m = self._marginals()
+        pl = self.dist_p.plan
+        N = data["N"]
+        out = torch.empty((2, N), dtype=torch.float64, device=pl.device)
+        _lib.check(pl.lib.mfgm_sparse_predict(ctypes.byref(data["struct"]), _ptr(m["mu"]), _ptr(m["Sig"]), _ptr(m["Sub"]), _ptr(out[0]),
+                                              _ptr(out[1]), _stream()), "mfgm_sparse_predict")
+        return out[0][:, None], out[1][:, None]
+
     def update_sites(self, input_data):
         """theta_m <- (1 - rho) theta_m + rho g_m, g_m = data gradients projected through p(f_k | v_m) (sparse_variational_cvi.py:176-221)."""
+        data = self._data(input_data)
+        if data is None:
+            return self._update_sites_generic(input_data)
+        import ctypes
+        from . import _lib
+        from .packed import _ptr, _stream
+        time_points, observations = input_data
+        fx_mus, fx_covs = self._predict_f_data(data)
+        _, grads = self.local_objective_and_gradients(fx_mus, fx_covs, observations)
+        g1, g2 = grads[0].reshape(-1).contiguous(), grads[1].reshape(-1).contiguous()
+        pl = self.dist_p.plan
+        _lib.check(pl.lib.mfgm_sparse_site_update(ctypes.byref(data["struct"]), _ptr(g1), _ptr(g2), float(self.learning_rate), _ptr(self.nat1),
+                                                  _ptr(self.nat2), _stream()), "mfgm_sparse_site_update")
+        self._version += 1
+
+    def _update_sites_generic(self, input_data):
         time_points, observations = input_data
         fx_mus, fx_covs = self.posterior.predict_f(time_points)
         _, grads = self.local_objective_and_gradients(fx_mus, fx_covs, observations)
@@ -80,14 +192,35 @@ class SparseCVIGaussianProcess:
         lr = self.learning_rate
         self.nat1 = (1 - lr) * self.nat1 + lr * s1
         self.nat2 = (1 - lr) * self.nat2 + lr * s2
+        self._version += 1
 
     def classic_elbo(self, input_data):
         """sum_i E_q log p(y_i | f_i) - KL[q(s_Z) || p(s_Z)] (sparse_variational_cvi.py:270-292)."""
         time_points, observations = input_data
-        q = self.dist_q
-        fx_mus, fx_covs = ConditionalProcess(q, self._kernel, self.inducing_inputs).predict_f(time_points)
+        data = self._data(input_data)
+        if data is None:
+            q = self.dist_q
+            fx_mus, fx_covs = ConditionalProcess(q, self._kernel, self.inducing_inputs).predict_f(time_points)
+            ve = self._likelihood.variational_expectations(fx_mus, fx_covs, observations).sum()
+            return ve - q.kl_divergence(self.dist_p).sum()
+        fx_mus, fx_covs = self._predict_f_data(data)
         ve = self._likelihood.variational_expectations(fx_mus, fx_covs, observations).sum()
-        return ve - q.kl_divergence(self.dist_p).sum()
+        # KL[q || p] from the marginal blocks of q and the prior's naturals (state_space_model.py:528-593); the prior mean is zero
+        m, pn = self._marginals(), self._prior_natural()
+        p = self.dist_p
+        pl = p.plan
+        s = m["packed"]
+        tr, mh = pl.kl_terms(s["Sig"], s["Sub"], s["x"], pn["nat"]["diag"], pn["nat"]["sub"], self._prior_mean_packed(), aD=-2.0, aS=-1.0)
+        kl = 0.5 * (tr + mh - float(p.T * p.d) + 2.0 * pn["nat"]["sumlogchol"] + 2.0 * m["logdetL"])
+        return ve - kl.sum()
+
+    def _prior_mean_packed(self):
+        """Marginal means of the prior chain, packed (zero for the kernel priors)."""
+        if getattr(self, "_pmu", None) is None:
+            p = self.dist_p
+            zero = bool((p._mu0 == 0).all() and (p._b == 0).all())
+            self._pmu = p.plan.zeros(VEC) if zero else p._posterior_packed()["s"]["x"]
+        return self._pmu
 
     def loss(self, input_data):
         return -self.classic_elbo(input_data)
