@@ -375,7 +375,92 @@ def cpu_baseline_cvigp(t, y, T, sample=2000):
             "sample": f"{n} steps of the NumPy oracle on the first {sample} of the {T} points ({el / n:.3f} s each), scaled linearly to {T}"}
 
 
-OTHER_CONFIGS = {"c3": bench_vdp, "c2": bench_cvigp}
+def sum16_kernel(K):
+    """Sum of 4 x Matern-5/2 + 2 x Matern-3/2 (state dimension 3*4 + 2*2 = 16), lengthscales log-spaced 0.05 .. 2, unit variances."""
+    ls = np.exp(np.linspace(np.log(0.05), np.log(2.0), 6))
+    return K.Sum([K.Matern52(float(l), 1.0) for l in ls[:4]] + [K.Matern32(float(l), 1.0) for l in ls[4:]])
+
+
+def bench_sparse(h, data_rank):
+    """Config 5: sparse / inducing-state CVI (SparseCVIGaussianProcess.update_sites + classic_elbo, sparse_variational_cvi.py:176-292),
+    Sum-of-Matern kernel with state dimension 16, M = T = 200 000 inducing states on a uniform grid, N = 2 M observations."""
+    import ctypes
+    import torch
+    import vidp_amd
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.packed import _ptr, _stream
+    from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
+    a, device = h.args, h.device
+    M, d = 200000, 16
+    N, span = 2 * M, 0.01 * M
+    rng = np.random.default_rng(71892305 + 5 + data_rank)
+    z = torch.linspace(0, span, M, dtype=torch.float64, device=device)
+    t = torch.from_numpy(np.sort(rng.uniform(0, span, size=N))).to(device)
+    y = (torch.sin(3 * t) + 0.1 * torch.from_numpy(rng.normal(size=N)).to(device))[:, None]
+    kern = sum16_kernel(K)
+    assert kern.state_dim == d
+    m = SparseCVIGaussianProcess(kern, z, Gaussian(0.01), learning_rate=0.5)
+    state = {"e": None}
+
+    def step():
+        m.update_sites((t, y))
+        state["e"] = h.vdist.allreduce_sum_(m.classic_elbo((t, y)))
+
+    elapsed = h.run(step)
+    pl = m.dist_p.plan
+    pl.check_info()
+    e = float(state["e"])
+    assert np.isfinite(e), "non-finite ELBO"
+    out = h.line(elapsed, f"sparse / inducing-state CVI (SparseCVIGaussianProcess.update_sites + classic_elbo), Sum-of-Matern kernel d={d}, "
+                          f"{M} inducing states, {N} observations, one chain per GPU", "c5",
+                 {"trajectories_per_gpu": 1, "T": M, "d": d, "observations": N, "total_trajectories": h.world,
+                  "partition": {"levels": pl.nlevels, "segment_len": pl.R, "segments": pl.P}})
+    out["elbo_last"] = e
+    if h.rank == 0:
+        # level-0 reduce of the MFMA sweeps alone (mfgm_packed_factor_phase 0: the memset of the level-1 inputs + km_reduce)
+        lib = vidp_amd._lib.load()
+        lin, diag, sub = m._theta()
+        f = m._sweep_bufs["f"]
+
+        def reduce0():
+            assert lib.mfgm_packed_factor_phase(pl.h, 0, _ptr(diag), _ptr(sub), _ptr(lin), -2.0, -1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]),
+                                                _ptr(f["y"]), None, None, _ptr(pl.ws), _ptr(pl.info), _stream()) == 0
+        out["roofline"] = h.roofline("mfgm::km_reduce<1, true, false> (+ the memset of the level-1 inputs)",
+                                     "level 0 reduce of the MFMA sweeps (one wavefront per segment, 16 x 16 fp64 MFMA tiles); reads D, S, r",
+                                     h.timed(reduce0), 8 * (2 * d * d + d) * M, 1, out["ms_per_step"])
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_sparse(M, N)
+    return out
+
+
+def cpu_baseline_sparse(M, N, sample=300):
+    """The NumPy oracle of the same step (oracle/np_conditionals.SparseCVIGaussianProcess, one thread) on `sample` inducing points and
+    2 x sample observations, scaled linearly to M (the algorithm is O(M + N))."""
+    from oracle import np_conditionals as npc, np_kernels, np_models
+    rng = np.random.default_rng(5)
+    span = 0.01 * sample
+    z = np.linspace(0, span, sample)
+    t = np.sort(rng.uniform(0, span, size=2 * sample))
+    y = (np.sin(3 * t) + 0.1 * rng.normal(size=t.size))[:, None]
+    o = npc.SparseCVIGaussianProcess(sum16_kernel(np_kernels), z, np_models.GaussianLik(0.01), learning_rate=0.5)
+    o.update_sites(t, y)
+    o.classic_elbo(t, y)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.update_sites(t, y)
+        o.classic_elbo(t, y)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 5:
+            break
+    per = el / n * (M / sample)
+    return {"value": 1.0 / per, "unit": "ELBO steps/s", "cores": 1, "threads_used": 1, "kind": "port",
+            "sample": f"{n} steps of the NumPy oracle on {sample} inducing states / {2 * sample} observations ({el / n:.3f} s each), scaled "
+                      f"linearly to {M} / {N}"}
+
+
+OTHER_CONFIGS = {"c3": bench_vdp, "c2": bench_cvigp, "c5": bench_sparse}
 
 
 def main():

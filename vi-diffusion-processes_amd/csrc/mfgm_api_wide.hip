@@ -158,8 +158,8 @@ int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, cons
         MFGM_CHECK_LAUNCH();
     }
     if (sumlogchol) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, P.T, 0, sumlogchol, (double*)nullptr);
-        MFGM_CHECK_LAUNCH();
+        int rc = launch_sum_partials(part, P.T, 0, P.B, sumlogchol, nullptr, ws + P.off_part2, st);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -169,9 +169,7 @@ int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const dou
     double* part = ws + P.off_part[0];
     hipLaunchKernelGGL(kw_kl_terms, dim3(P.B * P.T), dim3(64), 0, st, P.B, P.T, P.d, Sig, Sub, mu, Pd, Ps, aD, aS, mup, part);
     MFGM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, P.T, P.B * P.T, trace, maha);
-    MFGM_CHECK_LAUNCH();
-    return 0;
+    return launch_sum_partials(part, P.T, P.B * P.T, P.B, trace, maha, ws + P.off_part2, st);
 }
 
 }  // namespace mfgm

@@ -39,6 +39,7 @@ struct Plan {
     size_t off_Dhat[kMaxLevels], off_Rsub[kMaxLevels], off_S[kMaxLevels], off_rhat[kMaxLevels], off_rho[kMaxLevels];
     size_t off_L[kMaxLevels], off_G[kMaxLevels], off_y[kMaxLevels], off_Sig[kMaxLevels], off_mu[kMaxLevels];
     size_t off_part[kMaxLevels];   // per-lane partial sums (2 * Lpad doubles), all levels incl. 0
+    size_t off_part2;              // second-stage scratch of the split partial sums (2 * B * 128 doubles)
     size_t ws_doubles;             // total workspace size in doubles
 };
 

@@ -81,7 +81,7 @@ static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, cons
         double qm = 0.0, qv = 0.0;
         if (lane < d2) {
             double u = 0.0;
-            for (int k = 0; k < d2; ++k) u += PC[lane * d2 + k] * w[k];
+            for (int k = 0; k < d2; ++k) u += PC[k * d2 + lane] * w[k];      // PC is symmetric: column access, consecutive lanes
             qv = w[lane] * u;
             qm = w[lane] * pm[lane];
         }

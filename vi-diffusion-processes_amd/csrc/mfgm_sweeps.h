@@ -657,4 +657,42 @@ static __global__ __launch_bounds__(256) void k_sum_partials(const double* part,
     }
 }
 
+// The same sum in two deterministic stages for long partial arrays (the wavefront-per-node local kernels of the wide path keep one
+// partial per node: 200 000 per chain at config 5): kSumSplit blocks per chain sum a contiguous slice each into scratch
+// [2][B * kSumSplit], then k_sum_partials adds those.
+constexpr int kSumSplit = 128;
+static __global__ __launch_bounds__(256) void k_sum_partials_split(const double* part, int P, int stride2, int has2, double* scratch) {
+    __shared__ double sh0[4], sh1[4];
+    const int g = blockIdx.x, b = blockIdx.y, B = gridDim.y;
+    const int slice = (P + kSumSplit - 1) / kSumSplit;
+    const int lo = g * slice, hi = min(P, lo + slice);
+    double s0 = 0.0, s1 = 0.0;
+    for (int p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+        s0 += part[(size_t)b * P + p];
+        if (has2) s1 += part[(size_t)stride2 + (size_t)b * P + p];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { sh0[threadIdx.x >> 6] = s0; sh1[threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[(size_t)b * kSumSplit + g] = sh0[0] + sh0[1] + sh0[2] + sh0[3];
+        scratch[(size_t)B * kSumSplit + (size_t)b * kSumSplit + g] = sh1[0] + sh1[1] + sh1[2] + sh1[3];
+    }
+}
+// host helper: out0[b] = sum_p part[b*P + p], out1[b] = sum_p part[stride2 + b*P + p]
+inline int launch_sum_partials(const double* part, int P, int stride2, int B, double* out0, double* out1, double* scratch, hipStream_t st) {
+    if (P >= 8192 && scratch) {
+        hipLaunchKernelGGL(k_sum_partials_split, dim3(kSumSplit, B), dim3(256), 0, st, part, P, stride2, out1 != nullptr, scratch);
+        if (hipGetLastError() != hipSuccess) return 3;
+        hipLaunchKernelGGL(k_sum_partials, dim3(B), dim3(256), 0, st, (const double*)scratch, kSumSplit, B * kSumSplit, out0, out1);
+    } else {
+        hipLaunchKernelGGL(k_sum_partials, dim3(B), dim3(256), 0, st, part, P, stride2, out0, out1);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 }  // namespace mfgm

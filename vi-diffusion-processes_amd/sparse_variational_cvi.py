@@ -154,13 +154,18 @@ class SparseCVIGaussianProcess:
         import ctypes
         from . import _lib
         from .packed import _ptr, _stream
+        c = getattr(self, "_pred_cache", None)
+        if c is not None and c[0] == self._version and c[1] is data:
+            return c[2]          # the sites have not moved since these were computed (the ELBO of the previous iteration)
         m = self._marginals()
         pl = self.dist_p.plan
         N = data["N"]
         out = torch.empty((2, N), dtype=torch.float64, device=pl.device)
         _lib.check(pl.lib.mfgm_sparse_predict(ctypes.byref(data["struct"]), _ptr(m["mu"]), _ptr(m["Sig"]), _ptr(m["Sub"]), _ptr(out[0]),
                                               _ptr(out[1]), _stream()), "mfgm_sparse_predict")
-        return out[0][:, None], out[1][:, None]
+        res = (out[0][:, None], out[1][:, None])
+        self._pred_cache = (self._version, data, res)
+        return res
 
     def update_sites(self, input_data):
         """theta_m <- (1 - rho) theta_m + rho g_m, g_m = data gradients projected through p(f_k | v_m) (sparse_variational_cvi.py:176-221)."""
