@@ -119,6 +119,19 @@ int mfgm_packed_ssm_to_naturals(const mfgm_plan* plan, const double* A, const do
                                 double cS, double* lin, double* diag, double* sub, double* sumlogchol, void* ws,
                                 void* stream);
 
+/* The per-step part of naturals_to_ssm_params (ssm_gaussian_transformations.py:459-511) in one pass over the selected inverse of
+ * the precision (-2 theta_diag, -theta_sub): packed marginals Sig (SYM), Sub (FULL: Sigma_{t+1,t} at node t), mu (VEC) and the packed
+ * naturals -> packed SSM parameters A (FULL at node t: t -> t+1), off (VEC: mu_0 then b_k), chol (TRI: chol P_0 then chol Q_k).
+ * d <= 8; a non-positive pivot sets *info. */
+int mfgm_packed_naturals_to_ssm(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* mu, const double* theta_diag,
+                                const double* theta_sub, double* A, double* off, double* chol, int* info, void* stream);
+
+/* Block-tri-diagonal matrix times vector on natural-layout arrays (BlockTriDiagonal.dense_mult, block_tri_diag.py:175-199 ->
+ * product_band_mat): diag [B, T, d, d], sub [B, T-1, d, d] or NULL, x / out [B, T, d] (out != x), any d.  symmetric != 0: the matrix is
+ * symmetric with the lower triangles of diag given; otherwise it is lower block-bidiagonal and transpose != 0 applies its transpose. */
+int mfgm_btd_matvec(int B, int T, int d, const double* diag, const double* sub, const double* x, double* out, int symmetric,
+                    int transpose, void* stream);
+
 /* Trace and Mahalanobis terms of KL(q || p) (state_space_model.py:557-593): q given by marginal blocks
  * Sig (SYM), Sub (FULL), mu (VEC); p by precision blocks aD*Pd (SYM), aS*Ps (FULL) and marginal means mup.
  * trace[B], maha[B]. */

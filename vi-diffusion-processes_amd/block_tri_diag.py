@@ -73,23 +73,20 @@ class BlockTriDiagonal:
     def dense_mult(self, right, transpose_left=False):
         """
         M x (or M^T x) for right [..., outer_dim, inner_dim] (block_tri_diag.py:175-199 -> product_band_mat).
-        Embarrassingly parallel in the outer dimension: batched block mat-vecs.
+        Embarrassingly parallel in the outer dimension: one HIP kernel (mfgm_btd_matvec), one thread per output element.
         """
         x, _ = _flat(right, 2)
         if tuple(x.shape) != (self.B, self.outer_dim, self.inner_dim):
             raise ValueError("dense_mult: incompatible right-hand side")
-        dg = self._diag
-        if self._symmetric:
-            low = torch.tril(dg)
-            dg = low + torch.tril(dg, -1).transpose(-1, -2)
-        lower = self._symmetric or not transpose_left
-        upper = self._symmetric or transpose_left
-        out = ((dg if not (transpose_left and not self._symmetric) else dg.transpose(-1, -2)) @ x[..., None])[..., 0]
-        if self._sub is not None:
-            if lower:
-                out[:, 1:] += (self._sub @ x[:, :-1, :, None])[..., 0]
-            if upper:
-                out[:, :-1] += (self._sub.transpose(-1, -2) @ x[:, 1:, :, None])[..., 0]
+        from . import _lib
+        from .packed import _ptr, _stream
+        lib = _lib.load()
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        dg = self._diag.contiguous()
+        sub = self._sub.contiguous() if self._sub is not None else None
+        _lib.check(lib.mfgm_btd_matvec(self.B, self.outer_dim, self.inner_dim, _ptr(dg), _ptr(sub), _ptr(x), _ptr(out),
+                                       1 if self._symmetric else 0, 1 if transpose_left else 0, _stream()), "mfgm_btd_matvec")
         return self._unflat(out)
 
 

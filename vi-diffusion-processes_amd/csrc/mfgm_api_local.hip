@@ -2,6 +2,7 @@
 #include "mfgm_internal.h"
 #include "mfgm_sweeps.h"
 #include "mfgm_local.h"
+#include "mfgm_nat2ssm.h"
 
 using namespace mfgm;
 
@@ -31,9 +32,36 @@ int kl_impl(const Plan& P, const double* Sig, const double* Sub, const double* m
     MFGM_CHECK_LAUNCH();
     return 0;
 }
+template <int D>
+int n2s_impl(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* td, const double* ts, double* A,
+             double* off, double* chol, int* info, hipStream_t st) {
+    const LevelDesc& lv = P.lv[0];
+    hipLaunchKernelGGL((k_naturals_to_ssm<D>), dim3(lv.Lpad / 64), dim3(64), 0, st, lv, Sig, Sub, mu, td, ts, A, off, chol, info);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
 }  // namespace
 
 extern "C" {
+
+int mfgm_packed_naturals_to_ssm(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* mu, const double* theta_diag,
+                                const double* theta_sub, double* A, double* off, double* chol, int* info, void* stream) {
+    if (!plan || !Sig || !Sub || !mu || !theta_diag || !theta_sub || !A || !off || !chol || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.wide) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (n2s_impl<DD>(P, Sig, Sub, mu, theta_diag, theta_sub, A, off, chol, info, st)));
+}
+
+int mfgm_btd_matvec(int B, int T, int d, const double* diag, const double* sub, const double* x, double* out, int symmetric,
+                    int transpose, void* stream) {
+    if (B < 1 || T < 1 || d < 1 || !diag || !x || !out || x == out) return 1;
+    const size_t total = (size_t)B * T * d;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(k_btd_matvec, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, T, d, diag, sub, x, out, symmetric, transpose);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
 
 int mfgm_packed_ssm_to_naturals(const mfgm_plan* plan, const double* A, const double* off, const double* chol, double cD,
                                 double cS, double* lin, double* diag, double* sub, double* sumlogchol, void* ws,

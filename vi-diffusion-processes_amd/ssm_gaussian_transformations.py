@@ -5,6 +5,8 @@ Host-side mirror of markovflow/ssm_gaussian_transformations.py: the six bijectio
 The sequential work (block Cholesky, selected inverse, solves) runs in the HIP sweeps; what is left per time
 step is independent d x d algebra on the selected-inverse blocks.
 """
+import os
+
 import torch
 
 from . import linalg
@@ -81,8 +83,22 @@ def naturals_to_ssm_params_packed(plan: Plan, lin, diag, sub):
     """theta (packed) -> StateSpaceModel sharing `plan`."""
     f = plan.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
     s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True)
-    plan.check_info()
     T = plan.T
+    if plan.d <= 8 and os.environ.get("VIDP_FUSED_NAT2SSM", "1") != "0":
+        # the per-step algebra in one pass over the packed selected inverse (mfgm_packed_naturals_to_ssm); the natural-layout
+        # parameter tensors are unpacked on first use
+        from . import _lib
+        from .packed import _ptr, _stream
+        from ._lib import TRI
+        A, off, chol = plan.empty(FULL), plan.empty(VEC), plan.empty(TRI)
+        _lib.check(plan.lib.mfgm_packed_naturals_to_ssm(plan.h, _ptr(s["Sig"]), _ptr(s["Sub"]), _ptr(s["x"]), _ptr(diag), _ptr(sub), _ptr(A),
+                                                        _ptr(off), _ptr(chol), _ptr(plan.info), _stream()), "mfgm_packed_naturals_to_ssm")
+        plan.check_info()
+        from .variational_cvi_sde import _ssm_from_packed
+        ssm = _ssm_from_packed(plan, A, off, chol)
+        ssm._post = dict(f=f, s=s)        # the marginals of this model are the ones it was built from
+        return ssm
+    plan.check_info()
     pd = -2.0 * plan.unpack(SYM, diag)
     ps = -plan.unpack(FULL, sub, T - 1)
     mu, cov, cov_sub = plan.unpack(VEC, s["x"]), plan.unpack(SYM, s["Sig"]), plan.unpack(FULL, s["Sub"], T - 1)
