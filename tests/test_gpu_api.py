@@ -511,8 +511,7 @@ def test_ssm_natgrad_one_step_optimum(amd, rng):
     SSMNaturalGradient(gamma=0.3, momentum=False).minimize(loss, q2)
     e1 = float(loss.elbo(q2))
     assert e0 < e1 < ref + 1e-6
-    with pytest.raises(NotImplementedError):
-        SSMNaturalGradient(gamma=0.1).minimize(lambda: 0.0, q2)
+    # (plain closures go through the tape route: test_ssm_natgrad_tape_route)
 
 
 def test_ssm_natgrad_momentum(amd, rng):
@@ -1357,3 +1356,83 @@ def test_kalman_filter_sites_fused_output_dim_2(amd, tag, bs):
     sm, sc = g["smooth_means"], np.broadcast_to(g["smooth_covs"], bs + g["smooth_covs"].shape)
     assert_close(host(Fmu), np.einsum("ai,...ti->...ta", g["H"], sm))
     assert_close(host(Fvar), np.einsum("ai,...tij,aj->...ta", g["H"], sc, g["H"]))
+
+
+def test_tape_gradients_through_the_sweeps(amd, rng):
+    """vidp_amd.tape: gradients of a non-linear function of the marginals, cross-covariances, log-determinant and KL of a TapeSSM with
+    respect to its parameters (through the theta -> eta sweeps, backward = Fisher-vector product) against central differences of
+    the same function evaluated without a tape."""
+    import torch
+    from vidp_amd import tape
+    from vidp_amd.state_space_model import StateSpaceModel
+    B, T, d = 2, 9, 3
+    prm = [dev(a) for a in random_ssm_params(rng, (B,), T, d)]
+    prior = StateSpaceModel(*[dev(a) for a in random_ssm_params(rng, (B,), T, d)])
+    w = dev(rng.normal(size=(T, d)))
+
+    def fn(q):
+        mu, cov = q.marginals
+        sub = q.subsequent_covariances()
+        return ((mu * w) ** 2).sum() + (cov * cov).sum() + torch.sin(sub).sum() + 0.3 * q.log_det_precision().sum() + q.kl_divergence(prior).sum()
+
+    def value(p):
+        mu0, cP0, A, b, cQ = p
+        with torch.no_grad():
+            return float(fn(tape.TapeSSM(mu0, cP0, A, b, cQ, plan=prior.plan)))
+
+    q = tape.TapeSSM(*[p.clone().requires_grad_(True) for p in prm], plan=prior.plan)
+    loss = fn(q)
+    grads = torch.autograd.grad(loss, [q.mu0, q.cholP0, q.A, q.b, q.cholQ])
+    gen = np.random.default_rng(5)
+    for k, (p, g) in enumerate(zip(prm, grads)):
+        g = host(g)
+        for _ in range(4):
+            idx = tuple(gen.integers(0, s) for s in p.shape)
+            if k in (1, 4) and idx[-1] > idx[-2]:
+                continue              # strictly upper entries of the Cholesky factors are not parameters
+            h = 1e-5
+            up, dn = [x.clone() for x in prm], [x.clone() for x in prm]
+            up[k][idx] += h
+            dn[k][idx] -= h
+            fd = (value(up) - value(dn)) / (2 * h)
+            np.testing.assert_allclose(g[idx], fd, rtol=1e-6, atol=1e-6 * max(1.0, abs(fd)))
+
+
+def test_ssm_natgrad_tape_route(amd, rng):
+    """KA9 through the tape route (ssm_natgrad.py:121-218 with a plain closure): one natural-gradient step with gamma = 1 and a
+    Gaussian likelihood makes the variational ELBO equal to the GPR log-likelihood, and the closure's d loss / d eta equals the
+    closed-form one of GaussMarkovELBO."""
+    import torch
+    from oracle import np_kernels
+    from vidp_amd import kernels as K, tape
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.ssm_natgrad import GaussMarkovELBO, SSMNaturalGradient
+    from vidp_amd.state_space_model import StateSpaceModel
+    T, noise = 10, 0.3
+    mk = lambda m: m.Sum([m.Matern32(1.1, 0.7), m.Matern12(0.5, 1.2)])
+    gk = mk(K)
+    d = gk.state_dim
+    t = np.sort(rng.uniform(0, 4, size=T))
+    y = np.cos(3 * t)[:, None] + 0.1 * rng.normal(size=(T, 1))
+    p = gk.state_space_model(dev(t))
+    em = gk.generate_emission_model(dev(t))
+    lik = Gaussian(noise)
+    q = StateSpaceModel(*[dev(a) for a in random_ssm_params(rng, (), T, d)], plan=p.plan)
+    H, yy = em.emission_matrix, dev(y)
+
+    def neg_elbo(qt):                                  # a plain closure: no grad_wrt_expectations
+        mu, cov = qt.marginals
+        fm = torch.einsum("toi,bti->bto", H, mu)
+        fv = torch.einsum("toi,btij,toj->bto", H, cov, H)
+        return -(lik.variational_expectations(fm, fv, yy).sum() - qt.kl_divergence(p).sum())
+
+    closed = GaussMarkovELBO(p, em, lik, yy)
+    _, (g1, g2, g3) = tape.natgrad_wrt_expectations(neg_elbo, q)
+    (cl, cd, cs), _ = closed.grad_wrt_expectations(q)
+    pl = q.plan
+    assert_close(host(g1), host(pl.unpack(amd.VEC, cl)), rtol=1e-7)
+    assert_close(host(g2), host(pl.unpack(amd.SYM, cd)), rtol=1e-7)
+    assert_close(host(g3), host(pl.unpack(amd.FULL, cs, T - 1)), rtol=1e-7)
+    SSMNaturalGradient(gamma=1.0, momentum=False).minimize(neg_elbo, q)
+    ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), noise)
+    np.testing.assert_allclose(float(closed.elbo(q)), ref, rtol=1e-6, atol=1e-5)

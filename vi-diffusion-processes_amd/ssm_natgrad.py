@@ -3,11 +3,12 @@ Host-side mirror of markovflow/ssm_natgrad.py (`SSMNaturalGradient`, ssm_natgrad
 `StateSpaceModel` q,  theta <- theta - gamma dL/d eta,  followed by naturals_to_ssm_params (HIP sweeps).
 
 The reference obtains dL/d eta from a persistent GradientTape through the loss and `expectations_to_ssm_params`
-(ssm_natgrad.py:142-172), which needs gradients *through* the banded Cholesky / sparse inverse.  Differentiated sweeps are
-not built yet; instead the loss object supplies dL/d eta itself (`grad_wrt_expectations`), which is available in closed form
-for the losses on the path: the ELBO of a Gauss-Markov q is  sum_t VE_t(mu_t, Sigma_tt) - KL[q || p]  with
-d KL / d eta = theta_q - theta_p.  `GaussMarkovELBO` below is that loss (the `VariationalGaussianProcess.elbo` of the reference,
-models/variational.py:129-152).
+(ssm_natgrad.py:142-172), which needs gradients *through* the banded Cholesky / sparse inverse.  Two routes here:
+  * a loss object that supplies dL/d eta itself (`grad_wrt_expectations`), available in closed form for the losses on the path: the
+    ELBO of a Gauss-Markov q is  sum_t VE_t(mu_t, Sigma_tt) - KL[q || p]  with d KL / d eta = theta_q - theta_p.  `GaussMarkovELBO`
+    below is that loss (the `VariationalGaussianProcess.elbo` of the reference, models/variational.py:129-152);
+  * any closure `loss_fn(q)` of a differentiable view q of the model (`vidp_amd.tape.TapeSSM`): torch autograd with the sweeps as a
+    custom Function whose backward is the Fisher-vector product (vidp_amd/tape.py) -- the tape route of the reference.
 
 The Adam-like momentum variant (ssm_natgrad.py:36-58, 177-208; the reference's default) keeps moving averages m of the natural
 gradient g = dL/d eta and v of its squared norm in the Fisher metric, <g, dL/d theta> = g^T (d eta / d theta) g.  The reference
@@ -77,12 +78,17 @@ class SSMNaturalGradient:
 
     def _natgrad_step(self, loss_fn, ssm: StateSpaceModel):
         """theta <- theta - gamma dL/d eta, then back to SSM parameters (ssm_natgrad.py:121-218)."""
-        if not hasattr(loss_fn, "grad_wrt_expectations"):
-            raise NotImplementedError(
-                "SSMNaturalGradient needs a loss object with grad_wrt_expectations(ssm): gradients through the block-tri-diagonal "
-                "sweeps (the reference's GradientTape through banded ops) are not implemented")
         pl = ssm.plan
-        (gl, gd, gs), nq = loss_fn.grad_wrt_expectations(ssm)
+        if hasattr(loss_fn, "grad_wrt_expectations"):
+            (gl, gd, gs), nq = loss_fn.grad_wrt_expectations(ssm)         # closed form for the losses on the path
+        else:
+            # an arbitrary closure loss_fn(q) of a differentiable view q of the model (vidp_amd.tape.TapeSSM): the reference's
+            # persistent-tape route (ssm_natgrad.py:142-172), gradients through the sweeps included
+            from . import tape
+            _, (g1, g2, g3) = tape.natgrad_wrt_expectations(loss_fn, ssm)
+            gl, gd = pl.pack(VEC, g1.contiguous()), pl.pack(SYM, g2.contiguous())
+            gs = pl.pack(FULL, g3.contiguous()) if ssm.T > 1 else pl.zeros(FULL)
+            nq = pl.ssm_to_naturals(ssm.packed.A, ssm.packed.off, ssm.packed.chol)
         step, dl, dd, ds = self.gamma, gl, gd, gs
         if self._momentum:
             # ssm_natgrad.py:177-208

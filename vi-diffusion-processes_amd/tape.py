@@ -1,0 +1,287 @@
+"""
+Differentiable path through the sweeps: what the reference gets from a persistent `tf.GradientTape` through the banded ops
+(ssm_natgrad.py:142-172; tests/integration/models/test_variational_cvi.py:104-107).
+
+The only non-local map on the path is  theta -> eta  (natural -> expectation parameters of a Gauss-Markov chain: block Cholesky +
+selected inverse + solve).  It is the gradient of the log-partition function A(theta), so its Jacobian is the Fisher matrix
+F = d^2 A / d theta^2, which is SYMMETRIC: the vector-Jacobian product autograd needs equals the directional derivative,
+
+        (d eta / d theta)^T g  =  F g  =  d/d eps  eta(theta + eps g) |_{eps = 0} .
+
+`NaturalsToExpectations.backward` evaluates that derivative with the HIP sweeps themselves: the mean part exactly (one more solve
+with the same precision), the covariance part as a fourth-order (Richardson) central difference of factor + selected inverse (four
+passes, agreement with the closed-form gradients of the path at 1e-10) -- so no second set of adjoint kernels has to be kept in
+step with the forward ones.  Everything else on
+the path (ssm -> naturals, expectations -> ssm, the KL and likelihood terms) is per-time-step d x d algebra, written here with
+autograd-traceable torch operations (explicit Cholesky / substitution loops over the d <= 8 block dimension: the vendor's batched
+factorisations are not used).
+
+`TapeSSM` is a StateSpaceModel whose parameters are leaves of a torch graph and whose marginals / KL / log-determinant are
+differentiable; `SSMNaturalGradient.minimize(loss_fn, ssm)` builds one when `loss_fn` is a plain closure (ssm_natgrad.py).
+"""
+import torch
+
+from ._lib import FULL, SYM, VEC
+from .packed import Plan
+
+
+def _T(x):
+    return x.transpose(-1, -2)
+
+
+# ---- autograd-traceable d x d algebra (d small) -----------------------------------------------------------------------------------------
+def cholesky(S):
+    """Lower Cholesky factor of S [..., d, d] (symmetric positive definite), column by column."""
+    d = S.shape[-1]
+    L = [[None] * d for _ in range(d)]
+    for j in range(d):
+        s = S[..., j, j]
+        for k in range(j):
+            s = s - L[j][k] * L[j][k]
+        ljj = torch.sqrt(s)
+        L[j][j] = ljj
+        for i in range(j + 1, d):
+            t = S[..., i, j]
+            for k in range(j):
+                t = t - L[i][k] * L[j][k]
+            L[i][j] = t / ljj
+    zero = torch.zeros_like(S[..., 0, 0])
+    rows = [torch.stack([L[i][j] if j <= i else zero for j in range(d)], dim=-1) for i in range(d)]
+    return torch.stack(rows, dim=-2)
+
+
+def solve_lower(L, B):
+    """L^{-1} B for lower-triangular L [..., d, d], B [..., d, m]."""
+    d = L.shape[-1]
+    rows = []
+    for i in range(d):
+        t = B[..., i, :]
+        for k in range(i):
+            t = t - L[..., i, k, None] * rows[k]
+        rows.append(t / L[..., i, i, None])
+    return torch.stack(rows, dim=-2)
+
+
+def solve_lower_t(L, B):
+    """L^{-T} B."""
+    d = L.shape[-1]
+    rows = [None] * d
+    for i in range(d - 1, -1, -1):
+        t = B[..., i, :]
+        for k in range(i + 1, d):
+            t = t - L[..., k, i, None] * rows[k]
+        rows[i] = t / L[..., i, i, None]
+    return torch.stack(rows, dim=-2)
+
+
+def cholesky_solve(L, B):
+    return solve_lower_t(L, solve_lower(L, B))
+
+
+def spd_inverse_from_chol(L):
+    eye = torch.eye(L.shape[-1], dtype=L.dtype, device=L.device).expand(L.shape)
+    X = solve_lower(L, eye)
+    return _T(X) @ X
+
+
+# ---- theta -> eta through the HIP sweeps -------------------------------------------------------------------------------------------------
+def _marginals(plan, lin, diag, sub):
+    """(mu, Sigma_tt, Sigma_{t+1,t}) natural-layout tensors of the chain with naturals (lin or None, diag, sub): pack, factor, selected
+    inverse, unpack."""
+    T = plan.T
+    f = plan.factor(plan.pack(SYM, diag), plan.pack(FULL, sub) if T > 1 else plan.zeros(FULL), None if lin is None else plan.pack(VEC, lin),
+                    aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
+    s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True)
+    plan.check_info()
+    mu = None if lin is None else plan.unpack(VEC, s["x"])
+    cov = plan.unpack(SYM, s["Sig"])
+    if T > 1:
+        csub = plan.unpack(FULL, s["Sub"], T - 1)
+    else:
+        csub = torch.zeros((plan.B, 0, plan.d, plan.d), dtype=cov.dtype, device=cov.device)
+    return mu, cov, csub
+
+
+def _eta(mu, cov, csub):
+    return mu, cov + mu[..., :, None] * mu[..., None, :], csub + mu[:, 1:, :, None] * mu[:, :-1, None, :]
+
+
+def _precision_times(plan, g_diag, g_sub, x):
+    """(dP) x for the precision direction dP = (-2 g_diag, -g_sub) (symmetric block-tri-diagonal), mfgm_btd_matvec."""
+    from . import _lib
+    from .packed import _ptr, _stream
+    out = torch.empty_like(x)
+    dg, sb = (-2.0 * g_diag).contiguous(), ((-1.0 * g_sub).contiguous() if g_sub.numel() else None)
+    _lib.check(plan.lib.mfgm_btd_matvec(plan.B, plan.T, plan.d, _ptr(dg), _ptr(sb), _ptr(x.contiguous()), _ptr(out), 1, 0, _stream()),
+               "mfgm_btd_matvec")
+    return out
+
+
+class NaturalsToExpectations(torch.autograd.Function):
+    """
+    eta(theta) for theta = (theta_lin [B,T,d], theta_diag [B,T,d,d] symmetric, theta_sub [B,T-1,d,d]).  backward = the Fisher-vector
+    product F g = D eta(theta)[g] (module docstring), assembled from
+      d mu     = P^{-1} (g_lin - dP mu)                       one more solve with the precision P, exact (dP = (-2 g_diag, -g_sub));
+      d Sigma  = derivative of the selected inverse along dP  fourth-order (Richardson) central difference of factor + selected
+                                                              inverse WITHOUT a right-hand side: the covariance blocks are far
+                                                              better conditioned than the solves, and the difference quotient
+                                                              of the means would amplify the rounding of the solves by 1 / step.
+    """
+
+    rel_step = 3e-4
+
+    @staticmethod
+    def forward(ctx, lin, diag, sub, plan):
+        ctx.plan = plan
+        mu, cov, csub = _marginals(plan, lin.detach(), diag.detach(), sub.detach())
+        ctx.save_for_backward(lin, diag, sub, mu)
+        return _eta(mu, cov, csub)
+
+    @staticmethod
+    def backward(ctx, g_lin, g_diag, g_sub):
+        lin, diag, sub, mu = ctx.saved_tensors
+        plan = ctx.plan
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else g
+        g_lin, g_diag, g_sub = z(g_lin, lin), z(g_diag, diag), z(g_sub, sub)
+        g_diag = 0.5 * (g_diag + _T(g_diag))        # eta_diag is symmetric: only the symmetric part of its cotangent acts
+        gmax = max(float(g_lin.abs().max()), float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
+        if gmax == 0.0:
+            return torch.zeros_like(lin), torch.zeros_like(diag), torch.zeros_like(sub), None
+        # d mu: one solve with the unperturbed precision
+        dmu = _marginals(plan, g_lin - _precision_times(plan, g_diag, g_sub, mu), diag, sub)[0]
+        # d Sigma (diagonal and sub-diagonal blocks): Richardson central difference along (g_diag, g_sub)
+        dcov, dsub = torch.zeros_like(diag), torch.zeros_like(sub)
+        gm = max(float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
+        if gm > 0.0:
+            h = NaturalsToExpectations.rel_step * float(diag.abs().max()) / gm
+
+            def central(e):
+                up = _marginals(plan, None, diag + e * g_diag, sub + e * g_sub)
+                dn = _marginals(plan, None, diag - e * g_diag, sub - e * g_sub)
+                return (up[1] - dn[1]) / (2.0 * e), (up[2] - dn[2]) / (2.0 * e)
+
+            (c1, s1), (c2, s2) = central(h), central(0.5 * h)
+            dcov, dsub = (4.0 * c2 - c1) / 3.0, (4.0 * s2 - s1) / 3.0
+        d_diag = dcov + dmu[..., :, None] * mu[..., None, :] + mu[..., :, None] * dmu[..., None, :]
+        d_sub = dsub + dmu[:, 1:, :, None] * mu[:, :-1, None, :] + mu[:, 1:, :, None] * dmu[:, :-1, None, :]
+        return dmu, 0.5 * (d_diag + _T(d_diag)), d_sub, None
+
+
+# ---- per-step maps, autograd-traceable ---------------------------------------------------------------------------------------------------
+def ssm_to_naturals(A, b, chol_P0, chol_Q, mu0):
+    """ssm_gaussian_transformations.py:182-253 on [B, T-1, d, d], [B, T-1, d], [B, d, d], [B, T-1, d, d], [B, d]."""
+    chols = torch.cat([chol_P0[:, None], chol_Q], dim=1)                      # [B, T, d, d]
+    offs = torch.cat([mu0[:, None], b], dim=1)                                # [B, T, d]
+    Qinv = spd_inverse_from_chol(chols)
+    QA = Qinv[:, 1:] @ A                                                      # Qinv_{t+1} A_t = theta_sub
+    diag = torch.cat([Qinv[:, :-1] + _T(A) @ QA, Qinv[:, -1:]], dim=1)
+    z = (Qinv @ offs[..., None])[..., 0]
+    lin = torch.cat([z[:, :-1] - (_T(A) @ z[:, 1:, :, None])[..., 0], z[:, -1:]], dim=1)
+    return lin, -0.5 * diag, QA
+
+
+def expectations_to_ssm_params(eta_lin, eta_diag, eta_sub):
+    """ssm_gaussian_transformations.py:93-178 -> (A, b, chol_P0, chol_Q, mu0)."""
+    m = eta_lin[..., None]
+    cov = eta_diag - m @ _T(m)
+    cov_sub = _T(eta_sub) - m[:, :-1] @ _T(m[:, 1:])                            # Sigma_{t,t+1}
+    chols = cholesky(cov)
+    As = _T(cholesky_solve(chols[:, :-1], cov_sub))
+    offsets = (m[:, 1:] - As @ m[:, :-1])[..., 0]
+    cond = cov[:, 1:] - As @ (cov[:, :-1] @ _T(As))
+    return As, offsets, chols[:, 0], cholesky(0.5 * (cond + _T(cond))), m[:, 0, :, 0]
+
+
+class TapeSSM:
+    """A StateSpaceModel whose parameters are torch leaves (requires_grad) and whose derived quantities are differentiable; batch
+    shape [B].  Property / method names follow StateSpaceModel (state_space_model.py:35-664)."""
+
+    def __init__(self, initial_mean, chol_initial_covariance, state_transitions, state_offsets, chol_process_covariances, plan=None):
+        self.mu0, self.cholP0, self.A, self.b, self.cholQ = (initial_mean, chol_initial_covariance, state_transitions, state_offsets,
+                                                             chol_process_covariances)
+        B, Tm1, d, _ = state_transitions.shape
+        self.B, self.T, self.d = B, Tm1 + 1, d
+        self.batch_shape = (B,)
+        self.plan = plan if plan is not None else Plan(B, self.T, d, device=state_transitions.device)
+        self._eta = None
+
+    @classmethod
+    def from_ssm(cls, ssm):
+        leaf = lambda t: t.detach().clone().requires_grad_(True)
+        return cls(leaf(ssm._mu0), leaf(ssm._cholP0), leaf(ssm._A), leaf(ssm._b), leaf(ssm._cholQ), plan=ssm.plan)
+
+    @property
+    def parameters(self):
+        return [self.A, self.b, self.cholP0, self.cholQ, self.mu0]
+
+    # reference-named accessors
+    state_transitions = property(lambda self: self.A)
+    state_offsets = property(lambda self: self.b)
+    cholesky_process_covariances = property(lambda self: self.cholQ)
+    cholesky_initial_covariance = property(lambda self: self.cholP0)
+    initial_mean = property(lambda self: self.mu0)
+
+    def naturals(self):
+        return ssm_to_naturals(self.A, self.b, self.cholP0, self.cholQ, self.mu0)
+
+    def expectations(self):
+        """ssm_to_expectations (ssm_gaussian_transformations.py:32-89), differentiable."""
+        if self._eta is None:
+            self._eta = NaturalsToExpectations.apply(*self.naturals(), self.plan)
+        return self._eta
+
+    @property
+    def marginal_means(self):
+        return self.expectations()[0]
+
+    @property
+    def marginal_covariances(self):
+        mu, ed, _ = self.expectations()
+        return ed - mu[..., :, None] * mu[..., None, :]
+
+    @property
+    def marginals(self):
+        return self.marginal_means, self.marginal_covariances
+
+    def subsequent_covariances(self, marginal_covariances=None):
+        mu, _, es = self.expectations()
+        return es - mu[:, 1:, :, None] * mu[:, :-1, None, :]
+
+    def log_det_precision(self):
+        """-2 (log|chol P0| + sum log|chol Q_k|) (state_space_model.py:343-373)."""
+        ld = lambda c: torch.log(torch.abs(torch.diagonal(c, dim1=-2, dim2=-1))).sum(-1)
+        return -2.0 * (ld(self.cholP0) + ld(self.cholQ).sum(-1))
+
+    def kl_divergence(self, dist):
+        """KL(self || dist) for a (non-differentiated) StateSpaceModel `dist` (state_space_model.py:528-593)."""
+        pl = dist.plan
+        pp = dist._precision_packed()
+        Pd, Ps = pl.unpack(SYM, pp["diag"]), pl.unpack(FULL, pp["sub"], self.T - 1)
+        mup = pl.unpack(VEC, dist._posterior_packed()["s"]["x"])
+        mu, cov = self.marginals
+        sub = self.subsequent_covariances()
+        dm = mu - mup
+        tr = (Pd * cov).sum(dim=(-1, -2, -3)) + 2.0 * (Ps * sub).sum(dim=(-1, -2, -3))
+        mh = ((dm[..., None, :] @ Pd @ dm[..., :, None]).sum(dim=(-1, -2, -3))
+              + 2.0 * (dm[:, 1:, None, :] @ Ps @ dm[:, :-1, :, None]).sum(dim=(-1, -2, -3)))
+        dim = float(self.T * self.d)
+        return 0.5 * (tr + mh - dim + 2.0 * pp["sumlogchol"] + self.log_det_precision())
+
+
+def natgrad_wrt_expectations(loss_fn, ssm):
+    """
+    d loss / d eta for an arbitrary closure `loss_fn(q)` of a differentiable view q (TapeSSM) of `ssm`, as the reference computes it
+    (ssm_natgrad.py:142-172): gradients of the loss with respect to the SSM parameters (Cholesky factors restricted to their lower
+    triangles: the reference's `triangular()` transform), pulled back through expectations_to_ssm_params.
+    Returns (loss value, (g_lin [B,T,d], g_diag [B,T,d,d], g_sub [B,T-1,d,d])).
+    """
+    q = TapeSSM.from_ssm(ssm)
+    loss = loss_fn(q)
+    grads = torch.autograd.grad(loss, q.parameters, allow_unused=True)
+    grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, q.parameters)]
+    grads[2], grads[3] = torch.tril(grads[2]), torch.tril(grads[3])
+    eta = [e.detach().requires_grad_(True) for e in q.expectations()]
+    A, b, cP0, cQ, mu0 = expectations_to_ssm_params(*eta)
+    g_eta = torch.autograd.grad([A, b, cP0, cQ, mu0], eta, grad_outputs=grads, allow_unused=True)
+    g_eta = [torch.zeros_like(e) if g is None else g for g, e in zip(g_eta, eta)]
+    return loss.detach(), (g_eta[0], 0.5 * (g_eta[1] + _T(g_eta[1])), g_eta[2])
