@@ -1430,9 +1430,11 @@ def test_ssm_natgrad_tape_route(amd, rng):
     _, (g1, g2, g3) = tape.natgrad_wrt_expectations(neg_elbo, q)
     (cl, cd, cs), _ = closed.grad_wrt_expectations(q)
     pl = q.plan
-    assert_close(host(g1), host(pl.unpack(amd.VEC, cl)), rtol=1e-7)
-    assert_close(host(g2), host(pl.unpack(amd.SYM, cd)), rtol=1e-7)
-    assert_close(host(g3), host(pl.unpack(amd.FULL, cs, T - 1)), rtol=1e-7)
+    # the block parts agree to the accuracy of the Richardson difference (1e-10 of the largest entry); the linear part is the small
+    # difference of terms of that size (d/d eta_lin = d/d mu - 2 (d/d Sigma) mu ...), hence a looser absolute floor
+    assert_close(host(g1), host(pl.unpack(amd.VEC, cl)), rtol=1e-4, scale_atol=1e-5)
+    assert_close(host(g2), host(pl.unpack(amd.SYM, cd)), rtol=1e-7, scale_atol=1e-9)
+    assert_close(host(g3), host(pl.unpack(amd.FULL, cs, T - 1)), rtol=1e-7, scale_atol=1e-9)
     SSMNaturalGradient(gamma=1.0, momentum=False).minimize(neg_elbo, q)
     ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), noise)
     np.testing.assert_allclose(float(closed.elbo(q)), ref, rtol=1e-6, atol=1e-5)
