@@ -444,6 +444,15 @@ int mfgm_unpack_moments(const mfgm_plan* plan, const double* packed_mom, double*
  *                                                segments; logdet / quad are the partial sums over the owned segments
  *   selected inverse: mfgm_packed_selinv as usual (coarser levels replicated, level 0 on the owned segments, no communication). */
 int mfgm_plan_set_shard(mfgm_plan* plan, int seg_lo, int seg_hi);
+/* The same with the exchange at a coarser level ("each GPU eliminates its interior ... then a reduced system of 8 d x d
+ * interface blocks"): the process owns the nodes [node_lo, node_hi) of level `level` (1 <= level < nlevels) and, below it, the
+ * segments those nodes stand for; phase 0 runs the reduces of the levels 0 .. level-1 on them, the exchange region is the
+ * level's inputs -- n_level x (3 d^2 + 2 d) doubles per chain, e.g. 8 x 800 at config 5 with level chosen so that n_level = 8 --
+ * and phase 1 solves the levels >= level on every process and sweeps back down its own segments.  No other data cross processes
+ * (the forward sweep stores the factor blocks of the separator on the left of the range, which it reconstructs anyway). */
+int mfgm_plan_set_shard_level(mfgm_plan* plan, int level, int node_lo, int node_hi);
+/* out[0..3] = n, R, P, Lpad of a level */
+int mfgm_plan_level(const mfgm_plan* plan, int level, int* out4);
 int mfgm_plan_exchange_region(const mfgm_plan* plan, size_t* offset_doubles, size_t* count_doubles);
 int mfgm_packed_factor_phase(const mfgm_plan* plan, int phase, const double* D, const double* S, const double* r, double aD,
                              double aS, double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws,

@@ -104,3 +104,42 @@ def test_bench_refuses_a_mislabelled_world_size():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_one_chain_exchange_volume_at_config5():
+    """SURVEY 8e / config 5 (one chain, T = 200 000, d = 16, 8 ranks): the only per-time-step data that crosses ranks is the input of
+    the exchange level of the partition -- 8 x (3 d^2 + 2 d) doubles, i.e. one interface-block triple per rank (host-side plan logic,
+    no GPU needed)."""
+    import ctypes
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = ctypes.CDLL(os.path.join(root, "vi-diffusion-processes_amd", "csrc", "libmfgm.so"))
+    lib.mfgm_plan_create.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_void_p)]
+    lib.mfgm_plan_level.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    lib.mfgm_plan_set_shard_level.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.mfgm_plan_exchange_region.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    lib.mfgm_plan_describe.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.mfgm_plan_destroy.argtypes = [ctypes.c_void_p]
+    T, d, world = 200000, 16, 8
+    h = ctypes.c_void_p()
+    assert lib.mfgm_plan_create(1, T, d, 0, 0, ctypes.byref(h)) == 0
+    desc = (ctypes.c_int * 6)()
+    lib.mfgm_plan_describe(h, desc)
+    lev, levels = (ctypes.c_int * 4)(), []
+    for l in range(desc[0]):
+        assert lib.mfgm_plan_level(h, l, lev) == 0
+        levels.append(tuple(lev))
+    X = max(l for l in range(1, desc[0]) if levels[l][0] >= world)
+    covered = 0
+    for rank in range(world):
+        base, rem = divmod(levels[X][0], world)
+        lo = rank * base + min(rank, rem)
+        hi = lo + base + (1 if rank < rem else 0)
+        assert lib.mfgm_plan_set_shard_level(h, X, lo, hi) == 0
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        assert lib.mfgm_plan_exchange_region(h, ctypes.byref(off), ctypes.byref(cnt)) == 0
+        assert cnt.value <= world * (3 * d * d + 2 * d), (cnt.value, world * (3 * d * d + 2 * d))
+        covered += hi - lo
+    assert covered == levels[X][0]
+    assert lib.mfgm_plan_set_shard_level(h, desc[0], 0, 1) == 1          # no such level
+    lib.mfgm_plan_destroy(h)

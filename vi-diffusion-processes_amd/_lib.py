@@ -85,6 +85,8 @@ EXPORTS = {
     "mfgm_packed_kl_terms": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
     "mfgm_unpack_moments": (ctypes.c_int, [ctypes.c_void_p] * 4),
     "mfgm_plan_set_shard": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mfgm_plan_set_shard_level": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mfgm_plan_level": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "mfgm_plan_exchange_region": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "mfgm_packed_factor_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_double] * 3
                                  + [ctypes.c_void_p] * 8),

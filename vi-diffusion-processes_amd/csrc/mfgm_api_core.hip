@@ -72,7 +72,7 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
     // per-segment partial sums (narrow: also the d-vector hand-over of the fused Girsanov sweep); the wide local kernels keep one
     // partial per node
     P.off_part[0] = take(P.wide ? 2 * std::max<size_t>(P.lv[0].Lpad, (size_t)B * T) : (size_t)std::max(2, d) * P.lv[0].Lpad);
-    P.off_part2 = take((size_t)2 * B * 128);
+    P.off_part2 = take(std::max((size_t)2 * B * 128, (size_t)B * (d * d + d)));    // also: the saved boundary correction of a sharded chain
     for (int i = 1; i < P.nlevels; ++i) {
         const LevelDesc& lv = P.lv[i];
         P.off_Dhat[i] = take(level_elems(P, lv, 2));
@@ -93,21 +93,47 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
 
 void mfgm_plan_destroy(mfgm_plan* plan) { delete plan; }
 
-int mfgm_plan_set_shard(mfgm_plan* plan, int seg_lo, int seg_hi) {
+int mfgm_plan_set_shard_level(mfgm_plan* plan, int level, int node_lo, int node_hi) {
     if (!plan) return 1;
     Plan& P = plan->p;
-    if (!P.wide || P.nlevels < 2 || seg_lo < 0 || seg_hi > P.lv[0].P || seg_lo >= seg_hi) return 1;
-    P.seg_lo = seg_lo;
-    P.seg_hi = seg_hi;
+    if (!P.wide || level < 1 || level >= P.nlevels || node_lo < 0 || node_hi > P.lv[level].n || node_lo >= node_hi) return 1;
+    P.shard_level = level;
+    // the nodes [node_lo, node_hi) of level `level` are the segments [node_lo, node_hi) of level `level - 1`; going down, the segments
+    // of level l-1 inside the segments [lo, hi) of level l are [lo * R_l, min(hi * R_l, P_{l-1}))
+    int lo = node_lo, hi = node_hi;
+    for (int l = level - 1; l >= 0; --l) {
+        P.own_lo[l] = lo;
+        P.own_hi[l] = hi;
+        if (l > 0) {
+            lo = lo * P.lv[l].R;
+            hi = std::min(hi * P.lv[l].R, P.lv[l - 1].P);
+        }
+    }
+    for (int l = level; l < P.nlevels; ++l) { P.own_lo[l] = 0; P.own_hi[l] = P.lv[l].P; }
+    P.seg_lo = P.own_lo[0];
+    P.seg_hi = P.own_hi[0];
     return 0;
+}
+
+int mfgm_plan_set_shard(mfgm_plan* plan, int seg_lo, int seg_hi) {
+    // level-0 segments [seg_lo, seg_hi) = nodes of level 1: the exchange happens at level 1
+    return mfgm_plan_set_shard_level(plan, 1, seg_lo, seg_hi);
 }
 
 int mfgm_plan_exchange_region(const mfgm_plan* plan, size_t* offset_doubles, size_t* count_doubles) {
     if (!plan || !offset_doubles || !count_doubles) return 1;
     const Plan& P = plan->p;
     if (P.nlevels < 2) return 1;
-    *offset_doubles = P.off_Dhat[1];
-    *count_doubles = P.off_L[1] - P.off_Dhat[1];
+    const int l = P.shard_level > 0 ? P.shard_level : 1;
+    *offset_doubles = P.off_Dhat[l];
+    *count_doubles = P.off_L[l] - P.off_Dhat[l];
+    return 0;
+}
+
+int mfgm_plan_level(const mfgm_plan* plan, int level, int* out4) {
+    if (!plan || !out4 || level < 0 || level >= plan->p.nlevels) return 1;
+    const LevelDesc& lv = plan->p.lv[level];
+    out4[0] = lv.n; out4[1] = lv.R; out4[2] = lv.P; out4[3] = lv.Lpad;
     return 0;
 }
 

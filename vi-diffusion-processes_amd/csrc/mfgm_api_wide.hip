@@ -53,8 +53,10 @@ void wide_bind(const Plan& P, int l, double* ws, WideArgs& a) {
     const int K = P.nlevels - 1;
     a.lv = P.lv[l];
     a.d = P.d;
-    a.seg_lo = (l == 0) ? P.seg_lo : 0;
-    a.nseg = (l == 0) ? P.seg_hi - P.seg_lo : P.lv[l].P;
+    const bool below = (P.shard_level > 0 && l < P.shard_level);      // a sharded chain works on its own segments below the exchange level
+    a.seg_lo = below ? P.own_lo[l] : 0;
+    a.nseg = below ? P.own_hi[l] - P.own_lo[l] : P.lv[l].P;
+    a.store_left = below ? 1 : 0;
     if (l > 0) {
         a.Dg = ws + P.off_Dhat[l]; a.Dcorr = ws + P.off_Rsub[l]; a.Sg = ws + P.off_S[l];
         a.rg = ws + P.off_rhat[l]; a.rcorr = ws + P.off_rho[l];
@@ -74,15 +76,54 @@ void wide_bind(const Plan& P, int l, double* ws, WideArgs& a) {
 
 namespace mfgm {
 
-// phase -1: the whole factorisation (plans that own every segment);  phase 0: zero the level-1 inputs and run the level-0
-// reduce on the owned segments (a sharded chain then sums the level-1 inputs over the processes);  phase 1: everything after.
+// carry-up of a sharded chain: the Gram corrections (Rsub, rho) this process produced, at the levels below the exchange level, for
+// the separator on the left of its range belong to a node of the neighbouring process, which never sees them; that node is a
+// separator at every level up to the exchange level, where its diagonal block only ever receives additive terms, so they are
+// added to the exchange level's own correction of that node (one d x d block and one d-vector per level and chain).
+struct CarryArgs {
+    int nlev;                       // level slots 0 .. nlev-1 are the levels 1 .. exchange level; the last one receives the sums
+    int nn[kMaxLevels], qq[kMaxLevels];
+    double* Rsub[kMaxLevels];
+    double* rho[kMaxLevels];
+};
+// save [B][EF + d]: the exchange level's own correction of that node before the sums went in; the forward sweep below the exchange
+// level reconstructs its boundary state from exactly that (F_a = Ltil Ltil^T + R), so k_carry_restore puts it back once the levels
+// from the exchange level up are factorised.
+static __global__ void k_carry_up(int d, CarryArgs c, double* __restrict__ save) {
+    const int b = blockIdx.x, EF = d * d, top = c.nlev - 1;
+    for (int k = threadIdx.x; k < EF + d; k += blockDim.x) {
+        double acc = 0.0;
+        for (int j = 0; j < top; ++j) {
+            acc += (k < EF) ? c.Rsub[j][((size_t)b * c.nn[j] + c.qq[j]) * EF + k] : c.rho[j][((size_t)b * c.nn[j] + c.qq[j]) * d + (k - EF)];
+        }
+        double* dst = (k < EF) ? &c.Rsub[top][((size_t)b * c.nn[top] + c.qq[top]) * EF + k]
+                               : &c.rho[top][((size_t)b * c.nn[top] + c.qq[top]) * d + (k - EF)];
+        save[(size_t)b * (EF + d) + k] = *dst;
+        *dst += acc;
+    }
+}
+static __global__ void k_carry_restore(int d, int n, int q, double* __restrict__ Rsub, double* __restrict__ rho,
+                                       const double* __restrict__ save) {
+    const int b = blockIdx.x, EF = d * d;
+    for (int k = threadIdx.x; k < EF + d; k += blockDim.x) {
+        const double v = save[(size_t)b * (EF + d) + k];
+        if (k < EF) Rsub[((size_t)b * n + q) * EF + k] = v;
+        else rho[((size_t)b * n + q) * d + (k - EF)] = v;
+    }
+}
+
+// phase -1: the whole factorisation (plans that own every segment);  phase 0: zero the inputs of the levels 1 .. exchange level,
+// run the reduces below the exchange level on the owned segments and carry the boundary corrections up (a sharded chain then sums
+// the exchange level's inputs over the processes);  phase 1: everything after.
 int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st,
                 int phase) {
     const bool has_rhs = (rg != nullptr);
     const int K = P.nlevels - 1;
-    const bool sharded = (P.seg_lo != 0 || P.seg_hi != P.lv[0].P);
+    const bool sharded = (P.shard_level > 0);
+    const int X = sharded ? P.shard_level : 1;          // exchange level
     if (sharded && (phase < 0 || K == 0)) return 1;
+    if (!sharded && phase >= 0) return 1;
     auto make = [&](int l) {
         WideArgs a;
         memset(&a, 0, sizeof(a));
@@ -96,16 +137,32 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
         return a;
     };
     if (phase <= 0) {
-        if (phase == 0 && K > 0) {
-            if (hipMemsetAsync(ws + P.off_Dhat[1], 0, (P.off_L[1] - P.off_Dhat[1]) * sizeof(double), st) != hipSuccess) return 3;
+        if (phase == 0) {
+            for (int l = 1; l <= X; ++l)
+                if (hipMemsetAsync(ws + P.off_Dhat[l], 0, (P.off_L[l] - P.off_Dhat[l]) * sizeof(double), st) != hipSuccess) return 3;
         }
-        if (K > 0) {
-            int rc = wide_dispatch(P.d, 0, make(0), has_rhs, false, true, false, st);
+        const int upto = (phase == 0) ? X : std::min(1, K);      // reduces run here: levels 0 .. upto-1
+        for (int l = 0; l < upto && l < K; ++l) {
+            int rc = wide_dispatch(P.d, 0, make(l), has_rhs, l > 0, true, false, st);
             if (rc) return rc;
         }
-        if (phase == 0) return 0;
+        if (phase == 0) {
+            if (X > 1 && P.own_lo[0] > 0) {
+                // levels 1 .. X: node of the separator on the left = (first owned segment of the level below) - 1
+                CarryArgs c;
+                memset(&c, 0, sizeof(c));
+                c.nlev = X;
+                for (int l = 1; l <= X; ++l) {
+                    c.nn[l - 1] = P.lv[l].n; c.qq[l - 1] = P.own_lo[l - 1] - 1;
+                    c.Rsub[l - 1] = ws + P.off_Rsub[l]; c.rho[l - 1] = ws + P.off_rho[l];
+                }
+                hipLaunchKernelGGL(k_carry_up, dim3(P.B), dim3(256), 0, st, P.d, c, ws + P.off_part2);
+                MFGM_CHECK_LAUNCH();
+            }
+            return 0;
+        }
     }
-    for (int l = 1; l < K; ++l) {
+    for (int l = X; l < K; ++l) {
         int rc = wide_dispatch(P.d, 0, make(l), has_rhs, true, true, false, st);
         if (rc) return rc;
     }
@@ -113,6 +170,12 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
         if (hipMemsetAsync(ws + P.off_part[0], 0, 2 * (size_t)P.lv[0].Lpad * sizeof(double), st) != hipSuccess) return 3;
     }
     for (int l = K; l >= 0; --l) {
+        if (sharded && l == X - 1 && X > 1 && P.own_lo[0] > 0) {
+            // the levels from the exchange level up are factorised: back to this process's own correction of the separator on its left
+            hipLaunchKernelGGL(k_carry_restore, dim3(P.B), dim3(256), 0, st, P.d, P.lv[X].n, P.own_lo[X - 1] - 1, ws + P.off_Rsub[X],
+                               ws + P.off_rho[X], (const double*)(ws + P.off_part2));
+            MFGM_CHECK_LAUNCH();
+        }
         int rc = wide_dispatch(P.d, 1, make(l), has_rhs, l > 0, l < K, false, st);
         if (rc) return rc;
     }

@@ -33,7 +33,12 @@ struct Plan {
     int B, T, d;
     int wide;      // d > 8: wavefront-per-segment kernels on natural-layout arrays (mfgm_wide.h)
     int nlevels;
-    int seg_lo, seg_hi;   // level-0 segments this process owns (wide plans; the whole range unless mfgm_plan_set_shard was called)
+    int seg_lo, seg_hi;   // level-0 segments this process owns (wide plans; the whole range unless the plan is sharded)
+    // one chain over several processes (wide plans): the inputs of level `shard_level` are exchanged (summed) between the
+    // processes; below it a process works on its own segments [own_lo[l], own_hi[l]) only, from it upwards everything is replicated.
+    // shard_level == 0: not sharded.
+    int shard_level;
+    int own_lo[kMaxLevels], own_hi[kMaxLevels];
     LevelDesc lv[kMaxLevels];
     // per-level workspace offsets (in doubles) into the plan-owned level workspace, levels >= 1
     size_t off_Dhat[kMaxLevels], off_Rsub[kMaxLevels], off_S[kMaxLevels], off_rhat[kMaxLevels], off_rho[kMaxLevels];

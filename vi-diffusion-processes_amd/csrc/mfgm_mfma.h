@@ -423,10 +423,17 @@ static __global__ __launch_bounds__(64) void km_forward(WideArgs a) {
         const Mat<NT> Xt = mat_transpose<NT>(X, lds, L);
         const Mat<NT> Gat = gram<NT>(Xt, Sat);
         C = gram<NT>(Gat, Gat);
+        const bool keep = (a.store_left && p == a.seg_lo);       // sharded chain: see WideArgs::store_left
+        if (keep) {
+            st_mat<NT, true>(wblk(a.Lg, b, n, t0 - 1, EF), d, L, mat_upper<NT>(Fa, L));      // Fa holds L^T
+            st_mat<NT, true>(wblk(a.Gg, b, n, t0 - 1, EF), d, L, Gat);
+        }
         if (HAS_RHS) {
             Vec<NT> ha = ld_vec<NT>(wblk(a.urho, b, un, p - 1, d), d, L, 1.0);
             ha = gram<NT>(Ltu, ld_vec<NT>(wblk(a.uy, b, un, p - 1, d), d, L, 1.0), ha);
-            cv = gram<NT>(Gat, gram<NT>(Xt, ha));
+            const Vec<NT> ya = gram<NT>(Xt, ha);
+            if (keep) st_vec<NT>(wblk(a.yg, b, n, t0 - 1, d), d, L, ya);
+            cv = gram<NT>(Gat, ya);
         }
     }
     double quad = 0.0;

@@ -20,7 +20,9 @@ MFGM_DEV double bcast(double x, int src) {
 struct WideArgs {
     LevelDesc lv, up;
     int d;
-    int seg_lo, nseg;   // segments of this level covered by the launch (all of them except on a sharded level 0)
+    int seg_lo, nseg;   // segments of this level covered by the launch (all of them except below the exchange level of a sharded chain)
+    int store_left;     // forward sweep of a sharded chain: the first covered segment also stores the factor blocks (L, L_{t+1,t}, y) of
+                        // the separator on its left, which it reconstructs anyway (that node belongs to the neighbouring process)
     const double* Dg; const double* Sg; const double* rg; const double* Dcorr; const double* rcorr;
     double aD, aS, aR;
     double* Lg; double* Gg; double* yg; double* part;
@@ -269,7 +271,16 @@ static __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
         ld_row<DM>(wblk(a.Sg, b, n, t0 - 1, EF), d, lane, a.aS, Ga);
         chol_rsolve<DM, false>(Fa, invd, Ga, dummy, lane, bad);
         mm_abt<DM>(Ga, Ga, 1.0, C);
-        if (HAS_RHS) c = mv<DM>(Ga, fsolve<DM>(Fa, invd, ha, lane));
+        double ya = 0.0;
+        if (HAS_RHS) {
+            ya = fsolve<DM>(Fa, invd, ha, lane);
+            c = mv<DM>(Ga, ya);
+        }
+        if (a.store_left && p == a.seg_lo) {
+            st_row<DM>(wblk(a.Lg, b, n, t0 - 1, EF), d, lane, Fa);
+            st_row<DM>(wblk(a.Gg, b, n, t0 - 1, EF), d, lane, Ga);
+            if (HAS_RHS && lane < d) wblk(a.yg, b, n, t0 - 1, d)[lane] = ya;
+        }
     }
     double logacc = 0.0, quad = 0.0;
     for (int s = 0; s < len; ++s) {

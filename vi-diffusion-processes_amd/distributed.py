@@ -53,11 +53,13 @@ def allreduce_max_(t):
 
 class ChainShard:
     """
-    One long chain over several GPUs (SURVEY 8e second row, config 5): the time axis is cut at level-0 segment boundaries, rank k
-    owns segments [seg_lo, seg_hi).  Per factorisation there is one real exchange: the level-1 separator system
-    (P x (3 d^2 + 2 d) doubles, every entry written by one rank) is summed over the ranks with one all-reduce (plus a 2 d^2 halo of
-    factor blocks per cut and the scalar log-determinant / quadratic-form sums); the coarser levels
-    are then solved redundantly on every rank and the level-0 forward / backward sweeps touch only the owned segments.
+    One long chain over several GPUs (SURVEY 8e second row, config 5): the time axis is cut at segment boundaries of a COARSE level
+    X of the partition (the highest level that still has at least `world` nodes per chain); rank k owns a contiguous range of that
+    level's nodes and, below it, the segments they stand for.  Every rank eliminates the interior of its range by itself (the
+    reduces of the levels 0 .. X-1 on its own segments); the one exchange per factorisation is the sum of the level-X inputs --
+    n_X x (3 d^2 + 2 d) doubles per chain, every entry written by one rank (8 x 800 doubles = 51 KB at config 5) -- after which the
+    levels >= X are solved redundantly on every rank and the sweeps back down touch only the owned segments.  Besides that exchange
+    only the scalar log-determinant / quadratic-form sums cross ranks.
     Wide plans (8 < d <= 32) only.  Arrays are addressed with global node indices: a rank needs the inputs of its own nodes
     [node_lo, node_hi) and the sub-diagonal block at node_lo - 1; its outputs are valid on its own nodes (the cross-covariances
     Sigma_{t+1,t} on [node_lo - 1, node_hi - 1): each is produced together with Sigma_{t+1}).
@@ -70,14 +72,27 @@ class ChainShard:
         import ctypes
         from . import _lib
         self.plan, self.rank, self.world = plan, int(rank), int(world)
-        if plan.P < self.world:
-            raise ValueError(f"{plan.P} level-0 segments cannot be shared by {world} ranks: use a smaller R0")
-        self.seg_lo, self.seg_hi = shard_bounds(plan.P, self.rank, self.world)
-        _lib.check(plan.lib.mfgm_plan_set_shard(plan.h, self.seg_lo, self.seg_hi), "mfgm_plan_set_shard (wide plans with >= 2 levels only)")
+        lev = (ctypes.c_int * 4)()
+        levels = []
+        for l in range(plan.nlevels):
+            _lib.check(plan.lib.mfgm_plan_level(plan.h, l, lev), "mfgm_plan_level")
+            levels.append(tuple(lev))                       # (n, R, P, Lpad)
+        cand = [l for l in range(1, plan.nlevels) if levels[l][0] >= self.world]
+        if not cand:
+            raise ValueError(f"no level of this plan has {world} nodes per chain to share between the ranks: use a smaller R0")
+        self.level = max(cand)
+        n_x = levels[self.level][0]
+        lo, hi = shard_bounds(n_x, self.rank, self.world)
+        _lib.check(plan.lib.mfgm_plan_set_shard_level(plan.h, self.level, lo, hi), "mfgm_plan_set_shard_level (wide plans with >= 2 levels only)")
         off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
         _lib.check(plan.lib.mfgm_plan_exchange_region(plan.h, ctypes.byref(off), ctypes.byref(cnt)), "mfgm_plan_exchange_region")
         self.exchange = plan.ws[off.value:off.value + cnt.value]
-        self.node_lo, self.node_hi = self.seg_lo * plan.R, min(self.seg_hi * plan.R, plan.T)
+        # level-0 nodes of the range: one node of level l stands for R_{l-1} nodes of level l-1
+        span = 1
+        for l in range(self.level):
+            span *= levels[l][1]
+        self.node_lo, self.node_hi = lo * span, min(hi * span, plan.T)
+        self.seg_lo, self.seg_hi = self.node_lo // levels[0][1], -(-self.node_hi // levels[0][1])
         self._allreduce = allreduce if allreduce is not None else allreduce_sum_
 
     def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False):
@@ -95,15 +110,6 @@ class ChainShard:
         check(pl.lib.mfgm_packed_factor_phase(pl.h, 0, *args), "mfgm_packed_factor_phase(0)")
         self._allreduce(self.exchange)
         check(pl.lib.mfgm_packed_factor_phase(pl.h, 1, *args), "mfgm_packed_factor_phase(1)")
-        # halo: the factor blocks of the node to the left of the first owned node (needed for Sigma_{lo, lo-1}); 2 d^2 doubles per cut
-        B, T, d = pl.B, pl.T, pl.d
-        Lv, Gv = L.view(B, T, d, d), G.view(B, T, d, d)
-        halo = torch.zeros((self.world, 2, B, d, d), dtype=torch.float64, device=pl.device)
-        if self.node_hi < T:
-            halo[self.rank, 0], halo[self.rank, 1] = Lv[:, self.node_hi - 1], Gv[:, self.node_hi - 1]
-        self._allreduce(halo)
-        if self.node_lo > 0:
-            Lv[:, self.node_lo - 1], Gv[:, self.node_lo - 1] = halo[self.rank - 1, 0], halo[self.rank - 1, 1]
         if logdet is not None:
             self._allreduce(logdet)
         if quad is not None:
@@ -111,5 +117,5 @@ class ChainShard:
         return dict(L=L, G=G, y=y, logdet=logdet, quad=quad)
 
     def selinv(self, L, G, y=None, want_sub=True):
-        """Selected inverse on the owned nodes (no communication: the coarse levels are replicated)."""
+        """Selected inverse on the owned nodes (no communication: the levels from the exchange level up are replicated)."""
         return self.plan.selinv(L, G, y, want_sub=want_sub)
