@@ -296,6 +296,13 @@ int mfgm_sparse_theta(int T, int d, const double* nat1, const double* nat2, cons
  * states: mu [M, d], Sig [M, d, d], Sub [M, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N]. */
 int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
                         void* stream);
+/* ConditionalProcess.predict_state (posterior.py:207-229 -> conditional_predict / base_conditional_predict, conditionals.py:29-76,
+ * 380-421) at N query points: idx [N] = interval of each point (0 .. M, as above), P [N, d, 2d] / T [N, d, d] its conditional
+ * statistics (conditionals.py:207-256), the marginals of the M conditioning states as in mfgm_sparse_predict;
+ * out_mean [N, d] = P m_pair, out_cov [N, d, d] = T + P S_pair P^T (no [M+1, 2d, 2d] pairwise tensor, no per-point gather). */
+int mfgm_cond_predict(int M, int d, int N, const int* idx, const double* P, const double* T, const double* prior_mean,
+                      const double* prior_cov, const double* mu, const double* Sig, const double* Sub, double* out_mean, double* out_cov,
+                      void* stream);
 /* update_sites (sparse_variational_cvi.py:176-221): sites <- (1 - lr) sites + lr sum_{i in interval} (g1_i w_i, g2_i w_i w_i^T), in place;
  * g1, g2 [N] are the likelihood gradients with respect to the expectation parameters of f(t_i). */
 int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2,

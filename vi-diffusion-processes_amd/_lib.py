@@ -76,6 +76,7 @@ EXPORTS = {
     "mfgm_kf_sites_predict": (ctypes.c_int, [ctypes.c_void_p] * 16),
     "mfgm_sparse_theta": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 9),
     "mfgm_sparse_predict": (ctypes.c_int, [ctypes.c_void_p] * 7),
+    "mfgm_cond_predict": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 11),
     "mfgm_sparse_site_update": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] + [ctypes.c_void_p] * 3),
     "mfgm_packed_naturals_to_ssm": (ctypes.c_int, [ctypes.c_void_p] * 11),
     "mfgm_btd_matvec": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

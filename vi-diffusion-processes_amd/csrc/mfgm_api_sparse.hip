@@ -38,6 +38,20 @@ int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const do
     return 0;
 }
 
+int mfgm_cond_predict(int M, int d, int N, const int* idx, const double* P, const double* T, const double* prior_mean,
+                      const double* prior_cov, const double* mu, const double* Sig, const double* Sub, double* out_mean, double* out_cov,
+                      void* stream) {
+    if (M < 1 || d < 1 || d > 32 || N < 0 || !idx || !P || !T || !prior_mean || !prior_cov || !mu || !Sig || !Sub || !out_mean || !out_cov)
+        return 1;
+    if (N == 0) return 0;
+    const int d2 = 2 * d;
+    const size_t shmem = sizeof(double) * ((size_t)d2 * d2 + d2 + 2 * (size_t)d * d2);
+    hipLaunchKernelGGL(k_cond_predict, dim3(N), dim3(64), shmem, (hipStream_t)stream, M, d, N, idx, P, T, prior_mean, prior_cov, mu, Sig, Sub,
+                       out_mean, out_cov);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2,
                             void* stream) {
     if (!sparse_ok(data) || !nat1 || !nat2 || (data->N > 0 && (!g1 || !g2))) return 1;

@@ -98,6 +98,63 @@ static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, cons
     }
 }
 
+// State prediction at arbitrary sorted query points (conditional_predict + base_conditional_predict, conditionals.py:29-76, 380-421;
+// posterior.py:207-229): p(x(t_i)) = N(P_i m_pair, T_i + P_i S_pair P_i^T) with the pair of conditioning states around t_i taken
+// straight from the marginal blocks (the prior pads both ends).  Pm [N, d, 2d], Tm [N, d, d], idx [N] = interval of query i;
+// out_mean [N, d], out_cov [N, d, d].  One wavefront per query point.
+static __global__ __launch_bounds__(64) void k_cond_predict(int M, int d, int N, const int* __restrict__ idx, const double* __restrict__ Pm,
+                                                           const double* __restrict__ Tm, const double* __restrict__ prior_mean,
+                                                           const double* __restrict__ prior_cov, const double* __restrict__ mu,
+                                                           const double* __restrict__ Sig, const double* __restrict__ Sub,
+                                                           double* __restrict__ out_mean, double* __restrict__ out_cov) {
+    extern __shared__ double sh[];     // PC [2d][2d], pm [2d], P [d][2d], U = P PC [d][2d]
+    const int i = blockIdx.x, d2 = 2 * d, lane = threadIdx.x;
+    if (i >= N) return;
+    const int m = idx[i];
+    double* PC = sh;
+    double* pm = PC + d2 * d2;
+    double* P = pm + d2;
+    double* U = P + d * d2;
+    const bool lo_prior = (m == 0), hi_prior = (m == M);
+    const double* S_lo = lo_prior ? prior_cov : Sig + (size_t)(m - 1) * d * d;
+    const double* S_hi = hi_prior ? prior_cov : Sig + (size_t)m * d * d;
+    const double* C = (lo_prior || hi_prior) ? nullptr : Sub + (size_t)(m - 1) * d * d;
+    for (int e = lane; e < d2 * d2; e += 64) {
+        const int r = e / d2, c = e - r * d2;
+        double v;
+        if (r < d && c < d) v = S_lo[r * d + c];
+        else if (r >= d && c >= d) v = S_hi[(r - d) * d + (c - d)];
+        else if (r >= d) v = C ? C[(r - d) * d + c] : 0.0;
+        else v = C ? C[(c - d) * d + r] : 0.0;
+        PC[e] = v;
+    }
+    for (int e = lane; e < d2; e += 64) {
+        const bool hi = e >= d;
+        const int k = hi ? e - d : e;
+        pm[e] = hi ? (hi_prior ? prior_mean[k] : mu[(size_t)m * d + k]) : (lo_prior ? prior_mean[k] : mu[(size_t)(m - 1) * d + k]);
+    }
+    for (int e = lane; e < d * d2; e += 64) P[e] = Pm[(size_t)i * d * d2 + e];
+    __syncthreads();
+    for (int e = lane; e < d * d2; e += 64) {         // U = P PC
+        const int r = e / d2, c = e - r * d2;
+        double acc = 0.0;
+        for (int k = 0; k < d2; ++k) acc += P[r * d2 + k] * PC[k * d2 + c];
+        U[e] = acc;
+    }
+    for (int e = lane; e < d; e += 64) {
+        double acc = 0.0;
+        for (int k = 0; k < d2; ++k) acc += P[e * d2 + k] * pm[k];
+        out_mean[(size_t)i * d + e] = acc;
+    }
+    __syncthreads();
+    for (int e = lane; e < d * d; e += 64) {          // cov = T + U P^T
+        const int r = e / d, c = e - r * d;
+        double acc = Tm[(size_t)i * d * d + e];
+        for (int k = 0; k < d2; ++k) acc += U[r * d2 + k] * P[c * d2 + k];
+        out_cov[(size_t)i * d * d + e] = acc;
+    }
+}
+
 // sites <- (1 - lr) sites + lr (sum_i g1_i w_i, sum_i g2_i w_i w_i^T), in place; g1, g2 [N]
 static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const double* __restrict__ g1, const double* __restrict__ g2,
                                                             double lr, double* __restrict__ nat1, double* __restrict__ nat2) {
