@@ -130,7 +130,33 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
     if gpu_first_elbo is not None:
         ref = first[:Bs]
         out["first_step_elbo_max_rel_diff_vs_gpu"] = float(np.max(np.abs(gpu_first_elbo[:Bs] - ref) / np.abs(ref)))
+    out["lapack_banded"] = lapack_banded_comparator(T, d, dt)
     return out
+
+
+def lapack_banded_comparator(T, d, dt):
+    """Independent CPU comparator: LAPACK's banded Cholesky (dpbtrf / dpbtrs through scipy.linalg.cholesky_banded /
+    cho_solve_banded, one thread) on ONE trajectory's posterior precision of the same shape -- T*d rows, lower bandwidth 2d-1 -- i.e.
+    what the reference's banded_matrices ops do per refresh (factor + one solve; the step has two refreshes and a selected inverse each
+    on top).  Times only; not part of `value`."""
+    try:
+        from scipy.linalg import cho_solve_banded, cholesky_banded
+    except ImportError:
+        return None
+    n, bw = T * d, 2 * d - 1
+    rng = np.random.default_rng(0)
+    ab = np.zeros((bw + 1, n))
+    ab[0] = 2.0 / dt + rng.random(n)                      # diagonally dominant SPD band, magnitudes of the Euler-chain precision
+    for k in range(1, bw + 1):
+        ab[k, :n - k] = -0.3 / dt * rng.random(n - k) / bw
+    r = rng.standard_normal(n)
+    t0 = time.perf_counter()
+    cb = cholesky_banded(ab, lower=True, check_finite=False)
+    t1 = time.perf_counter()
+    cho_solve_banded((cb, True), r, check_finite=False)
+    t2 = time.perf_counter()
+    return {"what": f"scipy.linalg.cholesky_banded + cho_solve_banded (LAPACK dpbtrf / dpbtrs), one trajectory, n = {n}, bandwidth {bw}, 1 thread",
+            "factor_ms": 1e3 * (t1 - t0), "solve_ms": 1e3 * (t2 - t1)}
 
 
 def vdp_step_rate(B, T, d, dt, noise, idx, ys, device, steps=10):
