@@ -132,6 +132,14 @@ int mfgm_packed_naturals_to_ssm(const mfgm_plan* plan, const double* Sig, const 
 int mfgm_btd_matvec(int B, int T, int d, const double* diag, const double* sub, const double* x, double* out, int symmetric,
                     int transpose, void* stream);
 
+/* L x = r (transpose == 0) or L^T x = r for a lower block-bidiagonal factor on natural-layout arrays
+ * (LowerTriangularBlockTriDiagonal.solve, block_tri_diag.py:339-351 -> solve_triang_mat): Ld [B, T, d, d] (lower triangles read),
+ * Ls [B, T-1, d, d] = L_{t+1,t}, r / x [B, T, d], d <= 32; scratch of mfgm_bidiag_scratch_doubles(B, T, d) doubles.  The plain
+ * substitution, parallelised exactly over segments as an affine recurrence (csrc/mfgm_bidiag.h): no Gram matrix is formed. */
+size_t mfgm_bidiag_scratch_doubles(int B, int T, int d);
+int mfgm_bidiag_solve(int B, int T, int d, const double* Ld, const double* Ls, const double* r, double* x, int transpose, double* scratch,
+                      void* stream);
+
 /* Trace and Mahalanobis terms of KL(q || p) (state_space_model.py:557-593): q given by marginal blocks
  * Sig (SYM), Sub (FULL), mu (VEC); p by precision blocks aD*Pd (SYM), aS*Ps (FULL) and marginal means mup.
  * trace[B], maha[B]. */

@@ -86,6 +86,32 @@ def test_block_tri_diag(amd, rng, batch_shape, d, T, with_sub):
     assert_close(host(both.block_diagonal), 2 * diag)
 
 
+@pytest.mark.parametrize("d,T", [(2, 33), (5, 200), (12, 97), (20, 65)])
+def test_lower_block_bidiagonal_solve_direct(amd, rng, d, T):
+    """LowerTriangularBlockTriDiagonal.solve (block_tri_diag.py:339-351) across several segments of the affine-recurrence
+    parallelisation, both orientations, against the dense triangular solve; and on an ill-conditioned factor (cond(L) ~ 1e7,
+    so cond(L L^T) ~ 1e14), where a route through the Gram matrix would lose all accuracy."""
+    from vidp_amd.block_tri_diag import LowerTriangularBlockTriDiagonal
+    B = 2
+    for scale in (1.0, 1e-7):
+        Ld = np.tril(rng.normal(size=(B, T, d, d))) * 0.3 / np.sqrt(d)
+        idx = np.arange(d)
+        Ld[..., idx, idx] = rng.uniform(0.8, 1.5, size=(B, T, d))
+        Ld[:, T // 2, 0, 0] *= scale                  # one tiny pivot
+        Ls = 0.3 / np.sqrt(d) * rng.normal(size=(B, T - 1, d, d))      # a contracting recurrence, as a Cholesky factor's is
+        x = rng.normal(size=(B, T, d))
+        low = LowerTriangularBlockTriDiagonal(dev(Ld), dev(Ls))
+        for tr in (False, True):
+            got = host(low.solve(dev(x), transpose_left=tr))
+            for b in range(B):
+                dense = np_btd.to_dense(Ld[b], Ls[b], symmetric=False)
+                want = np.linalg.solve(dense.T if tr else dense, x[b].reshape(-1)).reshape(T, d)
+                # backward-stable substitution: the residual is at rounding level whatever the conditioning
+                res = (dense.T if tr else dense) @ got[b].reshape(-1) - x[b].reshape(-1)
+                assert np.abs(res).max() <= 1e-9 * max(1.0, np.abs(got[b]).max())
+                assert_close(got[b], want, rtol=1e-6)
+
+
 def test_not_positive_definite(amd):
     import torch
     from vidp_amd.block_tri_diag import SymmetricBlockTriDiagonal

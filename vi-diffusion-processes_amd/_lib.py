@@ -79,6 +79,8 @@ EXPORTS = {
     "mfgm_cond_predict": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 11),
     "mfgm_sparse_site_update": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] + [ctypes.c_void_p] * 3),
     "mfgm_packed_naturals_to_ssm": (ctypes.c_int, [ctypes.c_void_p] * 11),
+    "mfgm_bidiag_scratch_doubles": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "mfgm_bidiag_solve": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_btd_matvec": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "mfgm_natural_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_btd_cholesky": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 6),

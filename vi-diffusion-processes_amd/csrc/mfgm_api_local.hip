@@ -3,6 +3,7 @@
 #include "mfgm_sweeps.h"
 #include "mfgm_local.h"
 #include "mfgm_nat2ssm.h"
+#include "mfgm_bidiag.h"
 
 using namespace mfgm;
 
@@ -51,6 +52,37 @@ int mfgm_packed_naturals_to_ssm(const mfgm_plan* plan, const double* Sig, const 
     if (P.wide) return 1;
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (n2s_impl<DD>(P, Sig, Sub, mu, theta_diag, theta_sub, A, off, chol, info, st)));
+}
+
+size_t mfgm_bidiag_scratch_doubles(int B, int T, int d) {
+    if (B < 1 || T < 1 || d < 1) return 0;
+    const size_t P = (size_t)(T + kBidiagR - 1) / kBidiagR;
+    return (size_t)B * P * ((size_t)d * d + 2 * d);
+}
+
+int mfgm_bidiag_solve(int B, int T, int d, const double* Ld, const double* Ls, const double* r, double* x, int transpose, double* scratch,
+                      void* stream) {
+    if (B < 1 || T < 1 || d < 1 || d > 32 || !Ld || !r || !x || !scratch || (T > 1 && !Ls)) return 1;
+    const int P = (T + kBidiagR - 1) / kBidiagR;
+    double* Phi = scratch;
+    double* cvec = Phi + (size_t)B * P * d * d;
+    double* xin = cvec + (size_t)B * P * d;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B * P), block(64);
+#define BIDIAG(DM_)                                                                                                                    \
+    if (transpose) {                                                                                                                   \
+        hipLaunchKernelGGL((k_bidiag<DM_, true, 0>), grid, block, 0, st, T, d, P, Ld, Ls, r, Phi, cvec, (const double*)nullptr, x);      \
+        hipLaunchKernelGGL((k_bidiag_scan<true>), dim3(B), block, 0, st, d, P, (const double*)Phi, (const double*)cvec, xin);            \
+        hipLaunchKernelGGL((k_bidiag<DM_, true, 1>), grid, block, 0, st, T, d, P, Ld, Ls, r, Phi, cvec, (const double*)xin, x);          \
+    } else {                                                                                                                           \
+        hipLaunchKernelGGL((k_bidiag<DM_, false, 0>), grid, block, 0, st, T, d, P, Ld, Ls, r, Phi, cvec, (const double*)nullptr, x);     \
+        hipLaunchKernelGGL((k_bidiag_scan<false>), dim3(B), block, 0, st, d, P, (const double*)Phi, (const double*)cvec, xin);           \
+        hipLaunchKernelGGL((k_bidiag<DM_, false, 1>), grid, block, 0, st, T, d, P, Ld, Ls, r, Phi, cvec, (const double*)xin, x);         \
+    }
+    if (d <= 8) { BIDIAG(8) } else if (d <= 16) { BIDIAG(16) } else { BIDIAG(32) }
+#undef BIDIAG
+    MFGM_CHECK_LAUNCH();
+    return 0;
 }
 
 int mfgm_btd_matvec(int B, int T, int d, const double* diag, const double* sub, const double* x, double* out, int symmetric,
