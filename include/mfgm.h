@@ -79,6 +79,18 @@ int mfgm_packed_factor(const mfgm_plan* plan, const double* D, const double* S, 
 int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, const double* y, double* Sig,
                        double* Sub, double* x, void* ws, void* stream);
 
+/* The same pair for callers that only want what the selected inverse delivers (marginal blocks, means, log-determinant, quadratic
+ * form) and never read the factor itself.  form 0: exactly mfgm_packed_factor / mfgm_packed_selinv.  form 1 (plans with 8 < d <= 32
+ * only, otherwise error 1): INVERSE FORM -- the arrays L, G, y receive (F_t^{-1}, S_t F_t^{-1}, F_t^{-1} h_t) for the pivot blocks F_t of
+ * the elimination instead of (L_tt, L_{t+1,t}, y_t), logdet / quad are unchanged, and the arrays are only meaningful as inputs of
+ * mfgm_packed_selinv_form(form 1) of the same plan: the backward pass then needs no factorisation at all and the forward passes
+ * invert F_t with MFMA block sweeps (csrc/mfgm_mfma_inv.h). */
+int mfgm_packed_factor_form(const mfgm_plan* plan, int form, const double* D, const double* S, const double* r, double aD, double aS,
+                            double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                            void* stream);
+int mfgm_packed_selinv_form(const mfgm_plan* plan, int form, const double* L, const double* G, const double* y, double* Sig,
+                            double* Sub, double* x, void* ws, void* stream);
+
 /* out = a*x + b*y + c*z over n doubles (y and z may be NULL): the element-wise site / natural-parameter
  * arithmetic of the CVI updates (variational_cvi_sde.py:161-174, 279-317) on packed arrays. */
 int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, const double* y, double c,
@@ -472,6 +484,10 @@ int mfgm_plan_exchange_region(const mfgm_plan* plan, size_t* offset_doubles, siz
 int mfgm_packed_factor_phase(const mfgm_plan* plan, int phase, const double* D, const double* S, const double* r, double aD,
                              double aS, double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws,
                              int* info, void* stream);
+/* the phases with the factor arrays in the given form (see mfgm_packed_factor_form) */
+int mfgm_packed_factor_phase_form(const mfgm_plan* plan, int form, int phase, const double* D, const double* S, const double* r,
+                                  double aD, double aS, double aR, double* L, double* G, double* y, double* logdet, double* quad,
+                                  void* ws, int* info, void* stream);
 
 /* ---- batched small dense SPD algebra on natural-layout arrays -----------------------------------------------------------
  * The per-time-step algebra around the sweeps that has no fused kernel of its own: replaces the reference's

@@ -95,6 +95,61 @@ def test_factor_and_selinv_wide(amd, rng, B, T, d, R0, Rup, with_rhs):
         assert_close(host(plan.unpack(amd.VEC, s["x"])), x)
 
 
+@pytest.mark.parametrize("B,T,d,R0,Rup", CASES)
+@pytest.mark.parametrize("with_rhs", [True, False])
+def test_inverse_form_wide(amd, rng, B, T, d, R0, Rup, with_rhs):
+    """factor(moments_only=True) + selinv(form=1) (the inverse-form MFMA sweeps, csrc/mfgm_mfma_inv.h): the same marginal blocks, means,
+    log-determinant and quadratic form as the oracle's Cholesky route; the factor arrays hold F_t^{-1}, S_t F_t^{-1}, F_t^{-1} h_t."""
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    plan = amd.Plan(B, T, d, R0=R0, Rup=Rup)
+    Dp = plan.pack(amd.SYM, dev(-0.5 * diag))
+    Sp = plan.pack(amd.FULL, dev(-sub)) if T > 1 else plan.zeros(amd.FULL)
+    rp = plan.pack(amd.VEC, dev(2 * r)) if with_rhs else None
+    f = plan.factor(Dp, Sp, rp, aD=-2.0, aS=-1.0, aR=0.5, want_logdet=True, want_quad=True, moments_only=True)
+    plan.check_info()
+    assert f["form"] == 1
+    Ld, Ls = np_btd.cholesky(diag, sub)
+    np.testing.assert_allclose(host(f["logdet"]), np_btd.abs_log_det(Ld), rtol=1e-8, atol=1e-8)
+    if with_rhs:
+        y = np_btd.solve(Ld, Ls, r)
+        np.testing.assert_allclose(host(f["quad"]), np.sum(y * y, axis=(-1, -2)), rtol=1e-7)
+    # the factor arrays: with one segment per chain the pivot blocks are F_t = L_tt L_tt^T
+    if plan.nlevels == 1:
+        Fi = np.linalg.inv(Ld @ np.swapaxes(Ld, -1, -2))
+        assert_close(host(plan.unpack(amd.FULL, f["L"])), Fi)
+        if T > 1:
+            assert_close(host(plan.unpack(amd.FULL, f["G"], T - 1)), sub @ Fi[:, :-1])
+    s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True, form=f["form"])
+    Sd, Ss = np_btd.inverse_blocks(Ld, Ls)
+    assert_close(host(plan.unpack(amd.SYM, s["Sig"])), Sd)
+    if T > 1:
+        assert_close(host(plan.unpack(amd.FULL, s["Sub"], T - 1)), Ss)
+    if with_rhs:
+        x = np_btd.solve(Ld, Ls, np_btd.solve(Ld, Ls, r), transpose_left=True)
+        assert_close(host(plan.unpack(amd.VEC, s["x"])), x)
+    s2 = plan.selinv(f["L"], f["G"], f["y"], want_sub=False, form=f["form"])
+    assert_close(host(plan.unpack(amd.SYM, s2["Sig"])), Sd)
+
+
+def test_inverse_form_not_pd_and_narrow(amd, rng):
+    B, T, d = 2, 40, 11
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    plan = amd.Plan(B, T, d, R0=8)
+    plan.factor(plan.pack(amd.SYM, dev(-diag)), plan.pack(amd.FULL, dev(sub)), moments_only=True)
+    with pytest.raises(ArithmeticError):
+        plan.check_info()
+    # lane-per-segment plans (d <= 8) have no inverse form: the request falls back to the Cholesky form, the C entry refuses form 1
+    small = amd.Plan(1, 10, 3)
+    diag, sub = random_dominant_btd(rng, (1,), 10, 3)
+    Dp, Sp = small.pack(amd.SYM, dev(diag)), small.pack(amd.FULL, dev(sub))
+    f = small.factor(Dp, Sp, moments_only=True)
+    assert f["form"] == 0
+    from vidp_amd.packed import _ptr, _stream
+    assert small.lib.mfgm_packed_factor_form(small.h, 1, _ptr(Dp), _ptr(Sp), None, 1.0, 1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]), None, None, None,
+                                             _ptr(small.ws), _ptr(small.info), _stream()) == 1
+
+
 def test_scaled_inputs_and_not_pd_wide(amd, rng):
     B, T, d = 2, 40, 11
     diag, sub = random_dominant_btd(rng, (B,), T, d)

@@ -19,11 +19,14 @@ def main():
     S = (0.3 / d ** 0.5) * torch.randn((B, T, d, d), generator=g, device="cuda", dtype=torch.float64)
     r = torch.randn((B, T, d), generator=g, device="cuda", dtype=torch.float64)
     D, S, r = D.reshape(-1), S.reshape(-1), r.reshape(-1)
-    f = plan.factor(D, S, r)
-    s = plan.selinv(f["L"], f["G"], f["y"])
+    mo = __import__("os").environ.get("PROBE_MOMENTS_ONLY", "0") != "0"
+    f = plan.factor(D, S, r, moments_only=mo)
+    form = f["form"]
+    print("form", form)
+    s = plan.selinv(f["L"], f["G"], f["y"], form=form)
     torch.cuda.synchronize()
     plan.check_info()
-    for name, fn in (("factor", lambda: plan.factor(D, S, r, out=f)), ("selinv", lambda: plan.selinv(f["L"], f["G"], f["y"], out=s))):
+    for name, fn in (("factor", lambda: plan.factor(D, S, r, out=f, moments_only=mo)), ("selinv", lambda: plan.selinv(f["L"], f["G"], f["y"], out=s, form=form))):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 5
         ev0.record()

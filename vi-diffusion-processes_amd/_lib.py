@@ -29,6 +29,9 @@ EXPORTS = {
                                    ctypes.c_void_p]),
     "mfgm_packed_factor": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 8),
     "mfgm_packed_selinv": (ctypes.c_int, [ctypes.c_void_p] * 9),
+    "mfgm_packed_factor_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_double] * 3
+                                + [ctypes.c_void_p] * 8),
+    "mfgm_packed_selinv_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8),
     "mfgm_lincomb": (ctypes.c_int, [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_node_io": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -93,6 +96,8 @@ EXPORTS = {
     "mfgm_plan_exchange_region": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "mfgm_packed_factor_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_double] * 3
                                  + [ctypes.c_void_p] * 8),
+    "mfgm_packed_factor_phase_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+                                      + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 8),
     "mfgm_batched_cholesky": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4),
     "mfgm_batched_trsm": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
 }

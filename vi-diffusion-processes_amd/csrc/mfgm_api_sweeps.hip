@@ -570,6 +570,31 @@ int mfgm_packed_selinv(const mfgm_plan* plan, const double* L, const double* G, 
 }
 
 
+int mfgm_packed_factor_form(const mfgm_plan* plan, int form, const double* D, const double* S, const double* r, double aD, double aS,
+                            double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                            void* stream) {
+    if (form == 0) return mfgm_packed_factor(plan, D, S, r, aD, aS, aR, L, G, y, logdet, quad, ws, info, stream);
+    if (!plan || !D || !L || !G || !info || form != 1) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide) return 1;
+    if (P.T > 1 && !S) return 1;
+    if ((r != nullptr) != (y != nullptr)) return 1;
+    if (!ws && P.ws_doubles > 0) return 1;
+    return wide_factor(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, -1, 1);
+}
+
+int mfgm_packed_selinv_form(const mfgm_plan* plan, int form, const double* L, const double* G, const double* y, double* Sig,
+                            double* Sub, double* x, void* ws, void* stream) {
+    if (form == 0) return mfgm_packed_selinv(plan, L, G, y, Sig, Sub, x, ws, stream);
+    if (!plan || !L || !G || !Sig || form != 1) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide) return 1;
+    if ((y != nullptr) != (x != nullptr)) return 1;
+    if (!ws && P.ws_doubles > 0) return 1;
+    return wide_selinv(P, L, G, y, Sig, Sub, x, (double*)ws, (hipStream_t)stream, 1);
+}
+
+
 // Profiling / roofline entry points: launch exactly ONE kernel of a sweep (stage 0 = reduce, 1 = forward; level 0 is
 // the finest).  The coarser levels must already be in `ws` from a full mfgm_packed_factor / mfgm_packed_selinv call
 // with the same arguments; outputs are overwritten with identical values.
@@ -648,6 +673,16 @@ int mfgm_packed_factor_phase(const mfgm_plan* plan, int phase, const double* D, 
     if (!P.wide || P.nlevels < 2 || !S) return 1;
     if ((r != nullptr) != (y != nullptr)) return 1;
     return wide_factor(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, phase);
+}
+
+int mfgm_packed_factor_phase_form(const mfgm_plan* plan, int form, int phase, const double* D, const double* S, const double* r, double aD,
+                                  double aS, double aR, double* L, double* G, double* y, double* logdet, double* quad, void* ws,
+                                  int* info, void* stream) {
+    if (!plan || !D || !L || !G || !info || !ws || (phase != 0 && phase != 1) || (form != 0 && form != 1)) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide || P.nlevels < 2 || !S) return 1;
+    if ((r != nullptr) != (y != nullptr)) return 1;
+    return wide_factor(P, D, S, r, aD, aS, aR, L, G, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, phase, form);
 }
 
 }  // extern "C"

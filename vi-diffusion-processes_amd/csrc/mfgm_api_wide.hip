@@ -43,7 +43,8 @@ bool use_mfma() {
     return on;
 }
 
-int wide_dispatch(int d, int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st) {
+int wide_dispatch(int d, int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st, int form) {
+    if (form == 1) return mfma_inv_launch(which, a, has_rhs, has_corr, has_up, want_sub, st);
     if (use_mfma()) return mfma_launch(which, a, has_rhs, has_corr, has_up, want_sub, st);
     if (d <= 16) return wide_launch<16>(which, a, has_rhs, has_corr, has_up, want_sub, st);
     return wide_launch<32>(which, a, has_rhs, has_corr, has_up, want_sub, st);
@@ -117,7 +118,8 @@ static __global__ void k_carry_restore(int d, int n, int q, double* __restrict__
 // the exchange level's inputs over the processes);  phase 1: everything after.
 int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st,
-                int phase) {
+                int phase, int form) {
+    if (form != 0 && form != 1) return 1;
     const bool has_rhs = (rg != nullptr);
     const int K = P.nlevels - 1;
     const bool sharded = (P.shard_level > 0);
@@ -143,7 +145,7 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
         }
         const int upto = (phase == 0) ? X : std::min(1, K);      // reduces run here: levels 0 .. upto-1
         for (int l = 0; l < upto && l < K; ++l) {
-            int rc = wide_dispatch(P.d, 0, make(l), has_rhs, l > 0, true, false, st);
+            int rc = wide_dispatch(P.d, 0, make(l), has_rhs, l > 0, true, false, st, form);
             if (rc) return rc;
         }
         if (phase == 0) {
@@ -163,7 +165,7 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
         }
     }
     for (int l = X; l < K; ++l) {
-        int rc = wide_dispatch(P.d, 0, make(l), has_rhs, true, true, false, st);
+        int rc = wide_dispatch(P.d, 0, make(l), has_rhs, true, true, false, st, form);
         if (rc) return rc;
     }
     if (sharded && (logdet || quad)) {
@@ -176,7 +178,7 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
                                ws + P.off_rho[X], (const double*)(ws + P.off_part2));
             MFGM_CHECK_LAUNCH();
         }
-        int rc = wide_dispatch(P.d, 1, make(l), has_rhs, l > 0, l < K, false, st);
+        int rc = wide_dispatch(P.d, 1, make(l), has_rhs, l > 0, l < K, false, st, form);
         if (rc) return rc;
     }
     if (logdet || quad) {
@@ -188,7 +190,8 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
 }
 
 int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub, double* x,
-                double* ws, hipStream_t st) {
+                double* ws, hipStream_t st, int form) {
+    if (form != 0 && form != 1) return 1;
     const bool has_rhs = (yg != nullptr);
     const int K = P.nlevels - 1;
     for (int l = K; l >= 0; --l) {
@@ -199,7 +202,7 @@ int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double*
             a.Sigg = Sig; a.Subg = Sub; a.mug = x;
         }
         wide_bind(P, l, ws, a);
-        int rc = wide_dispatch(P.d, 2, a, has_rhs, false, l < K, l == 0 && Sub != nullptr, st);
+        int rc = wide_dispatch(P.d, 2, a, has_rhs, false, l < K, l == 0 && Sub != nullptr, st, form);
         if (rc) return rc;
     }
     return 0;

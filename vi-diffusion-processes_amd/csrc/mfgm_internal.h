@@ -51,9 +51,9 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // mfgm_api_wide.hip
 int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st,
-                int phase = -1);
+                int phase = -1, int form = 0);
 int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub, double* x,
-                double* ws, hipStream_t st);
+                double* ws, hipStream_t st, int form = 0);
 int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
                          double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st);
 int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps,
@@ -62,6 +62,8 @@ int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const dou
 // mfgm_api_mfma.hip: which = 0 reduce, 1 forward, 2 backward
 struct WideArgs;
 int mfma_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st);
+// mfgm_api_mfma_inv.hip: the same passes in inverse form (mfgm_mfma_inv.h)
+int mfma_inv_launch(int which, const WideArgs& a, bool has_rhs, bool has_corr, bool has_up, bool want_sub, hipStream_t st);
 int mfma_ssm_to_naturals(int B, int T, int d, const double* A, const double* off, const double* chol, double cD, double cS,
                          double* lin, double* diag, double* sub, double* part, hipStream_t st);
 

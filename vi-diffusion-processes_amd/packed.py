@@ -4,6 +4,7 @@ Device-resident packed tensors and the partition plan (thin wrapper over the C A
 PyTorch is used only as the owner of device memory and of the HIP stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -25,6 +26,7 @@ class Plan:
     def __init__(self, B, T, d, R0=0, Rup=0, device="cuda"):
         self.lib = _lib.load()
         self.B, self.T, self.d = int(B), int(T), int(d)
+        self.wide = self.d > 8      # one wavefront per segment (MFMA tiles) instead of one lane per segment
         h = ctypes.c_void_p()
         _lib.check(self.lib.mfgm_plan_create(self.B, self.T, self.d, int(R0), int(Rup), ctypes.byref(h)),
                    f"mfgm_plan_create(B={B}, T={T}, d={d})")
@@ -73,10 +75,14 @@ class Plan:
         return out
 
     # -- sweeps -------------------------------------------------------------------------------
-    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False, out=None, store_G=True):
-        """Block Cholesky (+ forward substitution).  Returns dict(L, G, y, logdet, quad).  store_G=False (d <= 8) skips the
-        L_{t+1,t} output; the selected inverse then has to be taken with selinv_mom(..., S=S, aS=aS)."""
+    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False, out=None, store_G=True,
+               moments_only=False):
+        """Block Cholesky (+ forward substitution).  Returns dict(L, G, y, logdet, quad, form).  store_G=False (d <= 8) skips the
+        L_{t+1,t} output; the selected inverse then has to be taken with selinv_mom(..., S=S, aS=aS).
+        moments_only=True says the factor arrays will only be handed to `selinv(..., form=f["form"])`: plans with d > 8 then use the
+        inverse form (mfgm_packed_factor_form, form 1), whose arrays are not Cholesky blocks."""
         out = {} if out is None else out
+        form = 1 if (moments_only and self.wide and store_G and os.environ.get("MFGM_INVERSE_FORM", "1") != "0") else 0
         L = out.get("L") if out.get("L") is not None else self.empty(TRI)
         G = None
         if store_G:
@@ -87,13 +93,13 @@ class Plan:
         self.epoch += 1
         logdet = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_logdet else None
         quad = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_quad else None
-        _lib.check(self.lib.mfgm_packed_factor(self.h, _ptr(D), _ptr(S), _ptr(r), float(aD), float(aS), float(aR),
-                                               _ptr(L), _ptr(G), _ptr(y), _ptr(logdet), _ptr(quad), _ptr(self.ws),
-                                               _ptr(self.info), _stream()), "mfgm_packed_factor")
-        return dict(L=L, G=G, y=y, logdet=logdet, quad=quad)
+        _lib.check(self.lib.mfgm_packed_factor_form(self.h, form, _ptr(D), _ptr(S), _ptr(r), float(aD), float(aS), float(aR),
+                                                    _ptr(L), _ptr(G), _ptr(y), _ptr(logdet), _ptr(quad), _ptr(self.ws),
+                                                    _ptr(self.info), _stream()), "mfgm_packed_factor_form")
+        return dict(L=L, G=G, y=y, logdet=logdet, quad=quad, form=form)
 
-    def selinv(self, L, G, y=None, want_sub=True, out=None):
-        """Selected inverse (+ backward substitution).  Returns dict(Sig, Sub, x)."""
+    def selinv(self, L, G, y=None, want_sub=True, out=None, form=0):
+        """Selected inverse (+ backward substitution).  Returns dict(Sig, Sub, x).  `form`: the form of the factor arrays (`factor`)."""
         out = {} if out is None else out
         Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
         Sub = None
@@ -102,8 +108,8 @@ class Plan:
         x = None
         if y is not None:
             x = out.get("x") if out.get("x") is not None else self.empty(VEC)
-        _lib.check(self.lib.mfgm_packed_selinv(self.h, _ptr(L), _ptr(G), _ptr(y), _ptr(Sig), _ptr(Sub), _ptr(x),
-                                               _ptr(self.ws), _stream()), "mfgm_packed_selinv")
+        _lib.check(self.lib.mfgm_packed_selinv_form(self.h, int(form), _ptr(L), _ptr(G), _ptr(y), _ptr(Sig), _ptr(Sub), _ptr(x),
+                                                    _ptr(self.ws), _stream()), "mfgm_packed_selinv_form")
         return dict(Sig=Sig, Sub=Sub, x=x)
 
     # -- local kernels --------------------------------------------------------------------------
