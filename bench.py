@@ -444,17 +444,39 @@ def bench_sparse(h, data_rank):
                   "partition": {"levels": pl.nlevels, "segment_len": pl.R, "segments": pl.P}})
     out["elbo_last"] = e
     if h.rank == 0:
-        # level-0 reduce of the MFMA sweeps alone (mfgm_packed_factor_phase 0: the memset of the level-1 inputs + km_reduce)
+        # the level-0 kernels of the MFMA sweeps alone (mfgm_wide_stage), on the model's own arrays, in the form the model uses
         lib = vidp_amd._lib.load()
         lin, diag, sub = m._theta()
-        f = m._sweep_bufs["f"]
+        m._marginals()
+        f, sv = m._sweep_bufs["f"], m._sweep_bufs["s"]
+        form = 1 if os.environ.get("MFGM_INVERSE_FORM", "1") != "0" else 0
+        null = None
 
-        def reduce0():
-            assert lib.mfgm_packed_factor_phase(pl.h, 0, _ptr(diag), _ptr(sub), _ptr(lin), -2.0, -1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]),
-                                                _ptr(f["y"]), None, None, _ptr(pl.ws), _ptr(pl.info), _stream()) == 0
-        out["roofline"] = h.roofline("mfgm::km_reduce<1, true, false> (+ the memset of the level-1 inputs)",
-                                     "level 0 reduce of the MFMA sweeps (one wavefront per segment, 16 x 16 fp64 MFMA tiles); reads D, S, r",
-                                     h.timed(reduce0), 8 * (2 * d * d + d) * M, 1, out["ms_per_step"])
+        def stage(which):
+            if which < 2:
+                rc = lib.mfgm_wide_stage(pl.h, form, which, _ptr(diag), _ptr(sub), _ptr(lin), -2.0, -1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]),
+                                         _ptr(f["y"]), null, null, null, _ptr(pl.ws), _ptr(pl.info), _stream())
+            else:
+                rc = lib.mfgm_wide_stage(pl.h, form, 2, null, null, null, 1.0, 1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]), _ptr(f["y"]),
+                                         _ptr(sv["Sig"]), _ptr(sv["Sub"]), _ptr(sv["x"]), _ptr(pl.ws), _ptr(pl.info), _stream())
+            assert rc == 0
+
+        pre = "kmi" if form == 1 else "km"
+        EF = d * d
+        rows = [h.roofline(f"mfgm::{pre}_{name}", what, h.timed(lambda w=w: stage(w)), 8 * dbl * M, 1, out["ms_per_step"])
+                for name, w, dbl, what in (
+                    ("forward<1, true, false, true>", 1, (2 * EF + d) + (2 * EF + d),
+                     "level 0 forward of the MFMA sweeps (one wavefront per segment, 16 x 16 fp64 MFMA tiles): pivot blocks inverted by 4 x 4 "
+                     "block sweeps; reads D, S, r, writes F^-1, S F^-1, F^-1 h" if form == 1 else
+                     "level 0 forward of the MFMA sweeps: block Cholesky + forward substitution; reads D, S, r, writes L, L_{t+1,t}, y"),
+                    ("reduce<1, true, false>", 0, 2 * EF + d, "level 0 reduce of the MFMA sweeps: segment elimination; reads D, S, r"),
+                    ("backward<1, true, true, true>", 2, (2 * EF + d) + (2 * EF + d),
+                     "level 0 backward of the MFMA sweeps: selected inverse + back-substitution; reads the factor arrays, writes Sigma_tt, "
+                     "Sigma_{t+1,t}, mu"))]
+        rows.sort(key=lambda r: -r["share_of_step"])
+        # these kernels are fp64-arithmetic bound, not HBM bound: per node the forward pass issues 16 and the reduce 28
+        # v_mfma_f64_16x16x4_f64 (64 cycles each on the one fp64 pipe of a SIMD) plus the pivot-block inverses
+        out["roofline"] = dict(rows[0], other_kernels=rows[1:])
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sparse(M, N)
     return out

@@ -454,6 +454,11 @@ int mfgm_packed_factor_stage(const mfgm_plan* plan, int stage, int level, const 
 int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, const double* G, const double* y, double* Sig,
                              double* Sub, double* x, void* ws, void* stream);
 
+/* the same for plans with 8 < d <= 32: the level-0 kernel of one pass alone (which 0 reduce, 1 forward: D, S, r, L, G, y as in
+ * mfgm_packed_factor_form; 2 backward: L, G, y, Sig, Sub, x as in mfgm_packed_selinv_form; unused arguments NULL) */
+int mfgm_wide_stage(const mfgm_plan* plan, int form, int which, const double* D, const double* S, const double* r, double aD, double aS,
+                    double aR, double* L, double* G, double* y, double* Sig, double* Sub, double* x, void* ws, int* info, void* stream);
+
 const char* mfgm_version(void);
 
 /* Natural [B, T, 3d] view (mu, diag Sigma_tt, diag Sigma_{t+1,t}) of the packed moment array written by

@@ -132,6 +132,28 @@ def test_inverse_form_wide(amd, rng, B, T, d, R0, Rup, with_rhs):
     assert_close(host(plan.unpack(amd.SYM, s2["Sig"])), Sd)
 
 
+@pytest.mark.parametrize("scale", [1e8, 1e-6])
+@pytest.mark.parametrize("B,T,d,R0,Rup", [(2, 64, 12, 8, 4), (1, 130, 16, 8, 8), (1, 60, 24, 6, 0)])
+def test_inverse_form_scaled(amd, rng, B, T, d, R0, Rup, scale):
+    """The inverse form on precision matrices of very large / very small magnitude (the Sum-of-Matern precisions of config 5 reach
+    1e8): relative accuracy must not depend on the scale."""
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    plan = amd.Plan(B, T, d, R0=R0, Rup=Rup)
+    f = plan.factor(plan.pack(amd.SYM, dev(scale * diag)), plan.pack(amd.FULL, dev(scale * sub)), plan.pack(amd.VEC, dev(scale * r)),
+                    want_logdet=True, want_quad=True, moments_only=True)
+    s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True, form=f["form"])
+    plan.check_info()
+    Ld, Ls = np_btd.cholesky(diag, sub)
+    Sd, Ss = np_btd.inverse_blocks(Ld, Ls)
+    assert_close(scale * host(plan.unpack(amd.SYM, s["Sig"])), Sd, rtol=1e-8)
+    assert_close(scale * host(plan.unpack(amd.FULL, s["Sub"], T - 1)), Ss, rtol=1e-8)
+    assert_close(host(plan.unpack(amd.VEC, s["x"])), np_btd.solve(Ld, Ls, np_btd.solve(Ld, Ls, r), transpose_left=True), rtol=1e-8)
+    np.testing.assert_allclose(host(f["logdet"]), np_btd.abs_log_det(Ld) + 0.5 * T * d * np.log(scale), rtol=1e-10)
+    y = np_btd.solve(Ld, Ls, r)
+    np.testing.assert_allclose(host(f["quad"]), scale * np.sum(y * y, axis=(-1, -2)), rtol=1e-8)
+
+
 def test_inverse_form_not_pd_and_narrow(amd, rng):
     B, T, d = 2, 40, 11
     diag, sub = random_dominant_btd(rng, (B,), T, d)
@@ -365,7 +387,8 @@ class _ThreadAllReduce:
 
 
 @pytest.mark.parametrize("d,T,R0,world", [(16, 400, 10, 4), (12, 333, 7, 3), (30, 200, 8, 2), (16, 64, 8, 8)])
-def test_one_chain_sharded_over_ranks(amd, rng, d, T, R0, world):
+@pytest.mark.parametrize("moments_only", [False, True])
+def test_one_chain_sharded_over_ranks(amd, rng, d, T, R0, world, moments_only):
     """SURVEY 8e, second row (config 5): one chain cut over `world` ranks (here threads sharing the GPU, each with its own plan,
     workspace and a copy of the inputs that is NaN outside the nodes the rank is entitled to read).  Every rank's slice of the
     factor, the marginals and the solve equals the single-process result; the log-determinant and |L^{-1} r|^2 are summed."""
@@ -377,11 +400,12 @@ def test_one_chain_sharded_over_ranks(amd, rng, d, T, R0, world):
     r = rng.normal(size=(B, T, d))
     whole = amd.Plan(B, T, d, R0=R0)
     Dp, Sp, rp = whole.pack(amd.SYM, dev(diag)), whole.pack(amd.FULL, dev(sub)), whole.pack(amd.VEC, dev(r))
-    f0 = whole.factor(Dp, Sp, rp, want_logdet=True, want_quad=True)
-    s0 = whole.selinv(f0["L"], f0["G"], f0["y"])
+    f0 = whole.factor(Dp, Sp, rp, want_logdet=True, want_quad=True, moments_only=moments_only)
+    s0 = whole.selinv(f0["L"], f0["G"], f0["y"], form=f0["form"])
     whole.check_info()
+    Lkind = amd.FULL if moments_only else amd.TRI          # inverse form: the "L" array holds the full blocks F_t^{-1}
     ref = {k: host(whole.unpack(kind, arr, n)) for k, kind, arr, n in (
-        ("L", amd.TRI, f0["L"], T), ("G", amd.FULL, f0["G"], T - 1), ("y", amd.VEC, f0["y"], T), ("Sig", amd.SYM, s0["Sig"], T),
+        ("L", Lkind, f0["L"], T), ("G", amd.FULL, f0["G"], T - 1), ("y", amd.VEC, f0["y"], T), ("Sig", amd.SYM, s0["Sig"], T),
         ("Sub", amd.FULL, s0["Sub"], T - 1), ("x", amd.VEC, s0["x"], T))}
     group = _ThreadAllReduce(world)
     out, errs = [None] * world, []
@@ -396,11 +420,12 @@ def test_one_chain_sharded_over_ranks(amd, rng, d, T, R0, world):
             slo, shi = max(lo - 1, 0), min(hi, T - 1)
             Sn[:, slo:shi] = sub[:, slo:shi]
             # the arrays of a wide plan are the natural ones: hand them over without the symmetrising pack
-            f = sh.factor(dev(Dn).reshape(-1), dev(Sn).reshape(-1), dev(rn).reshape(-1), want_logdet=True, want_quad=True)
-            s = sh.selinv(f["L"], f["G"], f["y"])
+            f = sh.factor(dev(Dn).reshape(-1), dev(Sn).reshape(-1), dev(rn).reshape(-1), want_logdet=True, want_quad=True,
+                          moments_only=moments_only)
+            s = sh.selinv(f["L"], f["G"], f["y"], form=f["form"])
             plan.check_info()
             res = {k: host(plan.unpack(kind, arr, n)) for k, kind, arr, n in (
-                ("L", amd.TRI, f["L"], T), ("G", amd.FULL, f["G"], T - 1), ("y", amd.VEC, f["y"], T), ("Sig", amd.SYM, s["Sig"], T),
+                ("L", Lkind, f["L"], T), ("G", amd.FULL, f["G"], T - 1), ("y", amd.VEC, f["y"], T), ("Sig", amd.SYM, s["Sig"], T),
                 ("Sub", amd.FULL, s["Sub"], T - 1), ("x", amd.VEC, s["x"], T))}
             out[rank] = (lo, hi, res, host(f["logdet"]), host(f["quad"]))
         except Exception as e:      # surfaced in the main thread

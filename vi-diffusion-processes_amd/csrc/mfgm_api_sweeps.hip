@@ -610,6 +610,16 @@ int mfgm_packed_factor_stage(const mfgm_plan* plan, int stage, int level, const 
     MFGM_DISPATCH_D(P.d, (factor_impl<DD>(P, D, S, r, aD, aS, aR, L, G, y, nullptr, nullptr, (double*)ws, info, st, stage, level)));
 }
 
+int mfgm_wide_stage(const mfgm_plan* plan, int form, int which, const double* D, const double* S, const double* r, double aD, double aS,
+                    double aR, double* L, double* G, double* y, double* Sig, double* Sub, double* x, void* ws, int* info, void* stream) {
+    if (!plan || !L || !G || !info || !ws) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide) return 1;
+    if (which < 2 && (!D || !S || (r != nullptr) != (y != nullptr))) return 1;
+    if (which == 2 && (!Sig || (y != nullptr) != (x != nullptr))) return 1;
+    return wide_stage(P, form, which, D, S, r, aD, aS, aR, L, G, y, Sig, Sub, x, (double*)ws, info, (hipStream_t)stream);
+}
+
 int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, const double* G, const double* y, double* Sig,
                              double* Sub, double* x, void* ws, void* stream) {
     if (!plan || !L || !G || !Sig) return 1;

@@ -209,6 +209,23 @@ int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double*
 }
 
 
+// one level-0 kernel alone (which 0 reduce, 1 forward, 2 backward) with the coarser levels already in ws
+int wide_stage(const Plan& P, int form, int which, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
+               double* Lg, double* Gg, double* yg, double* Sig, double* Sub, double* x, double* ws, int* info, hipStream_t st) {
+    if ((form != 0 && form != 1) || which < 0 || which > 2) return 1;
+    const int K = P.nlevels - 1;
+    if (which == 0 && K == 0) return 1;
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.info = info;
+    a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
+    a.Lg = Lg; a.Gg = Gg; a.yg = yg;
+    a.Sigg = Sig; a.Subg = Sub; a.mug = x;
+    wide_bind(P, 0, ws, a);
+    if (which < 2) return wide_dispatch(P.d, which, a, rg != nullptr, false, K > 0, false, st, form);
+    return wide_dispatch(P.d, 2, a, yg != nullptr, false, K > 0, Sub != nullptr, st, form);
+}
+
 int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
                          double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st) {
     double* part = sumlogchol ? ws + P.off_part[0] : nullptr;

@@ -17,8 +17,9 @@
 //      T = D^{-1} P            one MFMA  (A operand: D^{-1} in the lanes (g, c < 4); B operand: the panel, i.e. the lane's own register)
 //      A <- A - P^T T          one MFMA  (both operands are the lane's own registers)
 //      rows of the block <- T, pivot block <- -D^{-1}
-// and after the four sweeps A = -F^{-1}.  The only cross-lane traffic is the read of the 10 distinct entries of D (v_readlane);
-// D^{-1} is formed redundantly by every lane from two 2 x 2 determinants, whose product also accumulates log|F|.
+// and after the four sweeps A = -F^{-1}.  The only cross-lane traffic is the read of the 10 distinct entries of D (v_readlane) and a
+// 16-double LDS table that puts D^{-1} into the lanes (g, c < 4); D^{-1} is formed redundantly by every lane from two 2 x 2
+// determinants, whose product also accumulates log|F|.
 #pragma once
 #include "mfgm_mfma.h"
 
@@ -66,8 +67,9 @@ MFGM_DEV Sym4 inv4(const Sym4& m, double& detP, double& detS, int& bad) {
 
 // A <- A^{-1} for a symmetric positive definite matrix (identity padded), la *= det A
 template <int NT>
-MFGM_DEV void sweep_inv(Mat<NT>& A, const LaneId& L, LogAcc& la, int& bad) {
+MFGM_DEV void sweep_inv(Mat<NT>& A, const LaneId& L, LogAcc& la, int& bad, double* lds) {
     const int cl = L.c & 3;
+    const int ehi = max(L.g, cl), elo = min(L.g, cl), eidx = ehi * (ehi + 1) / 2 + elo;      // packed lower triangle
 #pragma unroll
     for (int J = 0; J < NT; ++J)
 #pragma unroll
@@ -84,22 +86,29 @@ MFGM_DEV void sweep_inv(Mat<NT>& A, const LaneId& L, LogAcc& la, int& bad) {
             la.mul(detP);
             la.mul(detS);
             la.renorm();
-            // lane (g, c < 4): Di[g][c]
-            const double r0 = (cl == 0) ? Di.a00 : (cl == 1) ? Di.a10 : (cl == 2) ? Di.a20 : Di.a30;
-            const double r1 = (cl == 0) ? Di.a10 : (cl == 1) ? Di.a11 : (cl == 2) ? Di.a21 : Di.a31;
-            const double r2 = (cl == 0) ? Di.a20 : (cl == 1) ? Di.a21 : (cl == 2) ? Di.a22 : Di.a32;
-            const double r3 = (cl == 0) ? Di.a30 : (cl == 1) ? Di.a31 : (cl == 2) ? Di.a32 : Di.a33;
-            double e = (L.g == 0) ? r0 : (L.g == 1) ? r1 : (L.g == 2) ? r2 : r3;
+            // lane (g, c < 4): Di[g][c] -- through a 16-double table in LDS (one lane writes it, every lane reads its entry), which
+            // costs a third of the instructions of selecting among the 10 uniform values lane by lane
+            if (L.lane == 0) {
+                lds[0] = Di.a00; lds[1] = Di.a10; lds[2] = Di.a11; lds[3] = Di.a20; lds[4] = Di.a21;
+                lds[5] = Di.a22; lds[6] = Di.a30; lds[7] = Di.a31; lds[8] = Di.a32; lds[9] = Di.a33;
+            }
+            __builtin_amdgcn_wave_barrier();
+            double e = lds[eidx];
+            __builtin_amdgcn_wave_barrier();
             e = (L.c < 4) ? e : 0.0;
             const bool inK = (L.c >> 2) == k;          // a pivot column (of tile column J)
+            const double eye = (inK && cl == L.g) ? 1.0 : 0.0;
             double Tpp[NT];
 #pragma unroll
             for (int Jc = 0; Jc < NT; ++Jc) {
                 double bop = A.t[J][Jc].r[k];
-                if (Jc == J) bop = inK ? ((cl == L.g) ? 1.0 : 0.0) : bop;      // identity in the pivot columns: T there is D^{-1}
+                if (Jc == J) bop = inK ? eye : bop;                            // identity in the pivot columns: T there is D^{-1}
                 const Tile t = mfma1(e, bop, tile_zero());
                 Tpp[Jc] = (Jc == J && inK) ? -t.r[0] : t.r[0];
             }
+            // A <- A - P^T T''; in the pivot columns of the other rows the old entries are REPLACED by P^T D^{-1}, so the accumulator is
+            // zeroed there.  (Subtracting P^T (T'' + I) instead, which is the same thing for an exactly symmetric A, leaves the rounding
+            // asymmetry of A behind at the scale of A, and T is smaller than A by the size of the pivot block: not done.)
 #pragma unroll
             for (int I = 0; I < NT; ++I) {
                 double aop = -A.t[J][I].r[k];
@@ -120,18 +129,6 @@ MFGM_DEV void sweep_inv(Mat<NT>& A, const LaneId& L, LogAcc& la, int& bad) {
     A = mat_neg<NT>(A);
 }
 
-// sum_r a_r b_r of two vectors (uniform result)
-template <int NT>
-MFGM_DEV double vec_dot(const Vec<NT>& x, const Vec<NT>& y, const LaneId& L) {
-    double q = 0.0;
-#pragma unroll
-    for (int I = 0; I < NT; ++I)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q = __builtin_fma(x.t[I].r[i], y.t[I].r[i], q);
-    q = (L.c == 0) ? q : 0.0;
-    return bcast(q, 0) + bcast(q, 16) + bcast(q, 32) + bcast(q, 48);
-}
-
 template <int NT>
 MFGM_DEV Mat<NT> mat_add(const Mat<NT>& a, const Mat<NT>& b) {
     Mat<NT> o;
@@ -143,28 +140,126 @@ MFGM_DEV Mat<NT> mat_add(const Mat<NT>& a, const Mat<NT>& b) {
             for (int i = 0; i < 4; ++i) o.t[I][J].r[i] = a.t[I][J].r[i] + b.t[I][J].r[i];
     return o;
 }
+
+// transpose through LDS (one 16 x 16 tile at a time, 17-double row stride); one wavefront, LDS accesses in program order
 template <int NT>
-MFGM_DEV Vec<NT> vec_add(const Vec<NT>& a, const Vec<NT>& b) {
-    Vec<NT> o;
+MFGM_DEV Mat<NT> mat_transpose_w(const Mat<NT>& m, double* lds, const LaneId& L) {
+    Mat<NT> o;
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o.t[I].r[i] = a.t[I].r[i] + b.t[I].r[i];
+        for (int J = 0; J < NT; ++J) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds[(L.g + 4 * i) * 17 + L.c] = m.t[I][J].r[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o.t[J][I].r[i] = lds[L.c * 17 + L.g + 4 * i];
+            __builtin_amdgcn_wave_barrier();
+        }
+    return o;
+}
+
+// ---- vectors on the vector ALU -------------------------------------------------------------------------------------------------------
+// A d-vector next to accumulator-layout tiles comes in two shapes: by COLUMN (lane (g, c) holds v[16 J + c], the same in the four
+// 16-lane rows) and by ROW (lane (g, c) holds v[16 I + g + 4 i], i = 0..3, the same in the 16 lanes of a row).  M^T x of a tile matrix
+// with x by row is four FMAs per tile and lane plus a sum over the four 16-lane rows (v_permlane32_swap / v_permlane16_swap), and
+// comes out by column; the pivot inverses and Sigma are symmetric, so every matrix-vector product of the sweeps has this shape.
+// Column -> row goes through 16 NT doubles of LDS.  (As tile columns of an MFMA the same products cost four MFMAs each.)
+template <int NT>
+struct RowVec {
+    double r[NT][4];
+};
+template <int NT>
+struct ColVec {
+    double c[NT];
+};
+
+MFGM_DEV double sum_rows(double x) {
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double u = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(u);
+    hi = __double2hiint(u);
+    const auto c = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto e = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(e[0], c[0]) + __hiloint2double(e[1], c[1]);
+}
+
+// acc + sign * M^T x
+template <int NT>
+MFGM_DEV ColVec<NT> tmatvec(const Mat<NT>& M, const RowVec<NT>& x, const ColVec<NT>& acc, double sign) {
+    ColVec<NT> y;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) {
+        double p = 0.0;
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p = __builtin_fma(M.t[I][J].r[i], x.r[I][i], p);
+        y.c[J] = __builtin_fma(sign, sum_rows(p), acc.c[J]);
+    }
+    return y;
+}
+template <int NT>
+MFGM_DEV ColVec<NT> col_zero() {
+    ColVec<NT> v;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) v.c[J] = 0.0;
+    return v;
+}
+template <int NT>
+MFGM_DEV ColVec<NT> col_sub(const ColVec<NT>& a, const ColVec<NT>& b) {
+    ColVec<NT> v;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) v.c[J] = a.c[J] - b.c[J];
+    return v;
+}
+template <int NT>
+MFGM_DEV ColVec<NT> col_add(const ColVec<NT>& a, const ColVec<NT>& b) {
+    ColVec<NT> v;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) v.c[J] = a.c[J] + b.c[J];
+    return v;
+}
+// lds: 16 NT doubles; the workgroup is one wavefront, whose LDS accesses execute in program order
+template <int NT>
+MFGM_DEV RowVec<NT> to_row(const ColVec<NT>& v, double* lds, const LaneId& L) {
+    if (L.g == 0) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J) lds[16 * J + L.c] = v.c[J];
+    }
+    __builtin_amdgcn_wave_barrier();
+    RowVec<NT> o;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.r[I][i] = lds[16 * I + L.g + 4 * i];
+    __builtin_amdgcn_wave_barrier();
     return o;
 }
 template <int NT>
-MFGM_DEV Vec<NT> vec_neg(const Vec<NT>& a) {
-    Vec<NT> o;
+MFGM_DEV ColVec<NT> ld_col(const double* __restrict__ v, int d, const LaneId& L, double scale) {
+    ColVec<NT> o;
+    double x[NT];
 #pragma unroll
-    for (int I = 0; I < NT; ++I)
+    for (int J = 0; J < NT; ++J) x[J] = v[(16 * J + L.c < d) ? 16 * J + L.c : 0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o.t[I].r[i] = -a.t[I].r[i];
+    for (int J = 0; J < NT; ++J) o.c[J] = x[J] * ((16 * J + L.c < d) ? scale : 0.0);
     return o;
+}
+template <int NT>
+MFGM_DEV void st_col(double* __restrict__ v, int d, const LaneId& L, const ColVec<NT>& a) {
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+        if (L.g == 0 && 16 * J + L.c < d) v[16 * J + L.c] = a.c[J];
 }
 
 // ---- reduce ------------------------------------------------------------------------------------------------------------------------
 template <int NT, bool HAS_RHS, bool HAS_CORR>
 static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
+    __shared__ double lds[16 * NT];
+    __shared__ double ldsE[16];
     const LaneId L{(int)threadIdx.x, (int)threadIdx.x >> 4, (int)threadIdx.x & 15};
     const int d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
@@ -179,21 +274,21 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
         return F;
     };
     auto ld_h = [&](int t) {
-        Vec<NT> h = ld_vec<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
-        if (HAS_CORR) h = vec_sub<NT>(h, ld_vec<NT>(wblk(a.rcorr, b, n, t, d), d, L, 1.0));
+        ColVec<NT> h = ld_col<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
+        if (HAS_CORR) h = col_sub<NT>(h, ld_col<NT>(wblk(a.rcorr, b, n, t, d), d, L, 1.0));
         return h;
     };
     Mat<NT> F = ld_F(t0);
     Mat<NT> W = (p > 0) ? ld_mat<NT, false, false>(wblk(a.Sg, b, n, t0 - 1, EF), d, L, a.aS) : mat_zero<NT>();
-    Vec<NT> h = HAS_RHS ? ld_h(t0) : vec_zero<NT>();
+    ColVec<NT> hc = HAS_RHS ? ld_h(t0) : col_zero<NT>();
     Mat<NT> Racc = mat_zero<NT>();
-    Vec<NT> rho = vec_zero<NT>();
+    ColVec<NT> rho = col_zero<NT>();
     for (int s = 0; s < len - 1; ++s) {
         const int t = t0 + s;
         const Mat<NT> St = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS);      // S^T
         Mat<NT> Fn = ld_F(t + 1);
-        Vec<NT> hn = HAS_RHS ? ld_h(t + 1) : vec_zero<NT>();
-        sweep_inv<NT>(F, L, la, bad);                          // (the determinant is not an output of this pass)
+        ColVec<NT> hn = HAS_RHS ? ld_h(t + 1) : col_zero<NT>();
+        sweep_inv<NT>(F, L, la, bad, ldsE);                          // (the determinant is not an output of this pass)
         const Mat<NT> nSt = mat_neg<NT>(St);
         const Mat<NT> TW = gram<NT>(F, W);                     // F^{-1} W
         {
@@ -202,26 +297,26 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
         }
         Racc = gram<NT>(W, TW, Racc);                          // R += W^T F^{-1} W
         if (HAS_RHS) {
-            const Vec<NT> th = gram<NT>(F, h);                 // F^{-1} h
-            rho = gram<NT>(W, th, rho);
-            hn = gram<NT>(nSt, th, hn);
+            const RowVec<NT> th = to_row<NT>(tmatvec<NT>(F, to_row<NT>(hc, lds, L), col_zero<NT>(), 1.0), lds, L);      // F^{-1} h
+            rho = tmatvec<NT>(W, th, rho, 1.0);
+            hn = tmatvec<NT>(St, th, hn, -1.0);
         }
         W = gram<NT>(nSt, TW);                                 // W' = -S F^{-1} W
         F = Fn;
-        h = hn;
+        hc = hn;
     }
     const int un = a.up.n;
     st_mat<NT, false>(wblk(a.uDhat, b, un, p, EF), d, L, F);
-    st_vec<NT>(wblk(a.urhat, b, un, p, d), d, L, h);
+    st_col<NT>(wblk(a.urhat, b, un, p, d), d, L, hc);
     if (p == P - 1) {
         st_mat<NT, false>(wblk(a.uRsub, b, un, p, EF), d, L, mat_zero<NT>());
         st_mat<NT, false>(wblk(a.uS, b, un, p, EF), d, L, mat_zero<NT>());
-        st_vec<NT>(wblk(a.urho, b, un, p, d), d, L, vec_zero<NT>());
+        st_col<NT>(wblk(a.urho, b, un, p, d), d, L, col_zero<NT>());
     }
     if (p > 0) {
         st_mat<NT, false>(wblk(a.uS, b, un, p - 1, EF), d, L, W);
         st_mat<NT, false>(wblk(a.uRsub, b, un, p - 1, EF), d, L, Racc);
-        st_vec<NT>(wblk(a.urho, b, un, p - 1, d), d, L, rho);
+        st_col<NT>(wblk(a.urho, b, un, p - 1, d), d, L, rho);
     }
     if (bad && L.lane == 0) atomicMax(a.info, 1);
 }
@@ -231,6 +326,9 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
 // backward pass fills later): the level below rebuilds the state on its separators from them,  F_a = F~ + R_p,  h_a = h~ + rho_p.
 template <int NT, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
 static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
+    __shared__ double lds[16 * NT];
+    __shared__ double ldsT[16 * 17];
+    __shared__ double ldsE[16];
     const LaneId L{(int)threadIdx.x, (int)threadIdx.x >> 4, (int)threadIdx.x & 15};
     const int d = a.d, EF = d * d;
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
@@ -240,62 +338,87 @@ static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
     LogAcc la;
     la.init();
     Mat<NT> C = mat_zero<NT>();
-    Vec<NT> cv = vec_zero<NT>();
+    ColVec<NT> cv = col_zero<NT>();
     if (HAS_UP && p > 0) {
         const int un = a.up.n;
         Mat<NT> Fa = ld_mat<NT, false, true>(wblk(a.uSig, b, un, p - 1, EF), d, L, 1.0);
         Fa = mat_add<NT>(Fa, ld_mat<NT, false, false>(wblk(a.uRsub, b, un, p - 1, EF), d, L, 1.0));
         const Mat<NT> Sat = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t0 - 1, EF), d, L, a.aS);
-        Vec<NT> ha = vec_zero<NT>();
-        if (HAS_RHS) ha = vec_add<NT>(ld_vec<NT>(wblk(a.umu, b, un, p - 1, d), d, L, 1.0), ld_vec<NT>(wblk(a.urho, b, un, p - 1, d), d, L, 1.0));
-        sweep_inv<NT>(Fa, L, la, bad);
+        ColVec<NT> ha = col_zero<NT>();
+        if (HAS_RHS) ha = col_add<NT>(ld_col<NT>(wblk(a.umu, b, un, p - 1, d), d, L, 1.0), ld_col<NT>(wblk(a.urho, b, un, p - 1, d), d, L, 1.0));
+        const bool keep = (a.store_left && p == a.seg_lo);     // sharded chain: see WideArgs::store_left
+        if (keep && a.Sigg) {                                  // ... and the level below rebuilds its own boundary from this node
+            st_mat<NT, false>(wblk(a.Sigg, b, n, t0 - 1, EF), d, L, Fa);
+            if (HAS_RHS) st_col<NT>(wblk(a.mug, b, n, t0 - 1, d), d, L, ha);
+        }
+        sweep_inv<NT>(Fa, L, la, bad, ldsE);
         la.init();                                             // that node's determinant is counted where it is owned
         const Mat<NT> Ja = gram<NT>(Fa, Sat);
         C = gram<NT>(Sat, Ja);
-        const bool keep = (a.store_left && p == a.seg_lo);     // sharded chain: see WideArgs::store_left
         if (keep) {
             st_mat<NT, false>(wblk(a.Lg, b, n, t0 - 1, EF), d, L, Fa);
-            st_mat<NT, true>(wblk(a.Gg, b, n, t0 - 1, EF), d, L, Ja);
+            st_mat<NT, false>(wblk(a.Gg, b, n, t0 - 1, EF), d, L, mat_transpose_w<NT>(Ja, ldsT, L));
         }
         if (HAS_RHS) {
-            const Vec<NT> za = gram<NT>(Fa, ha);
-            if (keep) st_vec<NT>(wblk(a.yg, b, n, t0 - 1, d), d, L, za);
-            cv = gram<NT>(Sat, za);
+            const ColVec<NT> za = tmatvec<NT>(Fa, to_row<NT>(ha, lds, L), col_zero<NT>(), 1.0);
+            if (keep) st_col<NT>(wblk(a.yg, b, n, t0 - 1, d), d, L, za);
+            cv = tmatvec<NT>(Sat, to_row<NT>(za, lds, L), col_zero<NT>(), 1.0);
         }
     }
-    double quad = 0.0;
-    for (int s = 0; s < len; ++s) {
-        const int t = t0 + s;
+    double quad = 0.0;                       // per lane: sum over the nodes of h_c z_c for the lane's column
+    // the inputs of a node are loaded one node ahead: the pivot inverse of the current node covers their latency
+    auto ld_node_F = [&](int t) {
         Mat<NT> F = ld_mat<NT, false, true>(wblk(a.Dg, b, n, t, EF), d, L, a.aD);
         if (HAS_CORR) F = mat_sub<NT>(F, ld_mat<NT, false, false>(wblk(a.Dcorr, b, n, t, EF), d, L, 1.0));
-        F = mat_sub<NT>(F, C);
-        Vec<NT> h = vec_zero<NT>();
+        return F;
+    };
+    auto ld_node_S = [&](int t) { return (t + 1 < n) ? ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS) : mat_zero<NT>(); };
+    auto ld_node_h = [&](int t) {
+        ColVec<NT> h = col_zero<NT>();
         if (HAS_RHS) {
-            h = ld_vec<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
-            if (HAS_CORR) h = vec_sub<NT>(h, ld_vec<NT>(wblk(a.rcorr, b, n, t, d), d, L, 1.0));
-            h = vec_sub<NT>(h, cv);
+            h = ld_col<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
+            if (HAS_CORR) h = col_sub<NT>(h, ld_col<NT>(wblk(a.rcorr, b, n, t, d), d, L, 1.0));
         }
+        return h;
+    };
+    Mat<NT> Fraw = ld_node_F(t0), Sraw = ld_node_S(t0);
+    ColVec<NT> hraw = ld_node_h(t0);
+    for (int s = 0; s < len; ++s) {
+        const int t = t0 + s;
+        Mat<NT> F = mat_sub<NT>(Fraw, C);
+        const ColVec<NT> h = col_sub<NT>(hraw, cv);
+        const Mat<NT> St = Sraw;
         const bool has_next = (t + 1 < n);
-        const Mat<NT> St = has_next ? ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS) : mat_zero<NT>();
+        if (s + 1 < len) {
+            Fraw = ld_node_F(t + 1);
+            Sraw = ld_node_S(t + 1);
+            hraw = ld_node_h(t + 1);
+        }
         if (a.Sigg) {
             st_mat<NT, false>(wblk(a.Sigg, b, n, t, EF), d, L, F);
-            if (HAS_RHS) st_vec<NT>(wblk(a.mug, b, n, t, d), d, L, h);
+            if (HAS_RHS) st_col<NT>(wblk(a.mug, b, n, t, d), d, L, h);
         }
-        sweep_inv<NT>(F, L, la, bad);
+        sweep_inv<NT>(F, L, la, bad, ldsE);
         st_mat<NT, false>(wblk(a.Lg, b, n, t, EF), d, L, F);
         const Mat<NT> J = gram<NT>(F, St);                     // F^{-1} S^T
-        if (has_next) st_mat<NT, true>(wblk(a.Gg, b, n, t, EF), d, L, J);
+        if (has_next) st_mat<NT, false>(wblk(a.Gg, b, n, t, EF), d, L, mat_transpose_w<NT>(J, ldsT, L));     // S F^{-1}, rows contiguous
         C = gram<NT>(St, J);
         if (HAS_RHS) {
-            const Vec<NT> z = gram<NT>(F, h);
-            st_vec<NT>(wblk(a.yg, b, n, t, d), d, L, z);
-            cv = gram<NT>(St, z);
-            quad += vec_dot<NT>(h, z, L);
+            const ColVec<NT> z = tmatvec<NT>(F, to_row<NT>(h, lds, L), col_zero<NT>(), 1.0);
+            st_col<NT>(wblk(a.yg, b, n, t, d), d, L, z);
+            cv = tmatvec<NT>(St, to_row<NT>(z, lds, L), col_zero<NT>(), 1.0);
+#pragma unroll
+            for (int J = 0; J < NT; ++J) quad = __builtin_fma(h.c[J], z.c[J], quad);
         }
     }
-    if (a.part && L.lane == 0) {
-        a.part[b * P + p] = 0.5 * la.value();
-        a.part[a.lv.Lpad + b * P + p] = quad;
+    if (a.part) {
+        quad = (L.g == 0) ? quad : 0.0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) quad += __shfl_xor(quad, off, 64);
+        if (L.lane == 0) {
+            a.part[b * P + p] = 0.5 * la.value();
+            a.part[a.lv.Lpad + b * P + p] = quad;
+        }
     }
     if (bad && L.lane == 0) atomicMax(a.info, 1);
 }
@@ -303,29 +426,30 @@ static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
 // ---- backward ----------------------------------------------------------------------------------------------------------------------
 template <int NT, bool HAS_RHS, bool HAS_UP, bool WANT_SUB>
 static __global__ __launch_bounds__(64) void kmi_backward(WideArgs a) {
+    __shared__ double lds[16 * NT];
     const LaneId L{(int)threadIdx.x, (int)threadIdx.x >> 4, (int)threadIdx.x & 15};
     const int d = a.d, EF = d * d;
     const int R = a.lv.R, n = a.lv.n;
     const int b = blockIdx.x / a.nseg, p = a.seg_lo + ((int)blockIdx.x - b * a.nseg);
     const int t0 = p * R, len = min(R, n - t0), te = t0 + len - 1;
     Mat<NT> Sn;
-    Vec<NT> xn = vec_zero<NT>();
+    ColVec<NT> xn = col_zero<NT>();
     if (HAS_UP) {
         Sn = ld_mat<NT, false, false>(wblk(a.uSig, b, a.up.n, p, EF), d, L, 1.0);
-        if (HAS_RHS) xn = ld_vec<NT>(wblk(a.umu, b, a.up.n, p, d), d, L, 1.0);
+        if (HAS_RHS) xn = ld_col<NT>(wblk(a.umu, b, a.up.n, p, d), d, L, 1.0);
     } else {
         Sn = ld_mat<NT, false, false>(wblk(a.Lg, b, n, te, EF), d, L, 1.0);
-        if (HAS_RHS) xn = ld_vec<NT>(wblk(a.yg, b, n, te, d), d, L, 1.0);
+        if (HAS_RHS) xn = ld_col<NT>(wblk(a.yg, b, n, te, d), d, L, 1.0);
     }
     st_mat<NT, false>(wblk(a.Sigg, b, n, te, EF), d, L, Sn);
-    if (HAS_RHS) st_vec<NT>(wblk(a.mug, b, n, te, d), d, L, xn);
+    if (HAS_RHS) st_col<NT>(wblk(a.mug, b, n, te, d), d, L, xn);
     auto step = [&](int t, bool write_node) {
         const Mat<NT> Jt = ld_mat<NT, false, false>(wblk(a.Gg, b, n, t, EF), d, L, 1.0);      // S F^{-1}
         Mat<NT> Fi = mat_zero<NT>();
-        Vec<NT> z = vec_zero<NT>();
+        ColVec<NT> z = col_zero<NT>();
         if (write_node) {
             Fi = ld_mat<NT, false, false>(wblk(a.Lg, b, n, t, EF), d, L, 1.0);
-            if (HAS_RHS) z = ld_vec<NT>(wblk(a.yg, b, n, t, d), d, L, 1.0);
+            if (HAS_RHS) z = ld_col<NT>(wblk(a.yg, b, n, t, d), d, L, 1.0);
         }
         const Mat<NT> U = gram<NT>(Sn, Jt);                    // Sigma_n S F^{-1}
         if (WANT_SUB) st_mat<NT, false>(wblk(a.Subg, b, n, t, EF), d, L, mat_neg<NT>(U));
@@ -333,8 +457,8 @@ static __global__ __launch_bounds__(64) void kmi_backward(WideArgs a) {
         const Mat<NT> Sig = gram<NT>(Jt, U, Fi);
         st_mat<NT, false>(wblk(a.Sigg, b, n, t, EF), d, L, Sig);
         if (HAS_RHS) {
-            xn = gram<NT>(mat_neg<NT>(Jt), xn, z);
-            st_vec<NT>(wblk(a.mug, b, n, t, d), d, L, xn);
+            xn = tmatvec<NT>(Jt, to_row<NT>(xn, lds, L), z, -1.0);
+            st_col<NT>(wblk(a.mug, b, n, t, d), d, L, xn);
         }
         Sn = Sig;
     };

@@ -95,8 +95,9 @@ class ChainShard:
         self.seg_lo, self.seg_hi = self.node_lo // levels[0][1], -(-self.node_hi // levels[0][1])
         self._allreduce = allreduce if allreduce is not None else allreduce_sum_
 
-    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False):
-        """Block Cholesky of the sharded chain.  Returns dict(L, G, y, logdet, quad) with logdet / quad already summed over ranks."""
+    def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False, moments_only=False):
+        """Block Cholesky of the sharded chain.  Returns dict(L, G, y, logdet, quad, form) with logdet / quad already summed over ranks.
+        moments_only: the factor arrays are only handed to `selinv(..., form=f["form"])` (inverse form, see Plan.factor)."""
         from ._lib import FULL, TRI, VEC, check
         from .packed import _ptr, _stream
         pl = self.plan
@@ -107,15 +108,16 @@ class ChainShard:
         quad = torch.empty(pl.B, dtype=torch.float64, device=pl.device) if want_quad else None
         args = (_ptr(D), _ptr(S), _ptr(r), float(aD), float(aS), float(aR), _ptr(L), _ptr(G), _ptr(y), _ptr(logdet), _ptr(quad),
                 _ptr(pl.ws), _ptr(pl.info), _stream())
-        check(pl.lib.mfgm_packed_factor_phase(pl.h, 0, *args), "mfgm_packed_factor_phase(0)")
+        form = 1 if moments_only else 0
+        check(pl.lib.mfgm_packed_factor_phase_form(pl.h, form, 0, *args), "mfgm_packed_factor_phase_form(0)")
         self._allreduce(self.exchange)
-        check(pl.lib.mfgm_packed_factor_phase(pl.h, 1, *args), "mfgm_packed_factor_phase(1)")
+        check(pl.lib.mfgm_packed_factor_phase_form(pl.h, form, 1, *args), "mfgm_packed_factor_phase_form(1)")
         if logdet is not None:
             self._allreduce(logdet)
         if quad is not None:
             self._allreduce(quad)
-        return dict(L=L, G=G, y=y, logdet=logdet, quad=quad)
+        return dict(L=L, G=G, y=y, logdet=logdet, quad=quad, form=form)
 
-    def selinv(self, L, G, y=None, want_sub=True):
+    def selinv(self, L, G, y=None, want_sub=True, form=0):
         """Selected inverse on the owned nodes (no communication: the levels from the exchange level up are replicated)."""
-        return self.plan.selinv(L, G, y, want_sub=want_sub)
+        return self.plan.selinv(L, G, y, want_sub=want_sub, form=form)

@@ -135,9 +135,9 @@ class SparseCVIGaussianProcess:
         pl, T, d = p.plan, p.T, p.d
         lin, diag, sub = self._theta()
         bufs = self.__dict__.setdefault("_sweep_bufs", dict(f={}, s={}))
-        f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=bufs["f"])
+        f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=bufs["f"], moments_only=True)
         bufs["f"].update(L=f["L"], G=f["G"], y=f["y"])
-        s = pl.selinv(f["L"], f["G"], f["y"], want_sub=True, out=bufs["s"])
+        s = pl.selinv(f["L"], f["G"], f["y"], want_sub=True, out=bufs["s"], form=f["form"])
         bufs["s"].update(Sig=s["Sig"], Sub=s["Sub"], x=s["x"])
         if pl.d > 8:
             mu, Sig, Sub = s["x"].view(T, d), s["Sig"].view(T, d, d), s["Sub"].view(T, d, d)
