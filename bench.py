@@ -419,7 +419,9 @@ def bench_sparse(h, data_rank):
     from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
     a, device = h.args, h.device
     M, d = 200000, 16
-    N, span = 2 * M, 0.01 * M
+    # grid spacing 0.1: rho = spacing / lengthscale >= 0.05 as in config 2 ("value ranges keep every Q_k SPD with cond <~ 1e8";
+    # at spacing 0.01 the Matern-5/2 component with lengthscale 2 makes the prior precision numerically singular in fp64, cond ~ 1e15)
+    N, span = 2 * M, 0.1 * M
     rng = np.random.default_rng(71892305 + 5 + data_rank)
     z = torch.linspace(0, span, M, dtype=torch.float64, device=device)
     t = torch.from_numpy(np.sort(rng.uniform(0, span, size=N))).to(device)
@@ -446,30 +448,37 @@ def bench_sparse(h, data_rank):
     if h.rank == 0:
         # the level-0 kernels of the MFMA sweeps alone (mfgm_wide_stage), on the model's own arrays, in the form the model uses
         lib = vidp_amd._lib.load()
-        lin, diag, sub = m._theta()
         m._marginals()
         f, sv = m._sweep_bufs["f"], m._sweep_bufs["s"]
-        form = 1 if os.environ.get("MFGM_INVERSE_FORM", "1") != "0" else 0
+        form = f.get("form", 0)
+        fused = m._fused_theta()       # the passes read the prior naturals + the sites instead of materialised posterior naturals
         null = None
+        if fused:
+            pn = m._prior_natural()
+            lin, diag, sub, s1, s2 = pn["lin"], pn["diag"], pn["sub"], m.nat1, m.nat2
+        else:
+            (lin, diag, sub), s1, s2 = m._theta(), None, None
 
         def stage(which):
             if which < 2:
                 rc = lib.mfgm_wide_stage(pl.h, form, which, _ptr(diag), _ptr(sub), _ptr(lin), -2.0, -1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]),
-                                         _ptr(f["y"]), null, null, null, _ptr(pl.ws), _ptr(pl.info), _stream())
+                                         _ptr(f["y"]), null, null, null, _ptr(s1), _ptr(s2), _ptr(pl.ws), _ptr(pl.info), _stream())
             else:
                 rc = lib.mfgm_wide_stage(pl.h, form, 2, null, null, null, 1.0, 1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]), _ptr(f["y"]),
-                                         _ptr(sv["Sig"]), _ptr(sv["Sub"]), _ptr(sv["x"]), _ptr(pl.ws), _ptr(pl.info), _stream())
+                                         _ptr(sv["Sig"]), _ptr(sv["Sub"]), _ptr(sv["x"]), null, null, _ptr(pl.ws), _ptr(pl.info), _stream())
             assert rc == 0
 
         pre = "kmi" if form == 1 else "km"
         EF = d * d
+        rd = (2 * EF + d) + (3 * EF + 2 * d) if fused else (2 * EF + d)      # fused: prior naturals + three site quadrants + site vectors
         rows = [h.roofline(f"mfgm::{pre}_{name}", what, h.timed(lambda w=w: stage(w)), 8 * dbl * M, 1, out["ms_per_step"])
                 for name, w, dbl, what in (
-                    ("forward<1, true, false, true>", 1, (2 * EF + d) + (2 * EF + d),
+                    ("forward<1, true, false, true>", 1, rd + (2 * EF + d),
                      "level 0 forward of the MFMA sweeps (one wavefront per segment, 16 x 16 fp64 MFMA tiles): pivot blocks inverted by 4 x 4 "
                      "block sweeps; reads D, S, r, writes F^-1, S F^-1, F^-1 h" if form == 1 else
                      "level 0 forward of the MFMA sweeps: block Cholesky + forward substitution; reads D, S, r, writes L, L_{t+1,t}, y"),
-                    ("reduce<1, true, false>", 0, 2 * EF + d, "level 0 reduce of the MFMA sweeps: segment elimination; reads D, S, r"),
+                    ("reduce<1, true, false>", 0, rd, "level 0 reduce of the MFMA sweeps: segment elimination; reads D, S, r"
+                     + (" as prior naturals + overlap-added sites" if fused else "")),
                     ("backward<1, true, true, true>", 2, (2 * EF + d) + (2 * EF + d),
                      "level 0 backward of the MFMA sweeps: selected inverse + back-substitution; reads the factor arrays, writes Sigma_tt, "
                      "Sigma_{t+1,t}, mu"))]
@@ -487,7 +496,7 @@ def cpu_baseline_sparse(M, N, sample=300):
     2 x sample observations, scaled linearly to M (the algorithm is O(M + N))."""
     from oracle import np_conditionals as npc, np_kernels, np_models
     rng = np.random.default_rng(5)
-    span = 0.01 * sample
+    span = 0.1 * sample
     z = np.linspace(0, span, sample)
     t = np.sort(rng.uniform(0, span, size=2 * sample))
     y = (np.sin(3 * t) + 0.1 * rng.normal(size=t.size))[:, None]

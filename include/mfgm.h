@@ -312,6 +312,14 @@ typedef struct mfgm_sparse_data {
  * overlap-added into the block-tri-diagonal structure (sparse_variational_cvi.py:140-174); T = M. */
 int mfgm_sparse_theta(int T, int d, const double* nat1, const double* nat2, const double* plin, const double* pdiag, const double* psub,
                       double* lin, double* diag, double* sub, void* stream);
+/* Factorisation of the sparse-CVI posterior straight from the sites (plans with 8 < d <= 32, one chain, T = M inducing states):
+ * mfgm_sparse_theta followed by mfgm_packed_factor_form(form 1, aD = -2, aS = -1, aR = 1) without materialising the posterior
+ * naturals -- the level-0 passes form  theta_t = prior_t + overlap-added sites  while loading (csrc/mfgm_mfma_inv.h, site_diag /
+ * site_sub / site_lin).  nat1 [M + 1, 2d], nat2 [M + 1, 2d, 2d]; plin (may be NULL) [M, d], pdiag / psub [M, d, d]: the prior's
+ * naturals.  L, G, y: inverse-form factor arrays for mfgm_packed_selinv_form(form 1); logdet / quad [1] may be NULL. */
+int mfgm_sparse_factor(const mfgm_plan* plan, const double* nat1, const double* nat2, const double* plin, const double* pdiag,
+                       const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                       void* stream);
 /* q(f(t_i)) at the data points (posterior.py:207-260 through conditionals.py:380-470) from the posterior marginals of the inducing
  * states: mu [M, d], Sig [M, d, d], Sub [M, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N]. */
 int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
@@ -455,9 +463,11 @@ int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, 
                              double* Sub, double* x, void* ws, void* stream);
 
 /* the same for plans with 8 < d <= 32: the level-0 kernel of one pass alone (which 0 reduce, 1 forward: D, S, r, L, G, y as in
- * mfgm_packed_factor_form; 2 backward: L, G, y, Sig, Sub, x as in mfgm_packed_selinv_form; unused arguments NULL) */
+ * mfgm_packed_factor_form; 2 backward: L, G, y, Sig, Sub, x as in mfgm_packed_selinv_form; unused arguments NULL; site1 / site2 non-NULL:
+ * the inputs of mfgm_sparse_factor, D = pdiag, S = psub, r = plin) */
 int mfgm_wide_stage(const mfgm_plan* plan, int form, int which, const double* D, const double* S, const double* r, double aD, double aS,
-                    double aR, double* L, double* G, double* y, double* Sig, double* Sub, double* x, void* ws, int* info, void* stream);
+                    double aR, double* L, double* G, double* y, double* Sig, double* Sub, double* x, const double* site1,
+                    const double* site2, void* ws, int* info, void* stream);
 
 const char* mfgm_version(void);
 

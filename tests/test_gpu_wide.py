@@ -154,6 +154,53 @@ def test_inverse_form_scaled(amd, rng, B, T, d, R0, Rup, scale):
     np.testing.assert_allclose(host(f["quad"]), scale * np.sum(y * y, axis=(-1, -2)), rtol=1e-8)
 
 
+@pytest.mark.parametrize("M,d,R0", [(1, 9, 0), (40, 12, 8), (130, 16, 8), (45, 20, 5)])
+def test_sparse_factor_from_sites(amd, rng, M, d, R0):
+    """mfgm_sparse_factor (posterior naturals = prior + overlap-added sites formed while loading, sparse_variational_cvi.py:160-172) against
+    mfgm_sparse_theta followed by the plain factorisation, and against the dense oracle."""
+    import torch
+    from vidp_amd import _lib
+    from vidp_amd.packed import _ptr, _stream
+    d2 = 2 * d
+    diag, sub = random_dominant_btd(rng, (1,), M, d)
+    plin = rng.normal(size=(M, d))
+    pdiag = -0.5 * diag[0]
+    psub = np.zeros((M, d, d))
+    if M > 1:
+        psub[:M - 1] = -sub[0]
+    A = 0.2 * rng.normal(size=(M + 1, d2, d2))
+    nat2 = -0.5 * (A @ np.swapaxes(A, -1, -2)) / d2            # negative semi-definite sites
+    nat1 = rng.normal(size=(M + 1, d2))
+    plan = amd.Plan(1, M, d, R0=R0)
+    lib = plan.lib
+    lin, dg, sb = [torch.empty(*sh, dtype=torch.float64, device="cuda") for sh in ((M, d), (M, d, d), (M, d, d))]
+    a = [dev(x) for x in (nat1, nat2, plin, pdiag, psub)]
+    _lib.check(lib.mfgm_sparse_theta(M, d, *[_ptr(x) for x in a], _ptr(lin), _ptr(dg), _ptr(sb), _stream()), "theta")
+    f0 = plan.factor(dg.view(-1), sb.view(-1), lin.view(-1), aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True)
+    s0 = plan.selinv(f0["L"], f0["G"], f0["y"])
+    plan.check_info()
+    f1 = plan.sparse_factor(*a, want_logdet=True)
+    s1 = plan.selinv(f1["L"], f1["G"], f1["y"], form=f1["form"])
+    plan.check_info()
+    for k, kind, n in (("Sig", amd.SYM, M), ("Sub", amd.FULL, M - 1), ("x", amd.VEC, M)):
+        if n > 0:
+            assert_close(host(plan.unpack(kind, s1[k], n)), host(plan.unpack(kind, s0[k], n)), rtol=1e-8)
+    np.testing.assert_allclose(host(f1["logdet"]), host(f0["logdet"]), rtol=1e-10)
+    # dense oracle of the overlap-add
+    P = np.zeros((M * d, M * d))
+    r = np.zeros(M * d)
+    for t in range(M):
+        P[t * d:(t + 1) * d, t * d:(t + 1) * d] = -2.0 * (pdiag[t] + nat2[t + 1, :d, :d] + nat2[t, d:, d:])
+        r[t * d:(t + 1) * d] = plin[t] + nat1[t + 1, :d] + nat1[t, d:]
+        if t + 1 < M:
+            S = -(psub[t] + 2.0 * nat2[t + 1, d:, :d])
+            P[(t + 1) * d:(t + 2) * d, t * d:(t + 1) * d] = S
+            P[t * d:(t + 1) * d, (t + 1) * d:(t + 2) * d] = S.T
+    cov = np.linalg.inv(P)
+    assert_close(host(plan.unpack(amd.VEC, s1["x"]))[0].reshape(-1), cov @ r, rtol=1e-7)
+    assert_close(host(plan.unpack(amd.SYM, s1["Sig"]))[0], np.stack([cov[t * d:(t + 1) * d, t * d:(t + 1) * d] for t in range(M)]), rtol=1e-7)
+
+
 def test_inverse_form_not_pd_and_narrow(amd, rng):
     B, T, d = 2, 40, 11
     diag, sub = random_dominant_btd(rng, (B,), T, d)
@@ -360,6 +407,36 @@ def test_sparse_cvi_d16(amd, rng):
     omu, ovar = npc.predict_f(o.dist_q, _sum16(np_kernels), z, tn)
     assert_close(host(mu), omu, rtol=1e-5)
     assert_close(host(var), ovar, rtol=1e-5)
+
+
+@pytest.mark.parametrize("inverse_form", ["1", "0"])
+def test_sparse_cvi_config5_grid(amd, rng, monkeypatch, inverse_form):
+    """Config 5 in miniature with its own conditioning: its kernel (4 x Matern-5/2 + 2 x Matern-3/2, lengthscales log-spaced 0.05 .. 2),
+    its grid spacing 0.1 and its noise, 2 observations per inducing state, against the oracle over 4 damped steps -- with the
+    inverse-form sweeps (the default; marginals formed from prior + sites on load) and with the Cholesky form."""
+    from oracle import np_conditionals as npc, np_models
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
+    monkeypatch.setenv("VIDP_SPARSE_INVERSE_FORM", inverse_form)
+    ls = np.exp(np.linspace(np.log(0.05), np.log(2.0), 6))
+    mk = lambda mod: mod.Sum([mod.Matern52(float(l), 1.0) for l in ls[:4]] + [mod.Matern32(float(l), 1.0) for l in ls[4:]])
+    M, dz = 120, 0.1
+    z = np.linspace(0, dz * M, M)
+    t = np.sort(rng.uniform(0, dz * M, size=2 * M))
+    y = (np.sin(3 * t) + 0.1 * rng.normal(size=t.size)).reshape(-1, 1)
+    g = SparseCVIGaussianProcess(mk(K), dev(z), Gaussian(0.01), learning_rate=0.5)
+    o = npc.SparseCVIGaussianProcess(mk(np_kernels), z, np_models.GaussianLik(0.01), learning_rate=0.5)
+    prev = -np.inf
+    for _ in range(4):
+        g.update_sites((dev(t), dev(y)))
+        o.update_sites(t, y)
+        e = float(g.classic_elbo((dev(t), dev(y))))
+        np.testing.assert_allclose(e, o.classic_elbo(t, y), rtol=1e-8)
+        assert e > prev
+        prev = e
+    assert g._marginals()["packed"] is not None and g._sweep_bufs["f"]["form"] == int(inverse_form)
+    g.dist_p.plan.check_info()
 
 
 class _ThreadAllReduce:

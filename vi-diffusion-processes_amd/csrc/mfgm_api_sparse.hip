@@ -32,8 +32,10 @@ int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const do
     if (!sparse_ok(data) || !mu || !Sig || !Sub || !fmu || !fvar || !data->prior_mean || !data->prior_cov) return 1;
     if (data->N == 0) return 0;
     const int d2 = 2 * data->d;
-    const size_t shmem = sizeof(double) * ((size_t)d2 * d2 + 2 * d2);
-    hipLaunchKernelGGL(k_sparse_predict, dim3(data->M + 1), dim3(64), shmem, (hipStream_t)stream, sparse_args(data), mu, Sig, Sub, fmu, fvar);
+#define PREDICT(P_) hipLaunchKernelGGL((k_sparse_predict<P_>), dim3(data->M + 1), dim3(64), 0, (hipStream_t)stream, sparse_args(data), mu, Sig, Sub, fmu, fvar)
+    if (d2 <= 2) PREDICT(2); else if (d2 <= 4) PREDICT(4); else if (d2 <= 8) PREDICT(8); else if (d2 <= 16) PREDICT(16);
+    else if (d2 <= 32) PREDICT(32); else PREDICT(64);
+#undef PREDICT
     MFGM_CHECK_LAUNCH();
     return 0;
 }
@@ -55,9 +57,8 @@ int mfgm_cond_predict(int M, int d, int N, const int* idx, const double* P, cons
 int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2,
                             void* stream) {
     if (!sparse_ok(data) || !nat1 || !nat2 || (data->N > 0 && (!g1 || !g2))) return 1;
-    const int d2 = 2 * data->d;
-    hipLaunchKernelGGL(k_sparse_sites, dim3(data->M + 1), dim3(256), sizeof(double) * (d2 + 2), (hipStream_t)stream, sparse_args(data), g1,
-                       g2, lr, nat1, nat2);
+    hipLaunchKernelGGL(k_sparse_sites, dim3(data->M + 1), dim3(256), sizeof(double) * (2 * data->d + 2), (hipStream_t)stream,
+                       sparse_args(data), g1, g2, lr, nat1, nat2);
     MFGM_CHECK_LAUNCH();
     return 0;
 }

@@ -611,13 +611,24 @@ int mfgm_packed_factor_stage(const mfgm_plan* plan, int stage, int level, const 
 }
 
 int mfgm_wide_stage(const mfgm_plan* plan, int form, int which, const double* D, const double* S, const double* r, double aD, double aS,
-                    double aR, double* L, double* G, double* y, double* Sig, double* Sub, double* x, void* ws, int* info, void* stream) {
+                    double aR, double* L, double* G, double* y, double* Sig, double* Sub, double* x, const double* site1,
+                    const double* site2, void* ws, int* info, void* stream) {
     if (!plan || !L || !G || !info || !ws) return 1;
     const Plan& P = plan->p;
     if (!P.wide) return 1;
-    if (which < 2 && (!D || !S || (r != nullptr) != (y != nullptr))) return 1;
+    if (which < 2 && (!D || !S || ((r != nullptr) || (site1 != nullptr)) != (y != nullptr))) return 1;
     if (which == 2 && (!Sig || (y != nullptr) != (x != nullptr))) return 1;
-    return wide_stage(P, form, which, D, S, r, aD, aS, aR, L, G, y, Sig, Sub, x, (double*)ws, info, (hipStream_t)stream);
+    return wide_stage(P, form, which, D, S, r, aD, aS, aR, L, G, y, Sig, Sub, x, (double*)ws, info, (hipStream_t)stream, site1, site2);
+}
+
+int mfgm_sparse_factor(const mfgm_plan* plan, const double* nat1, const double* nat2, const double* plin, const double* pdiag,
+                       const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                       void* stream) {
+    if (!plan || !nat1 || !nat2 || !pdiag || !psub || !L || !G || !y || !info || !ws) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide || P.B != 1 || P.shard_level > 0) return 1;
+    return wide_factor(P, pdiag, psub, plin, -2.0, -1.0, 1.0, L, G, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, -1, 1, nat1,
+                       nat2);
 }
 
 int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, const double* G, const double* y, double* Sig,

@@ -255,8 +255,56 @@ MFGM_DEV void st_col(double* __restrict__ v, int d, const LaneId& L, const ColVe
         if (L.g == 0 && 16 * J + L.c < d) v[16 * J + L.c] = a.c[J];
 }
 
+// d x d sub-block (row0, col0) of a row-major matrix with leading dimension ld, times scale, as tiles (zero padded; TRANSPOSED: its
+// transpose)
+template <int NT, bool TRANSPOSED>
+MFGM_DEV Mat<NT> ld_sub(const double* __restrict__ base, int ld, int row0, int col0, int d, const LaneId& L, double scale) {
+    Mat<NT> m;
+    double x[NT][NT][4];
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * I + L.g + 4 * i, c = 16 * J + L.c;
+                const bool ok = r < d && c < d;
+                x[I][J][i] = base[ok ? (TRANSPOSED ? (row0 + c) * ld + col0 + r : (row0 + r) * ld + col0 + c) : 0];
+            }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * I + L.g + 4 * i, c = 16 * J + L.c;
+                m.t[I][J].r[i] = x[I][J][i] * ((r < d && c < d) ? scale : 0.0);
+            }
+    return m;
+}
+
+// Posterior naturals of the sparse-CVI model at node t, formed on load (WideArgs::site1 / site2): site t + 1 has state t as the first
+// of its pair, site t as the second
+template <int NT>
+MFGM_DEV Mat<NT> site_diag(const WideArgs& a, int t, const LaneId& L) {
+    const int d = a.d, d2 = 2 * d;
+    const double* hi = a.site2 + (size_t)(t + 1) * d2 * d2;
+    const double* lo = a.site2 + (size_t)t * d2 * d2;
+    return mat_add<NT>(ld_sub<NT, false>(hi, d2, 0, 0, d, L, a.aD), ld_sub<NT, false>(lo, d2, d, d, d, L, a.aD));
+}
+template <int NT, bool TRANSPOSED>
+MFGM_DEV Mat<NT> site_sub(const WideArgs& a, int t, const LaneId& L) {
+    const int d = a.d, d2 = 2 * d;
+    return ld_sub<NT, TRANSPOSED>(a.site2 + (size_t)(t + 1) * d2 * d2, d2, d, 0, d, L, 2.0 * a.aS);
+}
+template <int NT>
+MFGM_DEV ColVec<NT> site_lin(const WideArgs& a, int t, const LaneId& L) {
+    const int d = a.d, d2 = 2 * d;
+    return col_add<NT>(ld_col<NT>(a.site1 + (size_t)(t + 1) * d2, d, L, a.aR), ld_col<NT>(a.site1 + (size_t)t * d2 + d, d, L, a.aR));
+}
+
 // ---- reduce ------------------------------------------------------------------------------------------------------------------------
-template <int NT, bool HAS_RHS, bool HAS_CORR>
+template <int NT, bool HAS_RHS, bool HAS_CORR, bool SITES = false>
 static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
     __shared__ double lds[16 * NT];
     __shared__ double ldsE[16];
@@ -271,21 +319,33 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
     auto ld_F = [&](int t) {
         Mat<NT> F = ld_mat<NT, false, true>(wblk(a.Dg, b, n, t, EF), d, L, a.aD);
         if (HAS_CORR) F = mat_sub<NT>(F, ld_mat<NT, false, false>(wblk(a.Dcorr, b, n, t, EF), d, L, 1.0));
+        if (SITES) F = mat_add<NT>(F, site_diag<NT>(a, t, L));
         return F;
     };
     auto ld_h = [&](int t) {
-        ColVec<NT> h = ld_col<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
+        ColVec<NT> h = a.rg ? ld_col<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR) : col_zero<NT>();
         if (HAS_CORR) h = col_sub<NT>(h, ld_col<NT>(wblk(a.rcorr, b, n, t, d), d, L, 1.0));
+        if (SITES) h = col_add<NT>(h, site_lin<NT>(a, t, L));
         return h;
     };
+    auto ld_S = [&](int t) {            // S_t
+        Mat<NT> S = ld_mat<NT, false, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS);
+        if (SITES) S = mat_add<NT>(S, site_sub<NT, false>(a, t, L));
+        return S;
+    };
+    auto ld_St = [&](int t) {           // S_t^T
+        Mat<NT> S = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS);
+        if (SITES) S = mat_add<NT>(S, site_sub<NT, true>(a, t, L));
+        return S;
+    };
     Mat<NT> F = ld_F(t0);
-    Mat<NT> W = (p > 0) ? ld_mat<NT, false, false>(wblk(a.Sg, b, n, t0 - 1, EF), d, L, a.aS) : mat_zero<NT>();
+    Mat<NT> W = (p > 0) ? ld_S(t0 - 1) : mat_zero<NT>();
     ColVec<NT> hc = HAS_RHS ? ld_h(t0) : col_zero<NT>();
     Mat<NT> Racc = mat_zero<NT>();
     ColVec<NT> rho = col_zero<NT>();
     for (int s = 0; s < len - 1; ++s) {
         const int t = t0 + s;
-        const Mat<NT> St = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS);      // S^T
+        const Mat<NT> St = ld_St(t);
         Mat<NT> Fn = ld_F(t + 1);
         ColVec<NT> hn = HAS_RHS ? ld_h(t + 1) : col_zero<NT>();
         sweep_inv<NT>(F, L, la, bad, ldsE);                          // (the determinant is not an output of this pass)
@@ -324,7 +384,7 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
 // ---- forward -----------------------------------------------------------------------------------------------------------------------
 // Levels above the finest also keep their pivot blocks F_t and right-hand sides h_t (in the level's Sigma / mu arrays, which the
 // backward pass fills later): the level below rebuilds the state on its separators from them,  F_a = F~ + R_p,  h_a = h~ + rho_p.
-template <int NT, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
+template <int NT, bool HAS_RHS, bool HAS_CORR, bool HAS_UP, bool SITES = false>
 static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
     __shared__ double lds[16 * NT];
     __shared__ double ldsT[16 * 17];
@@ -343,7 +403,8 @@ static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
         const int un = a.up.n;
         Mat<NT> Fa = ld_mat<NT, false, true>(wblk(a.uSig, b, un, p - 1, EF), d, L, 1.0);
         Fa = mat_add<NT>(Fa, ld_mat<NT, false, false>(wblk(a.uRsub, b, un, p - 1, EF), d, L, 1.0));
-        const Mat<NT> Sat = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t0 - 1, EF), d, L, a.aS);
+        Mat<NT> Sat = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t0 - 1, EF), d, L, a.aS);
+        if (SITES) Sat = mat_add<NT>(Sat, site_sub<NT, true>(a, t0 - 1, L));
         ColVec<NT> ha = col_zero<NT>();
         if (HAS_RHS) ha = col_add<NT>(ld_col<NT>(wblk(a.umu, b, un, p - 1, d), d, L, 1.0), ld_col<NT>(wblk(a.urho, b, un, p - 1, d), d, L, 1.0));
         const bool keep = (a.store_left && p == a.seg_lo);     // sharded chain: see WideArgs::store_left
@@ -370,14 +431,21 @@ static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
     auto ld_node_F = [&](int t) {
         Mat<NT> F = ld_mat<NT, false, true>(wblk(a.Dg, b, n, t, EF), d, L, a.aD);
         if (HAS_CORR) F = mat_sub<NT>(F, ld_mat<NT, false, false>(wblk(a.Dcorr, b, n, t, EF), d, L, 1.0));
+        if (SITES) F = mat_add<NT>(F, site_diag<NT>(a, t, L));
         return F;
     };
-    auto ld_node_S = [&](int t) { return (t + 1 < n) ? ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS) : mat_zero<NT>(); };
+    auto ld_node_S = [&](int t) {
+        if (t + 1 >= n) return mat_zero<NT>();
+        Mat<NT> S = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS);
+        if (SITES) S = mat_add<NT>(S, site_sub<NT, true>(a, t, L));
+        return S;
+    };
     auto ld_node_h = [&](int t) {
         ColVec<NT> h = col_zero<NT>();
         if (HAS_RHS) {
-            h = ld_col<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
+            if (a.rg) h = ld_col<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
             if (HAS_CORR) h = col_sub<NT>(h, ld_col<NT>(wblk(a.rcorr, b, n, t, d), d, L, 1.0));
+            if (SITES) h = col_add<NT>(h, site_lin<NT>(a, t, L));
         }
         return h;
     };

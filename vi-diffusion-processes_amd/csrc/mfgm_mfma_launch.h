@@ -43,6 +43,15 @@ int MFGM_CAT(mfma_inv_launch_, MFGM_MFMA_NT)(int which, const WideArgs& a, bool 
     constexpr int NT = MFGM_MFMA_NT;
     dim3 grid((a.lv.L / a.lv.P) * a.nseg), block(64);   // chains x covered segments
 #define KM(K) hipLaunchKernelGGL((K), grid, block, 0, st, a)
+    if (a.site2 && which < 2) {
+        // sparse-CVI inputs: level 0 of one chain, with a right-hand side
+        if (has_corr || !has_rhs || a.lv.L != a.lv.P) return 1;
+        if (which == 0) KM((kmi_reduce<NT, true, false, true>));
+        else if (has_up) KM((kmi_forward<NT, true, false, true, true>));
+        else KM((kmi_forward<NT, true, false, false, true>));
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
     if (which == 0) {
         if (has_rhs) { if (has_corr) KM((kmi_reduce<NT, true, true>)); else KM((kmi_reduce<NT, true, false>)); }
         else { if (has_corr) KM((kmi_reduce<NT, false, true>)); else KM((kmi_reduce<NT, false, false>)); }

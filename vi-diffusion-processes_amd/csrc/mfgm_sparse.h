@@ -45,46 +45,52 @@ static __global__ void k_sparse_theta(int T, int d, const double* __restrict__ n
     }
 }
 
-// marginals: mu [T, d], Sig [T, d, d] (full symmetric), Sub [T, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N]
+// marginals: mu [T, d], Sig [T, d, d] (full symmetric), Sub [T, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N].
+// One wavefront per interval, no LDS and no barriers: lane l owns column c = l mod 2d' of the pair covariance PC [2d, 2d] for the rows
+// r = h, h + H, ... (h = l / 2d', H = 64 / 2d'; 2d' = 2d rounded up to a power of two <= 64), loaded straight from the marginal
+// blocks, and sums  w_r PC[r][c] w_c  over its entries for every data point of the interval; one wavefront reduction per point.
+template <int D2P>
 static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, const double* __restrict__ mu, const double* __restrict__ Sig,
                                                              const double* __restrict__ Sub, double* __restrict__ fmu,
                                                              double* __restrict__ fvar) {
-    extern __shared__ double sh[];     // PC [2d][2d], pm [2d], w [2d]
+    constexpr int H = (64 / D2P < D2P) ? 64 / D2P : D2P, NR = D2P / H;          // row groups (lanes beyond H D2P idle), rows per lane
     const int m = blockIdx.x, d = a.d, d2 = 2 * d, lane = threadIdx.x;
     const int i0 = a.seg[m], i1 = a.seg[m + 1];
     if (i0 >= i1) return;
-    double* PC = sh;
-    double* pm = sh + d2 * d2;
-    double* w = pm + d2;
+    const int c = lane % D2P, h = lane / D2P;
     const bool lo_prior = (m == 0), hi_prior = (m == a.M);
     const double* S_lo = lo_prior ? a.prior_cov : Sig + (size_t)(m - 1) * d * d;
     const double* S_hi = hi_prior ? a.prior_cov : Sig + (size_t)m * d * d;
     const double* C = (lo_prior || hi_prior) ? nullptr : Sub + (size_t)(m - 1) * d * d;       // Cov(x_m, x_{m-1})
-    for (int e = lane; e < d2 * d2; e += 64) {
-        const int r = e / d2, cidx = e - r * d2;
-        double v;
-        if (r < d && cidx < d) v = S_lo[r * d + cidx];
-        else if (r >= d && cidx >= d) v = S_hi[(r - d) * d + (cidx - d)];
-        else if (r >= d) v = C ? C[(r - d) * d + cidx] : 0.0;               // lower-left: Cov(x_hi, x_lo)
-        else v = C ? C[(cidx - d) * d + r] : 0.0;                            // upper-right: its transpose
-        PC[e] = v;
-    }
-    for (int e = lane; e < d2; e += 64) {
-        const bool hi = e >= d;
-        const int k = hi ? e - d : e;
-        pm[e] = hi ? (hi_prior ? a.prior_mean[k] : mu[(size_t)m * d + k]) : (lo_prior ? a.prior_mean[k] : mu[(size_t)(m - 1) * d + k]);
-    }
-    __syncthreads();
-    for (int i = i0; i < i1; ++i) {
-        for (int e = lane; e < d2; e += 64) w[e] = a.w[(size_t)i * d2 + e];
-        __syncthreads();
-        double qm = 0.0, qv = 0.0;
-        if (lane < d2) {
-            double u = 0.0;
-            for (int k = 0; k < d2; ++k) u += PC[k * d2 + lane] * w[k];      // PC is symmetric: column access, consecutive lanes
-            qv = w[lane] * u;
-            qm = w[lane] * pm[lane];
+    double pc[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = h + H * k;
+        double v = 0.0;
+        if (h < H && r < d2 && c < d2) {
+            if (r < d && c < d) v = S_lo[r * d + c];
+            else if (r >= d && c >= d) v = S_hi[(r - d) * d + (c - d)];
+            else if (r >= d) v = C ? C[(r - d) * d + c] : 0.0;                  // lower-left: Cov(x_hi, x_lo)
+            else v = C ? C[(c - d) * d + r] : 0.0;                               // upper-right: its transpose
         }
+        pc[k] = v;
+    }
+    double pmc = 0.0;                                   // pair mean, entry c (counted by the row group 0 only)
+    if (h == 0 && c < d2) {
+        const bool hi = c >= d;
+        const int kk = hi ? c - d : c;
+        pmc = hi ? (hi_prior ? a.prior_mean[kk] : mu[(size_t)m * d + kk]) : (lo_prior ? a.prior_mean[kk] : mu[(size_t)(m - 1) * d + kk]);
+    }
+    for (int i = i0; i < i1; ++i) {
+        const double* w = a.w + (size_t)i * d2;
+        const double wc = (c < d2) ? w[c] : 0.0;
+        double u = 0.0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = h + H * k;
+            u = __builtin_fma(pc[k], (h < H && r < d2) ? w[r] : 0.0, u);
+        }
+        double qv = wc * u, qm = wc * pmc;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             qm += __shfl_down(qm, off, 64);
@@ -94,7 +100,6 @@ static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, cons
             fmu[i] = qm;
             fvar[i] = a.c[i] + qv;
         }
-        __syncthreads();
     }
 }
 
@@ -155,18 +160,25 @@ static __global__ __launch_bounds__(64) void k_cond_predict(int M, int d, int N,
     }
 }
 
-// sites <- (1 - lr) sites + lr (sum_i g1_i w_i, sum_i g2_i w_i w_i^T), in place; g1, g2 [N]
+// sites <- (1 - lr) sites + lr (sum_i g1_i w_i, sum_i g2_i w_i w_i^T), in place; g1, g2 [N].  One workgroup per interval; thread t owns
+// the entries t, t + 256, ... of the [2d, 2d] block (at most 16 for 2d <= 64), whose old values are requested before the data loop and
+// consumed after it; w_i is staged through LDS (per-thread gathers of w from memory were measured 1.6x slower).
 static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const double* __restrict__ g1, const double* __restrict__ g2,
                                                             double lr, double* __restrict__ nat1, double* __restrict__ nat2) {
     extern __shared__ double sh[];     // w [2d] and (g1, g2) of the current data point
     const int m = blockIdx.x, d2 = 2 * a.d, tid = threadIdx.x;
     const int i0 = a.seg[m], i1 = a.seg[m + 1];
     const int ne = d2 * d2;
-    // each thread owns entries tid, tid + 256, ... of the [2d, 2d] block (at most 16 of them for 2d <= 64)
-    double acc[16];
-    double acc1 = 0.0;
+    double* n2 = nat2 + (size_t)m * ne;
+    double old[16], acc[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + k * 256;
+        old[k] = (e < ne) ? n2[e] : 0.0;
+        acc[k] = 0.0;
+    }
+    const double old1 = (tid < d2) ? nat1[(size_t)m * d2 + tid] : 0.0;
+    double acc1 = 0.0;
     for (int i = i0; i < i1; ++i) {
         __syncthreads();
         for (int e = tid; e < d2; e += 256) sh[e] = a.w[(size_t)i * d2 + e];
@@ -183,13 +195,12 @@ static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const
         }
         if (tid < d2) acc1 += sh[d2] * sh[tid];
     }
-    double* n2 = nat2 + (size_t)m * ne;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int e = tid + k * 256;
-        if (e < ne) n2[e] = (1.0 - lr) * n2[e] + lr * acc[k];
+        if (e < ne) n2[e] = __builtin_fma(lr, acc[k], (1.0 - lr) * old[k]);
     }
-    if (tid < d2) nat1[(size_t)m * d2 + tid] = (1.0 - lr) * nat1[(size_t)m * d2 + tid] + lr * acc1;
+    if (tid < d2) nat1[(size_t)m * d2 + tid] = __builtin_fma(lr, acc1, (1.0 - lr) * old1);
 }
 
 }  // namespace mfgm

@@ -30,6 +30,10 @@ struct WideArgs {
     double* uDhat; double* uRsub; double* uS; double* urhat; double* urho;
     const double* uL; const double* uy; const double* uSig; const double* umu;
     int* info;
+    // sparse-CVI inputs (inverse-form kernels, level 0, one chain): when site2 != NULL the arrays Dg, Sg, rg are the PRIOR naturals and
+    // the posterior naturals are formed on load by overlap-adding the sites site1 [n + 1, 2d], site2 [n + 1, 2d, 2d] on pairs of
+    // consecutive states (sparse_variational_cvi.py:160-172; what k_sparse_theta would write out)
+    const double* site1; const double* site2;
 };
 
 // row i of a d x d block (zero padded), column i of a block

@@ -87,7 +87,7 @@ class BaseKalmanFilter:
         cst = -0.5 * math.log(2 * math.pi) * o * self._num_data()
         term1 = -0.5 * self._term1(disp)
         obs_proj = self._back_project(self._disp_grid(disp))
-        f = pl.factor(D, S, pl.pack(VEC, obs_proj.contiguous()), want_logdet=True, want_quad=True, moments_only=True)
+        f = pl.factor(D, S, pl.pack(VEC, obs_proj.contiguous()), want_logdet=True, want_quad=True)
         pl.check_info()
         term2 = 0.5 * f["quad"]
         term3 = -pr["sumlogchol"] - f["logdet"] + 0.5 * self._log_det_observation_precision

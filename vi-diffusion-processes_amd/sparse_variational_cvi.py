@@ -106,6 +106,19 @@ class SparseCVIGaussianProcess:
             self._pn = dict(nat=nat, lin=lin.contiguous(), diag=diag.contiguous(), sub=sub.contiguous(), zeros=pl.zeros(VEC))
         return self._pn
 
+    def _inverse_form(self):
+        """The marginals come from the inverse-form sweeps (Plan.factor(moments_only=True), d > 8).  They lose ~10 eps cond(F_t) where
+        the Cholesky form loses ~0.05 eps cond: on config 5's kernel and grid (rho = dz / lengthscale >= 0.05) the ELBO agrees with the
+        oracle to 1e-10 in either form; on grids so fine that the prior precision is numerically singular (rho ~ 0.005, cond 1e15)
+        neither form nor the NumPy oracle is meaningful in fp64.  VIDP_SPARSE_INVERSE_FORM=0 selects the Cholesky form."""
+        import os
+        return self.dist_p.plan.wide and os.environ.get("VIDP_SPARSE_INVERSE_FORM", "1") != "0"
+
+    def _fused_theta(self):
+        import os
+        return (self._inverse_form() and os.environ.get("VIDP_FUSED_THETA", "1") != "0" and self.nat1.is_contiguous()
+                and self.nat2.is_contiguous())
+
     def _theta(self):
         """Posterior naturals of the current sites, packed (lin, diag, sub): one pass over the sites (mfgm_sparse_theta)."""
         from . import _lib
@@ -133,10 +146,15 @@ class SparseCVIGaussianProcess:
             return m
         p = self.dist_p
         pl, T, d = p.plan, p.T, p.d
-        lin, diag, sub = self._theta()
         bufs = self.__dict__.setdefault("_sweep_bufs", dict(f={}, s={}))
-        f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=bufs["f"], moments_only=True)
-        bufs["f"].update(L=f["L"], G=f["G"], y=f["y"])
+        if self._fused_theta():
+            # the level-0 passes of the factorisation form  prior + overlap-added sites  while loading: no posterior naturals in memory
+            pn = self._prior_natural()
+            f = pl.sparse_factor(self.nat1, self.nat2, pn["lin"], pn["diag"], pn["sub"], want_logdet=True, out=bufs["f"])
+        else:
+            lin, diag, sub = self._theta()
+            f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=bufs["f"], moments_only=self._inverse_form())
+        bufs["f"].update(L=f["L"], G=f["G"], y=f["y"], form=f["form"])
         s = pl.selinv(f["L"], f["G"], f["y"], want_sub=True, out=bufs["s"], form=f["form"])
         bufs["s"].update(Sig=s["Sig"], Sub=s["Sub"], x=s["x"])
         if pl.d > 8:

@@ -133,8 +133,8 @@ class GaussianProcessWithSitesBase:
         if fused is not None:
             return fused
         pl, lin, diag, sub = self._posterior_naturals()
-        f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False, moments_only=True)
-        s = pl.selinv(f["L"], f["G"], f["y"], want_sub=False, form=f["form"])
+        f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
+        s = pl.selinv(f["L"], f["G"], f["y"], want_sub=False)
         pl.check_info()
         ssm = self.dist_p
         mu = pl.unpack(VEC, s["x"]).reshape(ssm.batch_shape + (ssm.T, ssm.d))
