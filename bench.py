@@ -750,6 +750,12 @@ def main():
                          "share_of_step": per_step * k_ms / ms_per_step})
         rows.sort(key=lambda r: -r["share_of_step"])
         out["roofline"] = dict(rows[0], other_kernels=rows[1:])
+        # the whole step against SURVEY 8d's own byte count for it (full CVI step: 8 (11 d^2 + 5 d) B per trajectory-time-step, dense
+        # naturals): 21.8 GB at the headline size, i.e. 2.73 ms at the HBM peak
+        step_bytes = 8 * (11 * d * d + 5 * d) * B * T
+        out["roofline"]["step"] = {"survey_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                                   "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "level0_share_of_step": sum(r["share_of_step"] for r in rows)}
         if world == 1 and not args.no_vdp and args.config == "headline":
             # free the CVI-DP state first: the VDP model keeps its own ~15 GB resident
             del model, f, s, cand, cq

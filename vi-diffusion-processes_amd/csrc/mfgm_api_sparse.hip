@@ -57,8 +57,13 @@ int mfgm_cond_predict(int M, int d, int N, const int* idx, const double* P, cons
 int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2,
                             void* stream) {
     if (!sparse_ok(data) || !nat1 || !nat2 || (data->N > 0 && (!g1 || !g2))) return 1;
-    hipLaunchKernelGGL(k_sparse_sites, dim3(data->M + 1), dim3(256), sizeof(double) * (2 * data->d + 2), (hipStream_t)stream,
-                       sparse_args(data), g1, g2, lr, nat1, nat2);
+    const int npair = 2 * data->d * data->d;            // entry pairs of a [2d, 2d] block
+    const size_t shmem = sizeof(double) * kSitesChunk * (2 * data->d + 2);
+#define SITES(SPI_)                                                                                                                    \
+    hipLaunchKernelGGL((k_sparse_sites<SPI_>), dim3((data->M + 1 + 8 / SPI_ - 1) / (8 / SPI_)), dim3(256), shmem, (hipStream_t)stream,  \
+                       sparse_args(data), g1, g2, lr, nat1, nat2)
+    if (npair <= 256) SITES(1); else if (npair <= 512) SITES(2); else if (npair <= 1024) SITES(4); else SITES(8);
+#undef SITES
     MFGM_CHECK_LAUNCH();
     return 0;
 }

@@ -160,47 +160,77 @@ static __global__ __launch_bounds__(64) void k_cond_predict(int M, int d, int N,
     }
 }
 
-// sites <- (1 - lr) sites + lr (sum_i g1_i w_i, sum_i g2_i w_i w_i^T), in place; g1, g2 [N].  One workgroup per interval; thread t owns
-// the entries t, t + 256, ... of the [2d, 2d] block (at most 16 for 2d <= 64), whose old values are requested before the data loop and
-// consumed after it; w_i is staged through LDS (per-thread gathers of w from memory were measured 1.6x slower).
+// sites <- (1 - lr) sites + lr (sum_i g1_i w_i, sum_i g2_i w_i w_i^T), in place; g1, g2 [N].  A streaming read-modify-write of the
+// [M + 1, 2d, 2d] site tensor: what bounds it is the number of bytes a compute unit keeps in flight, so a workgroup of 256 threads
+// takes G = 8 / SPI consecutive intervals (SPI = slots of 256 entry pairs per [2d, 2d] block: 2 for 2d = 32), requests all their old
+// values (16-byte accesses, 8 per thread) before anything else, and only then walks the data points of each interval (w, g1, g2 of up
+// to kSitesChunk points staged through LDS at a time; per-thread gathers of w from memory were measured 1.6x slower).
+constexpr int kSitesChunk = 8;
+template <int SPI>
 static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const double* __restrict__ g1, const double* __restrict__ g2,
                                                             double lr, double* __restrict__ nat1, double* __restrict__ nat2) {
-    extern __shared__ double sh[];     // w [2d] and (g1, g2) of the current data point
-    const int m = blockIdx.x, d2 = 2 * a.d, tid = threadIdx.x;
-    const int i0 = a.seg[m], i1 = a.seg[m + 1];
-    const int ne = d2 * d2;
-    double* n2 = nat2 + (size_t)m * ne;
-    double old[16], acc[16];
+    constexpr int G = 8 / SPI;
+    extern __shared__ double sh[];     // kSitesChunk x (w [2d], g1, g2)
+    const int d2 = 2 * a.d, tid = threadIdx.x, m0 = blockIdx.x * G;
+    const int ne = d2 * d2;            // even, and a row never splits a pair
+    double2 old[8], acc[8];
+    int rr[SPI], cc[SPI];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int e = tid + k * 256;
-        old[k] = (e < ne) ? n2[e] : 0.0;
-        acc[k] = 0.0;
+    for (int kk = 0; kk < SPI; ++kk) {
+        const int e = 2 * (tid + kk * 256);
+        rr[kk] = (e < ne) ? e / d2 : 0;
+        cc[kk] = (e < ne) ? e - rr[kk] * d2 : 0;
     }
-    const double old1 = (tid < d2) ? nat1[(size_t)m * d2 + tid] : 0.0;
-    double acc1 = 0.0;
-    for (int i = i0; i < i1; ++i) {
-        __syncthreads();
-        for (int e = tid; e < d2; e += 256) sh[e] = a.w[(size_t)i * d2 + e];
-        if (tid == 0) { sh[d2] = g1[i]; sh[d2 + 1] = g2[i]; }
-        __syncthreads();
-        const double gg = sh[d2 + 1];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + k * 256;
-            if (e < ne) {
-                const int r = e / d2, cidx = e - r * d2;
-                acc[k] += gg * sh[r] * sh[cidx];
+    for (int k = 0; k < 8; ++k) {
+        const int gi = k / SPI, p = tid + (k % SPI) * 256;
+        const bool ok = (m0 + gi <= a.M) && 2 * p < ne;
+        old[k] = ok ? reinterpret_cast<const double2*>(nat2 + (size_t)(m0 + gi) * ne)[p] : make_double2(0.0, 0.0);
+        acc[k] = make_double2(0.0, 0.0);
+    }
+    double old1[G], acc1[G];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        old1[gi] = (tid < d2 && m0 + gi <= a.M) ? nat1[(size_t)(m0 + gi) * d2 + tid] : 0.0;
+        acc1[gi] = 0.0;
+    }
+    const int st = d2 + 2;
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        const int m = min(m0 + gi, a.M);
+        const int i0 = a.seg[m], i1 = (m0 + gi <= a.M) ? a.seg[m + 1] : i0;
+        for (int c0 = i0; c0 < i1; c0 += kSitesChunk) {
+            const int np = min(kSitesChunk, i1 - c0);
+            __syncthreads();
+            for (int e = tid; e < np * d2; e += 256) {
+                const int pt = e / d2, j = e - pt * d2;
+                sh[pt * st + j] = a.w[(size_t)(c0 + pt) * d2 + j];
+            }
+            if (tid < np) { sh[tid * st + d2] = g1[c0 + tid]; sh[tid * st + d2 + 1] = g2[c0 + tid]; }
+            __syncthreads();
+            for (int pt = 0; pt < np; ++pt) {
+                const double* w = sh + pt * st;
+                const double gg = w[d2 + 1];
+#pragma unroll
+                for (int kk = 0; kk < SPI; ++kk) {
+                    const double gr = gg * w[rr[kk]];
+                    acc[gi * SPI + kk].x = __builtin_fma(gr, w[cc[kk]], acc[gi * SPI + kk].x);
+                    acc[gi * SPI + kk].y = __builtin_fma(gr, w[cc[kk] + 1], acc[gi * SPI + kk].y);
+                }
+                if (tid < d2) acc1[gi] = __builtin_fma(w[d2], w[tid], acc1[gi]);
             }
         }
-        if (tid < d2) acc1 += sh[d2] * sh[tid];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int e = tid + k * 256;
-        if (e < ne) n2[e] = __builtin_fma(lr, acc[k], (1.0 - lr) * old[k]);
+    for (int k = 0; k < 8; ++k) {
+        const int gi = k / SPI, p = tid + (k % SPI) * 256;
+        if ((m0 + gi <= a.M) && 2 * p < ne)
+            reinterpret_cast<double2*>(nat2 + (size_t)(m0 + gi) * ne)[p] =
+                make_double2(__builtin_fma(lr, acc[k].x, (1.0 - lr) * old[k].x), __builtin_fma(lr, acc[k].y, (1.0 - lr) * old[k].y));
     }
-    if (tid < d2) nat1[(size_t)m * d2 + tid] = __builtin_fma(lr, acc1, (1.0 - lr) * old1);
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+        if (tid < d2 && m0 + gi <= a.M) nat1[(size_t)(m0 + gi) * d2 + tid] = __builtin_fma(lr, acc1[gi], (1.0 - lr) * old1[gi]);
 }
 
 }  // namespace mfgm
