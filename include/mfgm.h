@@ -324,6 +324,12 @@ int mfgm_sparse_factor(const mfgm_plan* plan, const double* nat1, const double* 
  * states: mu [M, d], Sig [M, d, d], Sub [M, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N]. */
 int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
                         void* stream);
+/* the same pass with the trace and Mahalanobis terms of KL[q || p] (mfgm_packed_kl_terms: state_space_model.py:528-593) taken from the
+ * pair covariances it holds anyway; plan: the wide plan (8 < d <= 32, one chain, T = M) whose workspace ws receives the partial sums;
+ * Pd / Ps [M, d, d]: the prior's precision blocks times aD / aS; mup [M, d]: its marginal means; trace / maha [1]. */
+int mfgm_sparse_predict_kl(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
+                           const mfgm_plan* plan, const double* Pd, const double* Ps, double aD, double aS, const double* mup,
+                           double* trace, double* maha, void* ws, void* stream);
 /* ConditionalProcess.predict_state (posterior.py:207-229 -> conditional_predict / base_conditional_predict, conditionals.py:29-76,
  * 380-421) at N query points: idx [N] = interval of each point (0 .. M, as above), P [N, d, 2d] / T [N, d, d] its conditional
  * statistics (conditionals.py:207-256), the marginals of the M conditioning states as in mfgm_sparse_predict;

@@ -100,6 +100,7 @@ EXPORTS = {
                                       + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 8),
     "mfgm_wide_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_double] * 3
                         + [ctypes.c_void_p] * 11),
+    "mfgm_sparse_predict_kl": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
     "mfgm_sparse_factor": (ctypes.c_int, [ctypes.c_void_p] * 14),
     "mfgm_batched_cholesky": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4),
     "mfgm_batched_trsm": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),

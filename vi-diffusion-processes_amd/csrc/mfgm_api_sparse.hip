@@ -1,6 +1,7 @@
 // C-ABI entry points of the sparse / inducing-state CVI local kernels (mfgm_sparse.h).
 #include "mfgm_internal.h"
 #include "mfgm_sparse.h"
+#include "mfgm_sweeps.h"
 
 using namespace mfgm;
 
@@ -27,17 +28,39 @@ int mfgm_sparse_theta(int T, int d, const double* nat1, const double* nat2, cons
     return 0;
 }
 
-int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
-                        void* stream) {
-    if (!sparse_ok(data) || !mu || !Sig || !Sub || !fmu || !fvar || !data->prior_mean || !data->prior_cov) return 1;
-    if (data->N == 0) return 0;
+namespace {
+int launch_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
+                   const SparseKl& kl, hipStream_t st) {
     const int d2 = 2 * data->d;
-#define PREDICT(P_) hipLaunchKernelGGL((k_sparse_predict<P_>), dim3(data->M + 1), dim3(64), 0, (hipStream_t)stream, sparse_args(data), mu, Sig, Sub, fmu, fvar)
+#define PREDICT(P_) hipLaunchKernelGGL((k_sparse_predict<P_>), dim3(data->M + 1), dim3(64), 0, st, sparse_args(data), mu, Sig, Sub, fmu, fvar, kl)
     if (d2 <= 2) PREDICT(2); else if (d2 <= 4) PREDICT(4); else if (d2 <= 8) PREDICT(8); else if (d2 <= 16) PREDICT(16);
     else if (d2 <= 32) PREDICT(32); else PREDICT(64);
 #undef PREDICT
     MFGM_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
+                        void* stream) {
+    if (!sparse_ok(data) || !mu || !Sig || !Sub || !fmu || !fvar || !data->prior_mean || !data->prior_cov) return 1;
+    if (data->N == 0) return 0;
+    SparseKl kl;
+    memset(&kl, 0, sizeof(kl));
+    return launch_predict(data, mu, Sig, Sub, fmu, fvar, kl, (hipStream_t)stream);
+}
+
+int mfgm_sparse_predict_kl(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
+                           const mfgm_plan* plan, const double* Pd, const double* Ps, double aD, double aS, const double* mup,
+                           double* trace, double* maha, void* ws, void* stream) {
+    if (!sparse_ok(data) || !mu || !Sig || !Sub || !fmu || !fvar || !data->prior_mean || !data->prior_cov) return 1;
+    if (!plan || !Pd || !Ps || !mup || !trace || !maha || !ws) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide || P.B != 1 || P.T != data->M || P.d != data->d) return 1;
+    SparseKl kl{Pd, Ps, mup, aD, aS, (double*)ws + P.off_part[0]};
+    int rc = launch_predict(data, mu, Sig, Sub, fmu, fvar, kl, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_sum_partials(kl.part, data->M + 1, data->M + 1, 1, trace, maha, (double*)ws + P.off_part2, (hipStream_t)stream);
 }
 
 int mfgm_cond_predict(int M, int d, int N, const int* idx, const double* P, const double* T, const double* prior_mean,

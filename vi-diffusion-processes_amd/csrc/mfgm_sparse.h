@@ -27,6 +27,16 @@ struct SparseArgs {
     const double* prior_cov;   // [d, d] the kernel's initial covariance
 };
 
+// optional KL[q || p] terms taken in the same pass as the predictions (the pair covariance of an interval holds Sigma_m and Sigma_{m,m-1}):
+// part[m] = trace term, part[M + 1 + m] = Mahalanobis term of node m / pair (m, m - 1), as kw_kl_terms (mfgm_wide.h) defines them
+struct SparseKl {
+    const double* Pd;        // [T, d, d] prior precision blocks (times aD)
+    const double* Ps;        // [T, d, d] sub-diagonal blocks P_{t+1,t} at t (times aS)
+    const double* mup;       // [T, d] prior marginal means
+    double aD, aS;
+    double* part;            // [2 (M + 1)] or NULL
+};
+
 // theta = prior naturals + overlap-added sites.  nat1 [M+1, 2d], nat2 [M+1, 2d, 2d]; plin [T, d], pdiag / psub [T, d, d] with T = M.
 static __global__ void k_sparse_theta(int T, int d, const double* __restrict__ nat1, const double* __restrict__ nat2,
                                       const double* __restrict__ plin, const double* __restrict__ pdiag,
@@ -52,11 +62,11 @@ static __global__ void k_sparse_theta(int T, int d, const double* __restrict__ n
 template <int D2P>
 static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, const double* __restrict__ mu, const double* __restrict__ Sig,
                                                              const double* __restrict__ Sub, double* __restrict__ fmu,
-                                                             double* __restrict__ fvar) {
+                                                             double* __restrict__ fvar, SparseKl kl) {
     constexpr int H = (64 / D2P < D2P) ? 64 / D2P : D2P, NR = D2P / H;          // row groups (lanes beyond H D2P idle), rows per lane
     const int m = blockIdx.x, d = a.d, d2 = 2 * d, lane = threadIdx.x;
     const int i0 = a.seg[m], i1 = a.seg[m + 1];
-    if (i0 >= i1) return;
+    if (i0 >= i1 && !kl.part) return;
     const int c = lane % D2P, h = lane / D2P;
     const bool lo_prior = (m == 0), hi_prior = (m == a.M);
     const double* S_lo = lo_prior ? a.prior_cov : Sig + (size_t)(m - 1) * d * d;
@@ -80,6 +90,39 @@ static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, cons
         const bool hi = c >= d;
         const int kk = hi ? c - d : c;
         pmc = hi ? (hi_prior ? a.prior_mean[kk] : mu[(size_t)m * d + kk]) : (lo_prior ? a.prior_mean[kk] : mu[(size_t)(m - 1) * d + kk]);
+    }
+    if (kl.part) {
+        // node m: aD Pd_m . (Sigma_m + dv_m dv_m^T);  pair (m, m-1): 2 aS Ps_{m-1} . (Sigma_{m,m-1} + dv_m dv_{m-1}^T);  dv = mu_prior - mu
+        double tr = 0.0, mh = 0.0;
+        if (!hi_prior && c < d2) {
+            const bool diag_col = c >= d;
+            const int j = diag_col ? c - d : c;
+            const bool has = diag_col || !lo_prior;
+            const double* Pblk = diag_col ? kl.Pd + (size_t)m * d * d : kl.Ps + (size_t)(has ? m - 1 : 0) * d * d;
+            const double sc = diag_col ? kl.aD : 2.0 * kl.aS;
+            const size_t tj = diag_col ? (size_t)m : (size_t)(has ? m - 1 : 0);
+            const double dvc = has ? kl.mup[tj * d + j] - mu[tj * d + j] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int r = h + H * k;
+                if (h < H && r >= d && r < d2 && has) {
+                    const int i = r - d;
+                    const double pv = sc * Pblk[i * d + j];
+                    const double dvr = kl.mup[(size_t)m * d + i] - mu[(size_t)m * d + i];
+                    tr = __builtin_fma(pv, pc[k], tr);
+                    mh = __builtin_fma(pv * dvr, dvc, mh);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            tr += __shfl_down(tr, off, 64);
+            mh += __shfl_down(mh, off, 64);
+        }
+        if (lane == 0) {
+            kl.part[m] = tr;
+            kl.part[a.M + 1 + m] = mh;
+        }
     }
     for (int i = i0; i < i1; ++i) {
         const double* w = a.w + (size_t)i * d2;

@@ -179,8 +179,19 @@ class SparseCVIGaussianProcess:
         pl = self.dist_p.plan
         N = data["N"]
         out = torch.empty((2, N), dtype=torch.float64, device=pl.device)
-        _lib.check(pl.lib.mfgm_sparse_predict(ctypes.byref(data["struct"]), _ptr(m["mu"]), _ptr(m["Sig"]), _ptr(m["Sub"]), _ptr(out[0]),
-                                              _ptr(out[1]), _stream()), "mfgm_sparse_predict")
+        import os
+        if pl.wide and os.environ.get("VIDP_FUSED_SPARSE_KL", "1") != "0":
+            # the pass over the pair covariances also takes the trace / Mahalanobis terms of KL[q || p] (what classic_elbo asks for next)
+            pn = self._prior_natural()
+            kt = torch.empty(2, dtype=torch.float64, device=pl.device)
+            _lib.check(pl.lib.mfgm_sparse_predict_kl(ctypes.byref(data["struct"]), _ptr(m["mu"]), _ptr(m["Sig"]), _ptr(m["Sub"]), _ptr(out[0]),
+                                                     _ptr(out[1]), pl.h, _ptr(pn["nat"]["diag"]), _ptr(pn["nat"]["sub"]), -2.0, -1.0,
+                                                     _ptr(self._prior_mean_packed()), _ptr(kt[0:1]), _ptr(kt[1:2]), _ptr(pl.ws), _stream()),
+                       "mfgm_sparse_predict_kl")
+            self._kl_cache = (self._version, kt[0:1], kt[1:2])
+        else:
+            _lib.check(pl.lib.mfgm_sparse_predict(ctypes.byref(data["struct"]), _ptr(m["mu"]), _ptr(m["Sig"]), _ptr(m["Sub"]), _ptr(out[0]),
+                                                  _ptr(out[1]), _stream()), "mfgm_sparse_predict")
         res = (out[0][:, None], out[1][:, None])
         self._pred_cache = (self._version, data, res)
         return res
@@ -233,7 +244,11 @@ class SparseCVIGaussianProcess:
         p = self.dist_p
         pl = p.plan
         s = m["packed"]
-        tr, mh = pl.kl_terms(s["Sig"], s["Sub"], s["x"], pn["nat"]["diag"], pn["nat"]["sub"], self._prior_mean_packed(), aD=-2.0, aS=-1.0)
+        kc = getattr(self, "_kl_cache", None)
+        if kc is not None and kc[0] == self._version:
+            tr, mh = kc[1], kc[2]          # taken together with the predictions (mfgm_sparse_predict_kl)
+        else:
+            tr, mh = pl.kl_terms(s["Sig"], s["Sub"], s["x"], pn["nat"]["diag"], pn["nat"]["sub"], self._prior_mean_packed(), aD=-2.0, aS=-1.0)
         kl = 0.5 * (tr + mh - float(p.T * p.d) + 2.0 * pn["nat"]["sumlogchol"] + 2.0 * m["logdetL"])
         return ve - kl.sum()
 
