@@ -205,6 +205,18 @@ def test_full_size_properties(amd, name, B, T, d):
     rec[:, 1:] += G @ G.transpose(-1, -2)
     assert float((rec - D).abs().max()) < 1e-12 * float(D.abs().max()) * 100
     del rec, L, G, Kx
+    if d > 8:
+        # the inverse-form sweeps (mfgm_packed_factor_form / _selinv_form, form 1) deliver the same moments
+        f3 = plan.factor(Dp, Sp, rp, want_logdet=True, want_quad=True, moments_only=True)
+        s3 = plan.selinv(f3["L"], f3["G"], f3["y"], want_sub=True, form=f3["form"])
+        plan.check_info()
+        assert f3["form"] == 1
+        np.testing.assert_allclose(f3["logdet"].cpu().numpy(), f["logdet"].cpu().numpy(), rtol=1e-12)
+        np.testing.assert_allclose(f3["quad"].cpu().numpy(), f["quad"].cpu().numpy(), rtol=1e-11)
+        assert float((plan.unpack(amd.VEC, s3["x"]) - x).abs().max()) < 1e-11
+        assert float((plan.unpack(amd.SYM, s3["Sig"]) - Sig).abs().max()) < 1e-11
+        assert float((plan.unpack(amd.FULL, s3["Sub"], T - 1) - Sub).abs().max()) < 1e-11
+        del f3, s3
     # another time partition gives the same log-determinant and solve
     plan2 = amd.Plan(B, T, d, R0=max(8, plan.R * 3 + 1), Rup=5)
     f2 = plan2.factor(plan2.pack(amd.SYM, D), plan2.pack(amd.FULL, S), plan2.pack(amd.VEC, r), want_logdet=True)
@@ -246,5 +258,14 @@ def test_random_partitions(amd):
                 assert_close(plan.unpack(amd.FULL, s["Sub"], T - 1).cpu().numpy(), Ss)
             x = np_btd.solve(Ld, Ls, np_btd.solve(Ld, Ls, r), transpose_left=True)
             assert_close(plan.unpack(amd.VEC, s["x"]).cpu().numpy(), x)
+            if d > 8:      # the same moments from the inverse-form sweeps
+                f = plan.factor(plan.pack(amd.SYM, _dev(diag)), Sp, plan.pack(amd.VEC, _dev(r)), want_logdet=True, moments_only=True)
+                s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True, form=f["form"])
+                plan.check_info()
+                np.testing.assert_allclose(f["logdet"].cpu().numpy(), np_btd.abs_log_det(Ld), rtol=1e-9, atol=1e-9)
+                assert_close(plan.unpack(amd.SYM, s["Sig"]).cpu().numpy(), Sd)
+                assert_close(plan.unpack(amd.VEC, s["x"]).cpu().numpy(), x)
+                if T > 1:
+                    assert_close(plan.unpack(amd.FULL, s["Sub"], T - 1).cpu().numpy(), Ss)
         except AssertionError as e:
             raise AssertionError(ctx + "\n" + str(e)) from None

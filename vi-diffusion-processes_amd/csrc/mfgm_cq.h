@@ -49,6 +49,20 @@ MFGM_DEV void st_part(double* __restrict__ base, int R, int s, LaneRef w, const 
 }
 MFGM_DEV int cq_slot(const int* __restrict__ slot, int R, int s, LaneRef w) { return slot[((size_t)w.tile * R + s) * 64 + w.l]; }
 
+// a value that is the same in every lane, pinned to scalar registers
+MFGM_DEV double cq_uniform(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+// the data-site block every observation adds to theta_diag, read ONCE per kernel into scalar registers: read inside the node loop it
+// costs ET dependent loads per node, each behind an s_waitcnt vmcnt(0) that also drains the prefetch of the next record
+template <int ET>
+MFGM_DEV void cq_site_sym(const CqArgs& q, bool sites, double (&ssym)[ET]) {
+#pragma unroll
+    for (int e = 0; e < ET; ++e) ssym[e] = sites ? q.site_sym[e] : 0.0;
+#pragma unroll
+    for (int e = 0; e < ET; ++e) ssym[e] = cq_uniform(ssym[e]);
+}
+
 // theta_sub block of a transition from its diagonal
 template <int D>
 MFGM_DEV void cq_sub(const double (&sd)[D], double sOff, double (&G)[D * D]) {
@@ -72,6 +86,8 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
     const int len = min(R, a.lv.n - p * R);
     const bool sites = (q.slot != nullptr);
     int bad = 0;
+    double ssym[ET];
+    cq_site_sym<ET>(q, sites, ssym);
 
     double F[ET], W[EF], h[D], Racc[ET], rho[D], sdc[D];     // sdc: diag theta_sub of the node being eliminated
     {
@@ -86,7 +102,7 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
         for (int i = 0; i < D; ++i) { h[i] = r0[i]; sdc[i] = r0[2 * D + i]; }
         if (s0 >= 0) {
 #pragma unroll
-            for (int e = 0; e < ET; ++e) F[e] += q.site_sym[e];
+            for (int e = 0; e < ET; ++e) F[e] += ssym[e];
 #pragma unroll
             for (int i = 0; i < D; ++i) h[i] += q.site_lin[(size_t)s0 * D + i];
         }
@@ -161,7 +177,7 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
             for (int i = 0; i < D; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
-                    const double dn = ((i == j) ? rc[D + i] : q.dOff) + (sites ? cnt * q.site_sym[tix(i, j)] : 0.0);
+                    const double dn = __builtin_fma(cnt, ssym[tix(i, j)], (i == j) ? rc[D + i] : q.dOff);
                     F[tix(i, j)] = __builtin_fma(a.aD, dn, -F[tix(i, j)]);
                 }
 #pragma unroll
@@ -222,6 +238,8 @@ static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q)
     const int len = min(R, n - p * R);
     const bool sites = (q.slot != nullptr);
     int bad = 0;
+    double ssym[ET];
+    cq_site_sym<ET>(q, sites, ssym);
 
     double C[ET], c[D];
 #pragma unroll
@@ -300,7 +318,7 @@ static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q)
             for (int i = 0; i < D; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
-                    const double dn = ((i == j) ? rn[D + i] : q.dOff) + (sites ? cnt * q.site_sym[tix(i, j)] : 0.0);
+                    const double dn = __builtin_fma(cnt, ssym[tix(i, j)], (i == j) ? rn[D + i] : q.dOff);
                     F[tix(i, j)] = __builtin_fma(a.aD, dn, -C[tix(i, j)]);
                 }
 #pragma unroll

@@ -97,6 +97,15 @@ struct SweepArgs {
 // ---- reduce -------------------------------------------------------------------------------------
 // The bodies are device functions of (lane, me): the per-level kernels call them with the wave's uniform tile (me = {blockIdx.x,
 // threadIdx.x}: scalar node pointers), the fused coarse-level kernels (k_coarse_*) with arbitrary lanes of one chain.
+// Keep a batch of loads a batch: an empty asm that "modifies" every value makes the loads complete where the batch was issued.  Without
+// it the compiler, under register pressure, sinks each load to its point of use and waits for it there -- on the latency-bound coarse
+// levels that turned one memory round trip per step into ~25 dependent ones (global_load; s_waitcnt vmcnt(0); use; ... in the ISA).
+template <int N>
+MFGM_DEV void pin_loaded(double (&v)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) asm volatile("" : "+v"(v[e]));
+}
+
 template <int D, bool HAS_RHS, bool HAS_CORR>
 MFGM_DEV void reduce_body(const SweepArgs& a, const int lane, const LaneRef me) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
@@ -159,6 +168,10 @@ MFGM_DEV void reduce_body(const SweepArgs& a, const int lane, const LaneRef me) 
                 load_step(s, G, Dcur, rcur);
                 ld_node<ET, HAS_CORR>(a.Dcorr, R, s + 1, me, Dc_);
                 if (HAS_RHS) ld_node<D, HAS_CORR>(a.rcorr, R, s + 1, me, rc_);
+                pin_loaded(G);
+                pin_loaded(Dcur);
+                pin_loaded(Dc_);
+                if (HAS_RHS) { pin_loaded(rcur); pin_loaded(rc_); }
             } else {
 #pragma unroll
                 for (int e = 0; e < EF; ++e) G[e] = Gn[e];
