@@ -283,6 +283,116 @@ MFGM_DEV Mat<NT> ld_sub(const double* __restrict__ base, int ld, int row0, int c
     return m;
 }
 
+// Loads whose values are consumed later: the raw doubles of a (sub-)block / vector now, scale and padding when they are needed
+// (fix_*), so that a pass can request the next node's inputs before the pivot inverse of the current one and touch them after it --
+// scaling inside the load makes the compiler wait for the data where the load was issued.
+template <int NT>
+struct RawMat {
+    double x[NT][NT][4];
+};
+template <int NT>
+struct RawCol {
+    double x[NT];
+};
+template <int NT, bool TRANSPOSED>
+MFGM_DEV RawMat<NT> ld_raw(const double* __restrict__ base, int ld, int row0, int col0, int d, const LaneId& L) {
+    RawMat<NT> m;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * I + L.g + 4 * i, c = 16 * J + L.c;
+                const bool ok = r < d && c < d;
+                m.x[I][J][i] = base[ok ? (TRANSPOSED ? (row0 + c) * ld + col0 + r : (row0 + r) * ld + col0 + c) : 0];
+            }
+    return m;
+}
+// acc + scale * raw (zero outside d x d; PAD_EYE: plus an identity on the padded diagonal)
+template <int NT, bool PAD_EYE>
+MFGM_DEV Mat<NT> fix_mat(const RawMat<NT>& raw, int d, const LaneId& L, double scale, const Mat<NT>& acc) {
+    Mat<NT> m;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * I + L.g + 4 * i, c = 16 * J + L.c;
+                const bool ok = r < d && c < d;
+                m.t[I][J].r[i] = __builtin_fma(raw.x[I][J][i], ok ? scale : 0.0, acc.t[I][J].r[i] + ((!ok && PAD_EYE && r == c) ? 1.0 : 0.0));
+            }
+    return m;
+}
+template <int NT>
+MFGM_DEV RawCol<NT> ld_col_raw(const double* __restrict__ v, int d, const LaneId& L) {
+    RawCol<NT> o;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) o.x[J] = v[(16 * J + L.c < d) ? 16 * J + L.c : 0];
+    return o;
+}
+template <int NT>
+MFGM_DEV ColVec<NT> fix_col(const RawCol<NT>& raw, int d, const LaneId& L, double scale, const ColVec<NT>& acc) {
+    ColVec<NT> o;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) o.c[J] = __builtin_fma(raw.x[J], (16 * J + L.c < d) ? scale : 0.0, acc.c[J]);
+    return o;
+}
+
+// The inputs of one node of a pass (diagonal block, its Gram correction, right-hand side and its correction, and -- sparse-CVI
+// inputs -- the site quadrants / halves that are overlap-added), raw.  HAS_S: also the sub-diagonal block S_t (TRANSPOSED_S: as S_t^T).
+template <int NT>
+struct RawNode {
+    RawMat<NT> D, Dc, Shi, Slo, S, Ss;
+    RawCol<NT> r, rc, s1, s2;
+};
+template <int NT, bool HAS_RHS, bool HAS_CORR, bool SITES, bool TRANSPOSED_S>
+MFGM_DEV void ld_node_raw(const WideArgs& a, int b, int t, bool want_S, const LaneId& L, RawNode<NT>& o) {
+    const int d = a.d, EF = d * d, d2 = 2 * d, n = a.lv.n;
+    o.D = ld_raw<NT, false>(wblk(a.Dg, b, n, t, EF), d, 0, 0, d, L);
+    if (HAS_CORR) o.Dc = ld_raw<NT, false>(wblk(a.Dcorr, b, n, t, EF), d, 0, 0, d, L);
+    if (SITES) {
+        o.Shi = ld_raw<NT, false>(a.site2 + (size_t)(t + 1) * d2 * d2, d2, 0, 0, d, L);
+        o.Slo = ld_raw<NT, false>(a.site2 + (size_t)t * d2 * d2, d2, d, d, d, L);
+    }
+    if (want_S) {
+        o.S = ld_raw<NT, TRANSPOSED_S>(wblk(a.Sg, b, n, t, EF), d, 0, 0, d, L);
+        if (SITES) o.Ss = ld_raw<NT, TRANSPOSED_S>(a.site2 + (size_t)(t + 1) * d2 * d2, d2, d, 0, d, L);
+    }
+    if (HAS_RHS) {
+        if (a.rg) o.r = ld_col_raw<NT>(wblk(a.rg, b, n, t, d), d, L);
+        if (HAS_CORR) o.rc = ld_col_raw<NT>(wblk(a.rcorr, b, n, t, d), d, L);
+        if (SITES) {
+            o.s1 = ld_col_raw<NT>(a.site1 + (size_t)(t + 1) * d2, d, L);
+            o.s2 = ld_col_raw<NT>(a.site1 + (size_t)t * d2 + d, d, L);
+        }
+    }
+}
+template <int NT, bool HAS_CORR, bool SITES>
+MFGM_DEV Mat<NT> node_F(const WideArgs& a, const RawNode<NT>& o, const LaneId& L) {
+    Mat<NT> F = fix_mat<NT, true>(o.D, a.d, L, a.aD, mat_zero<NT>());
+    if (HAS_CORR) F = fix_mat<NT, false>(o.Dc, a.d, L, -1.0, F);
+    if (SITES) F = fix_mat<NT, false>(o.Slo, a.d, L, a.aD, fix_mat<NT, false>(o.Shi, a.d, L, a.aD, F));
+    return F;
+}
+template <int NT, bool SITES>
+MFGM_DEV Mat<NT> node_S(const WideArgs& a, const RawNode<NT>& o, const LaneId& L) {
+    Mat<NT> S = fix_mat<NT, false>(o.S, a.d, L, a.aS, mat_zero<NT>());
+    if (SITES) S = fix_mat<NT, false>(o.Ss, a.d, L, 2.0 * a.aS, S);
+    return S;
+}
+template <int NT, bool HAS_RHS, bool HAS_CORR, bool SITES>
+MFGM_DEV ColVec<NT> node_h(const WideArgs& a, const RawNode<NT>& o, const LaneId& L) {
+    ColVec<NT> h = col_zero<NT>();
+    if (HAS_RHS) {
+        if (a.rg) h = fix_col<NT>(o.r, a.d, L, a.aR, h);
+        if (HAS_CORR) h = fix_col<NT>(o.rc, a.d, L, -1.0, h);
+        if (SITES) h = fix_col<NT>(o.s2, a.d, L, a.aR, fix_col<NT>(o.s1, a.d, L, a.aR, h));
+    }
+    return h;
+}
+
 // Posterior naturals of the sparse-CVI model at node t, formed on load (WideArgs::site1 / site2): site t + 1 has state t as the first
 // of its pair, site t as the second
 template <int NT>
@@ -333,11 +443,6 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
         if (SITES) S = mat_add<NT>(S, site_sub<NT, false>(a, t, L));
         return S;
     };
-    auto ld_St = [&](int t) {           // S_t^T
-        Mat<NT> S = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS);
-        if (SITES) S = mat_add<NT>(S, site_sub<NT, true>(a, t, L));
-        return S;
-    };
     Mat<NT> F = ld_F(t0);
     Mat<NT> W = (p > 0) ? ld_S(t0 - 1) : mat_zero<NT>();
     ColVec<NT> hc = HAS_RHS ? ld_h(t0) : col_zero<NT>();
@@ -345,10 +450,16 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
     ColVec<NT> rho = col_zero<NT>();
     for (int s = 0; s < len - 1; ++s) {
         const int t = t0 + s;
-        const Mat<NT> St = ld_St(t);
-        Mat<NT> Fn = ld_F(t + 1);
-        ColVec<NT> hn = HAS_RHS ? ld_h(t + 1) : col_zero<NT>();
+        // the next node's inputs and S_t^T are requested now and touched after the pivot inverse, which covers their latency
+        RawNode<NT> nx;
+        ld_node_raw<NT, HAS_RHS, HAS_CORR, SITES, true>(a, b, t + 1, false, L, nx);
+        nx.S = ld_raw<NT, true>(wblk(a.Sg, b, n, t, EF), d, 0, 0, d, L);
+        if (SITES) nx.Ss = ld_raw<NT, true>(a.site2 + (size_t)(t + 1) * (4 * EF), 2 * d, d, 0, d, L);
         sweep_inv<NT>(F, L, la, bad, ldsE);                          // (the determinant is not an output of this pass)
+        __builtin_amdgcn_sched_barrier(0);
+        const Mat<NT> St = node_S<NT, SITES>(a, nx, L);
+        Mat<NT> Fn = node_F<NT, HAS_CORR, SITES>(a, nx, L);
+        ColVec<NT> hn = node_h<NT, HAS_RHS, HAS_CORR, SITES>(a, nx, L);
         const Mat<NT> nSt = mat_neg<NT>(St);
         const Mat<NT> TW = gram<NT>(F, W);                     // F^{-1} W
         {
@@ -427,41 +538,18 @@ static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
         }
     }
     double quad = 0.0;                       // per lane: sum over the nodes of h_c z_c for the lane's column
-    // the inputs of a node are loaded one node ahead: the pivot inverse of the current node covers their latency
-    auto ld_node_F = [&](int t) {
-        Mat<NT> F = ld_mat<NT, false, true>(wblk(a.Dg, b, n, t, EF), d, L, a.aD);
-        if (HAS_CORR) F = mat_sub<NT>(F, ld_mat<NT, false, false>(wblk(a.Dcorr, b, n, t, EF), d, L, 1.0));
-        if (SITES) F = mat_add<NT>(F, site_diag<NT>(a, t, L));
-        return F;
-    };
-    auto ld_node_S = [&](int t) {
-        if (t + 1 >= n) return mat_zero<NT>();
-        Mat<NT> S = ld_mat<NT, true, false>(wblk(a.Sg, b, n, t, EF), d, L, a.aS);
-        if (SITES) S = mat_add<NT>(S, site_sub<NT, true>(a, t, L));
-        return S;
-    };
-    auto ld_node_h = [&](int t) {
-        ColVec<NT> h = col_zero<NT>();
-        if (HAS_RHS) {
-            if (a.rg) h = ld_col<NT>(wblk(a.rg, b, n, t, d), d, L, a.aR);
-            if (HAS_CORR) h = col_sub<NT>(h, ld_col<NT>(wblk(a.rcorr, b, n, t, d), d, L, 1.0));
-            if (SITES) h = col_add<NT>(h, site_lin<NT>(a, t, L));
-        }
-        return h;
-    };
-    Mat<NT> Fraw = ld_node_F(t0), Sraw = ld_node_S(t0);
-    ColVec<NT> hraw = ld_node_h(t0);
+    // the inputs of a node are requested one node ahead (raw) and touched at the top of its own step: the pivot inverse and the products
+    // of the current node cover their latency
+    RawNode<NT> nx;
+    ld_node_raw<NT, HAS_RHS, HAS_CORR, SITES, true>(a, b, t0, t0 + 1 < n, L, nx);
     for (int s = 0; s < len; ++s) {
         const int t = t0 + s;
-        Mat<NT> F = mat_sub<NT>(Fraw, C);
-        const ColVec<NT> h = col_sub<NT>(hraw, cv);
-        const Mat<NT> St = Sraw;
         const bool has_next = (t + 1 < n);
-        if (s + 1 < len) {
-            Fraw = ld_node_F(t + 1);
-            Sraw = ld_node_S(t + 1);
-            hraw = ld_node_h(t + 1);
-        }
+        Mat<NT> F = mat_sub<NT>(node_F<NT, HAS_CORR, SITES>(a, nx, L), C);
+        const ColVec<NT> h = col_sub<NT>(node_h<NT, HAS_RHS, HAS_CORR, SITES>(a, nx, L), cv);
+        const Mat<NT> St = has_next ? node_S<NT, SITES>(a, nx, L) : mat_zero<NT>();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < len) ld_node_raw<NT, HAS_RHS, HAS_CORR, SITES, true>(a, b, t + 1, t + 2 < n, L, nx);
         if (a.Sigg) {
             st_mat<NT, false>(wblk(a.Sigg, b, n, t, EF), d, L, F);
             if (HAS_RHS) st_col<NT>(wblk(a.mug, b, n, t, d), d, L, h);

@@ -537,6 +537,13 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
     const int len = min(R, n - p * R);
     (void)b;
     const int N = n - 1;                     // number of transitions; psi / lambda live on nodes 0 .. N-1
+    // the block every observation contributes, read once into scalar registers (read inside the node loop it is ET loads per node)
+    double dcst[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) dcst[e] = obs_count ? dobs_const[e] : 0.0;
+#pragma unroll
+    for (int e = 0; e < ET; ++e)
+        dcst[e] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dcst[e])), __builtin_amdgcn_readfirstlane(__double2loint(dcst[e])));
     // state: psi (full), lam (the running products of the segment maps are k_vdp_lagrange_products' job)
     double psi[EF], lam[D];
     if (PASS == 1) {
@@ -568,29 +575,30 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                     ld_node<D>(bm, R, s, me, bb);
                 }
                 if (PASS == 4) {
-                    // update_param at node t (vi_sde.py:377-414) from the multipliers just obtained
-                    double pc[EF], lc[D];
-#pragma unroll
-                    for (int e = 0; e < EF; ++e) pc[e] = pr.clip > 0.0 ? vdp_stab(psi[e], pr.clip) : psi[e];
-#pragma unroll
-                    for (int i = 0; i < D; ++i) lc[i] = pr.clip > 0.0 ? vdp_stab(lam[i], pr.clip) : lam[i];
-                    st_node<EF>(psig, R, s, me, pc);
-                    st_node<D>(lamg, R, s, me, lc);
+                    // update_param at node t (vi_sde.py:377-414) from the multipliers just obtained.  Element by element, straight to
+                    // memory: the clipped multipliers, A~ = 2 q psi_c - diag(J) and the blended A never exist as arrays (this kernel
+                    // has no registers to spare: three more d x d arrays put it into scratch)
                     double Ef[D], Jf[D], Vf[D], t0[D], t1[D], t2[D], t3[D], t4[D];
                     drift_moments<D>(pr, m, S, Ef, Jf, Vf, t0, t1, t2, t3, t4);
-                    double At[EF], bt[D], An[EF], bn[D];
+                    double* pP = psig + ((size_t)me.tile * R + s) * (size_t)(EF * 64) + me.l;
+                    double* pA = Am + ((size_t)me.tile * R + s) * (size_t)(EF * 64) + me.l;
+                    double bn[D];
 #pragma unroll
-                    for (int i = 0; i < D; ++i)
+                    for (int i = 0; i < D; ++i) {
+                        const double lc = pr.clip > 0.0 ? vdp_stab(lam[i], pr.clip) : lam[i];
+                        double bt = Ef[i] - pr.q[i] * lc;
 #pragma unroll
-                        for (int j = 0; j < D; ++j) At[i * D + j] = 2.0 * pr.q[i] * pc[i * D + j] - (i == j ? Jf[i] : 0.0);
-                    gemv<D>(At, m, bt);
-#pragma unroll
-                    for (int i = 0; i < D; ++i) bt[i] += Ef[i] - pr.q[i] * lc[i];
-#pragma unroll
-                    for (int e = 0; e < EF; ++e) An[e] = (1.0 - pr.lr) * A[e] + pr.lr * At[e];
-#pragma unroll
-                    for (int i = 0; i < D; ++i) bn[i] = (1.0 - pr.lr) * bb[i] + pr.lr * bt[i];
-                    st_node<EF>(Am, R, s, me, An);
+                        for (int j = 0; j < D; ++j) {
+                            const double pc = pr.clip > 0.0 ? vdp_stab(psi[i * D + j], pr.clip) : psi[i * D + j];
+                            const double At = 2.0 * pr.q[i] * pc - (i == j ? Jf[i] : 0.0);
+                            bt = __builtin_fma(At, m[j], bt);
+                            pP[(i * D + j) * 64] = pc;
+                            pA[(i * D + j) * 64] = (1.0 - pr.lr) * A[i * D + j] + pr.lr * At;
+                        }
+                        t0[i] = lc;
+                        bn[i] = (1.0 - pr.lr) * bb[i] + pr.lr * bt;
+                    }
+                    st_node<D>(lamg, R, s, me, t0);
                     st_node<D>(bm, R, s, me, bn);
                 }
                 if (t >= 1) {
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                         // d (d + 1) / 2 doubles that are zero at all but the observation nodes
                         const double cnt = (double)obs_count[((size_t)me.tile * R + s) * 64 + me.l];
 #pragma unroll
-                        for (int e = 0; e < ET; ++e) dob[e] = cnt * dobs_const[e];
+                        for (int e = 0; e < ET; ++e) dob[e] = cnt * dcst[e];
                     } else {
                         ld_node<ET>(dobsS, R, s, me, dob);
                     }
