@@ -401,6 +401,29 @@ MFGM_DEV void cq_store_blocks(const SdeParams& pr, const CqArgs& q, int R, int s
     st_part<3 * D, D, D>(q.dyn_out, R, s, w, ad);
     st_part<3 * D, 2 * D, D>(q.dyn_out, R, s, w, sd);
 }
+// the same with the old values already in registers (requested a step ahead by the sweep)
+template <int D>
+MFGM_DEV void cq_store_blocks_pre(const SdeParams& pr, const CqArgs& q, int R, int s, LaneRef w, const double (&dg)[D],
+                                  const double (&sb)[D], const double (&Sdiag)[D], const double (&ad_old)[D]) {
+    const double lr = pr.lr, kp = 1.0 - pr.lr;
+    double ad[D], sd[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        ad[i] = kp * ad_old[i] + lr * dg[i];
+        sd[i] = kp * Sdiag[i] + lr * sb[i];
+    }
+    st_part<3 * D, D, D>(q.dyn_out, R, s, w, ad);
+    st_part<3 * D, 2 * D, D>(q.dyn_out, R, s, w, sd);
+}
+template <int D>
+MFGM_DEV void cq_store_lin_pre(const SdeParams& pr, const CqArgs& q, int R, int s, LaneRef w, const double (&own)[D],
+                               const double (&prev)[D], const double (&lin_old)[D]) {
+    const double lr = pr.lr, kp = 1.0 - pr.lr;
+    double a1[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) a1[i] = kp * lin_old[i] + lr * (own[i] + prev[i]);
+    st_part<3 * D, 0, D>(q.dyn_out, R, s, w, a1);
+}
 template <int D>
 MFGM_DEV void cq_store_lin(const SdeParams& pr, const CqArgs& q, int R, int s, LaneRef w, const double (&own)[D],
                            const double (&prev)[D]) {
@@ -448,23 +471,30 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov_cq(SweepArgs a,
         for (int i = 0; i < D; ++i) pend[i] = lin[i];
     }
 
-    double Ln[ET], Gdn[D], yn[D];
+    // the record parts a step reads -- theta_sub and theta_diag of the node it visits, theta_lin of the node above it -- are all
+    // requested one step ahead (the old theta_diag / theta_lin used to be read at the end of the step that blends them: two more
+    // memory round trips per node on the critical path)
+    double Ln[ET], Gdn[D], yn[D], adn[D], l1n[D];
     if (len > 1) {
         ld_node<ET>(a.Lg, R, se - 1, me, Ln);
         ld_part<E3, 2 * D, D>(q.dyn, R, se - 1, me, Gdn);
+        ld_part<E3, D, D>(q.dyn, R, se - 1, me, adn);
+        ld_part<E3, 0, D>(q.dyn, R, se, me, l1n);
         ld_node<D>(a.yg, R, se - 1, me, yn);
     }
     for (int s = R - 2; s >= 0; --s) {
         if (s < len - 1) {
-            double Lt[ET], G[EF], x[D], Gd[D];
+            double Lt[ET], G[EF], x[D], Gd[D], adc[D], l1c[D];
 #pragma unroll
             for (int e = 0; e < ET; ++e) Lt[e] = Ln[e];
 #pragma unroll
-            for (int e = 0; e < D; ++e) { Gd[e] = Gdn[e]; x[e] = yn[e]; }
+            for (int e = 0; e < D; ++e) { Gd[e] = Gdn[e]; x[e] = yn[e]; adc[e] = adn[e]; l1c[e] = l1n[e]; }
             cq_sub<D>(Gd, q.sOff, G);
             if (s > 0) {
                 ld_node<ET>(a.Lg, R, s - 1, me, Ln);
                 ld_part<E3, 2 * D, D>(q.dyn, R, s - 1, me, Gdn);
+                ld_part<E3, D, D>(q.dyn, R, s - 1, me, adn);
+                ld_part<E3, 0, D>(q.dyn, R, s, me, l1n);
                 ld_node<D>(a.yg, R, s - 1, me, yn);
             }
             double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET], tg[D];
@@ -474,13 +504,13 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov_cq(SweepArgs a,
 #pragma unroll
             for (int i = 0; i < D; ++i) { v[i] = Sig[tix(i, i)]; c[i] = Ssub[i * D + i]; }
             girsanov_node<D>(pr, true, x, v, c, xn, lin, dg, sb, wd);
-            cq_store_blocks<D>(pr, q, R, s, me, true, dg, sb, Gd);
+            cq_store_blocks_pre<D>(pr, q, R, s, me, dg, sb, Gd, adc);
             if (s + 1 == se && !last) {
                 // the separator's theta_lin is assembled by the lane on the right
 #pragma unroll
                 for (int i = 0; i < D; ++i) fix[(size_t)i * Lp + lane] = pr.lr * wd[i];
             } else {
-                cq_store_lin<D>(pr, q, R, s + 1, me, pend, wd);
+                cq_store_lin_pre<D>(pr, q, R, s + 1, me, pend, wd, l1c);
             }
 #pragma unroll
             for (int i = 0; i < D; ++i) { pend[i] = lin[i]; xn[i] = x[i]; }
