@@ -678,10 +678,12 @@ def main():
                 assert lib.mfgm_cq_factor_stage(plan.h, st, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), _ptr(plan.ws), _ptr(plan.info),
                                                 _stream()) == 0
 
+            lazy = model._q is not None and model._q["mu"] is None     # the step does not write the [B, T] marginal arrays
+
             def backward():
                 assert lib.mfgm_cq_selinv_kl(plan.h, 0, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), ctypes.byref(model._sde_prm),
-                                             _ptr(s["Sig"]), _ptr(s["x"]), _ptr(klbuf), _ptr(model.fx_mus_obs), _ptr(model.fx_covs_obs),
-                                             _ptr(plan.ws), _stream()) == 0
+                                             None if lazy else _ptr(s["Sig"]), None if lazy else _ptr(s["x"]), _ptr(klbuf),
+                                             _ptr(model.fx_mus_obs), _ptr(model.fx_covs_obs), _ptr(plan.ws), _stream()) == 0
 
             def girsanov():
                 assert lib.mfgm_cq_selinv_girsanov(plan.h, 0, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), ctypes.byref(model._sde_prm),
@@ -693,8 +695,10 @@ def main():
                  "level 0 forward: block Cholesky + forward substitution; reads the cq record and the slot, writes L and y"),
                 (f"void mfgm::k_reduce_cq<{d}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot), lambda: stage(0),
                  "level 0 reduce: segment elimination; reads the cq record and the slot"),
-                (f"void mfgm::k_backward_kl_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs)", 1, (ET + d + d + slot) + (ET + d), backward,
-                 "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, y, diag theta_sub, slot; writes Sigma, mu"),
+                (f"void mfgm::k_backward_kl_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs)", 1,
+                 (ET + d + d + slot) + (0 if lazy else ET + d), backward,
+                 "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, y, diag theta_sub, slot; writes "
+                 + ("the marginals at the observation nodes only" if lazy else "Sigma, mu")),
                 (f"void mfgm::k_backward_girsanov_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs, double*)", 1, (ET + d + E3) + E3, girsanov,
                  "level 0 backward fused with the Girsanov-site update; reads L, y, the cq record, writes the new record"),
             ]

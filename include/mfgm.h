@@ -262,8 +262,9 @@ int mfgm_cq_factor_stage(const mfgm_plan* plan, int stage, const mfgm_cq_state* 
  * the caller scales d_off / s_off by (1 - lr)).  only_level 0: the level-0 kernel alone (+ its fix-up), < 0: every level. */
 int mfgm_cq_selinv_girsanov(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
                             const mfgm_sde_params* prm, double* dyn_out, void* ws, void* stream);
-/* backward sweep with the KL sum (mfgm_packed_selinv_kl): marginals Sig (SYM), x (VEC), kl_part [B]; obs_mu [n, d] / obs_cov
- * [n, d, d] (both or neither) receive the marginals at the observation nodes, in observation order. */
+/* backward sweep with the KL sum (mfgm_packed_selinv_kl): marginals Sig (SYM), x (VEC) -- both NULL: not written, the ELBO needs only
+ * the sums and the observation nodes --, kl_part [B]; obs_mu [n, d] / obs_cov [n, d, d] (both or neither) receive the marginals at
+ * the observation nodes, in observation order. */
 int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
                       const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, double* obs_mu, double* obs_cov, void* ws,
                       void* stream);

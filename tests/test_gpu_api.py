@@ -1034,6 +1034,40 @@ def test_fused_girsanov_update_equals_two_kernel_update(amd, rng, d, kind, B, T,
             np.testing.assert_allclose(xc, xb, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(xb).max()))
 
 
+def test_cq_marginals_on_demand(amd, rng, monkeypatch):
+    """The cq refresh behind classic_elbo does not write the [B, T] marginal arrays (only the KL sum and the marginals at the observation
+    nodes); fx_mus / fx_covs produce them on demand from the factor in place -- also after another factorisation has run on the plan
+    (its coarse levels are then stale and the factor is redone) -- and equal the eager route (VIDP_LAZY_MARGINALS=0)."""
+    import torch
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    d, B, T = 6, 2, 150
+    grid = np.arange(T) * 0.02
+    idx = np.sort(rng.choice(np.arange(1, T), size=9, replace=False))
+    y = np.sign(rng.normal(size=(B, 9, d))) + 0.2 * rng.normal(size=(B, 9, d))
+    q = torch.diag(torch.from_numpy(0.5 + rng.random(d)))
+
+    def run(lazy, disturb):
+        monkeypatch.setenv("VIDP_LAZY_MARGINALS", "1" if lazy else "0")
+        m = CVISitesSDE(gsde.DoubleWellSDE(q), grid, (grid[idx], dev(y)), MultivariateGaussian(dev(0.3 * np.eye(d))),
+                        plan=amd.Plan(B, T, d, R0=8, Rup=3))
+        for _ in range(2):
+            m.update_data_sites(0.5)
+            m.update_girsanov_sites(0.3)
+        e = host(m.classic_elbo_per_trajectory())
+        assert m._cq is not None and (m._q["mu"] is None) == lazy
+        if disturb:
+            m.dist_q.marginal_means          # another factorisation on the same plan
+        return e, host(m.fx_mus), host(m.fx_covs), host(m.fx_mus_obs)
+
+    ref = run(False, False)
+    for lazy, disturb in ((True, False), (True, True)):
+        got = run(lazy, disturb)
+        for a, b in zip(got, ref):
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
+
+
 @pytest.mark.parametrize("d,B,T,stab,kind", [(1, 2, 60, False, "dw"), (2, 2, 700, False, "ou"), (3, 1, 140, True, "dw"), (6, 2, 90, True, "dw")])
 def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind):
     """update_lagrange_and_param (one set of sweeps) against update_lagrange followed by update_param, three consecutive iterations."""

@@ -506,8 +506,8 @@ int mfgm_cq_selinv_girsanov(const mfgm_plan* plan, int only_level, const mfgm_cq
 int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
                       const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, double* obs_mu, double* obs_cov, void* ws,
                       void* stream) {
-    if (!cq_ok(plan, q) || !L || !y || !prm || !Sig || !x || !kl_part || !ws || prm->kind != 0) return 1;
-    if ((obs_mu != nullptr) != (obs_cov != nullptr)) return 1;
+    if (!cq_ok(plan, q) || !L || !y || !prm || !kl_part || !ws || prm->kind != 0) return 1;
+    if ((obs_mu != nullptr) != (obs_cov != nullptr) || (Sig != nullptr) != (x != nullptr)) return 1;
     const Plan& P = plan->p;
     SdeParams pr;
     memcpy(&pr, prm, sizeof(pr));

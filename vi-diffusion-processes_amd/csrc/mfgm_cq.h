@@ -606,8 +606,11 @@ static __global__ __launch_bounds__(64) void k_backward_kl_cq(SweepArgs a, SdePa
         ld_node<ET, true>(a.uSig, uR, us, LaneRef::of(ul), Sn);
         ld_node<D, true>(a.umu, uR, us, LaneRef::of(ul), xn);
     }
-    st_node<ET>(a.Sigg, R, se, me, Sn);
-    st_node<D>(a.mug, R, se, me, xn);
+    const bool keep = (a.Sigg != nullptr);       // the marginal arrays are optional: the ELBO needs the sums and the observation nodes only
+    if (keep) {
+        st_node<ET>(a.Sigg, R, se, me, Sn);
+        st_node<D>(a.mug, R, se, me, xn);
+    }
     if (obs) cq_store_obs<D>(q, cq_slot(q.slot, R, se, me), xn, Sn);
 
     double Ln[ET], Gdn[D], yn[D];
@@ -636,8 +639,10 @@ static __global__ __launch_bounds__(64) void k_backward_kl_cq(SweepArgs a, SdePa
             double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET], tg[D];
             backward_s_head<D>(Lt, G, a.aS, xn, invd, X, Sig, H, tg);
             backward_s_tail<D>(Lt, invd, X, a.aS, Sn, H, tg, Sig, Ssub, x);
-            st_node<D>(a.mug, R, s, me, x);
-            st_node<ET>(a.Sigg, R, s, me, Sig);
+            if (keep) {
+                st_node<D>(a.mug, R, s, me, x);
+                st_node<ET>(a.Sigg, R, s, me, Sig);
+            }
             if (obs) cq_store_obs<D>(q, sc, x, Sig);
             double v[D], c[D], vn[D];
 #pragma unroll

@@ -352,10 +352,14 @@ class Plan:
                                                     _ptr(dyn_out), _ptr(self.ws), _stream()), "mfgm_cq_selinv_girsanov")
         return dyn_out
 
-    def cq_selinv_kl(self, cq, L, y, prm, out=None, obs_mu=None, obs_cov=None, only_level=-1):
+    def cq_selinv_kl(self, cq, L, y, prm, out=None, obs_mu=None, obs_cov=None, only_level=-1, want_marginals=True):
+        """want_marginals=False: the marginal arrays are not written (Sig, x = None in the result); the KL sum and the marginals at
+        the observation nodes are all the ELBO needs."""
         out = {} if out is None else out
-        Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
-        x = out.get("x") if out.get("x") is not None else self.empty(VEC)
+        Sig = x = None
+        if want_marginals:
+            Sig = out.get("Sig") if out.get("Sig") is not None else self.empty(SYM)
+            x = out.get("x") if out.get("x") is not None else self.empty(VEC)
         kl = torch.empty(self.B, dtype=torch.float64, device=self.device)
         _lib.check(self.lib.mfgm_cq_selinv_kl(self.h, int(only_level), ctypes.byref(cq.struct()), _ptr(L), _ptr(y), ctypes.byref(prm), _ptr(Sig),
                                               _ptr(x), _ptr(kl), _ptr(obs_mu), _ptr(obs_cov), _ptr(self.ws), _stream()), "mfgm_cq_selinv_kl")

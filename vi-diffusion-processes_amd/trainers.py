@@ -128,7 +128,7 @@ class CVISitesTrainer:
         return elbo_vals[1:], nlpd_vals, rmse_vals
 
     def _nlpd_rmse(self):
-        q = self.model._refresh()
+        q = self.model._refresh(want_marginals=True)
         return self._metrics(q["mu"], q["Sig"])
 
     def _optimize_sites_under_stable_prior(self):

@@ -157,7 +157,7 @@ class CVISitesSSM:
         """True when the level-0 backward sweep can do the model's local work itself (CVISitesSDE, mfgm_girsanov.h)."""
         return False
 
-    def _refresh(self, want_sub=None, want_mom=None):
+    def _refresh(self, want_sub=None, want_mom=None, want_marginals=False):
         """theta_q -> (L, log|L|, mu, Sigma_tt, [Sigma_{t+1,t}], [moments | KL sum]) in one forward and one backward sweep."""
         want_sub = self._need_sub if want_sub is None else want_sub
         fuse = self._sweep_fusion() and not want_sub
@@ -200,7 +200,7 @@ class CVISitesSSM:
         return naturals_to_ssm_params_packed(self.plan, tq.lin, tq.diag, tq.sub)
 
     def _gather_obs(self):
-        q = self._refresh()
+        q = self._refresh(want_marginals=True)
         # persistent buffers, updated in place: the state that crosses iterations keeps its addresses (a captured HIP graph
         # of one iteration can then be replayed)
         self.plan.gather_nodes_pair(q["mu"], q["Sig"], self.obs_node_ids, self.fx_mus_obs, self.fx_covs_obs)
@@ -208,11 +208,11 @@ class CVISitesSSM:
 
     @property
     def fx_mus(self):
-        return self.plan.unpack(VEC, self._refresh()["mu"])
+        return self.plan.unpack(VEC, self._refresh(want_marginals=True)["mu"])
 
     @property
     def fx_covs(self):
-        return self.plan.unpack(SYM, self._refresh()["Sig"])
+        return self.plan.unpack(SYM, self._refresh(want_marginals=True)["Sig"])
 
     # -- updates -------------------------------------------------------------------------------------------
     def _obs_flat(self):
@@ -330,7 +330,8 @@ class CVISitesSDE(CVISitesSSM):
     def _path_packed(self):
         """Current posterior path (mu, Sigma) in packed form: the initial path before the first refresh."""
         if self._q is not None:
-            return self._q["mu"], self._q["Sig"]
+            q = self._refresh(want_marginals=True)      # the cq refresh leaves the marginal arrays out until someone asks
+            return q["mu"], q["Sig"]
         if self._path is not None:
             return self._path
         pl, d = self.plan, self.state_dim
@@ -544,21 +545,37 @@ class CVISitesSDE(CVISitesSSM):
         cq.site_sym.lerp_(self._cq_g2[1], lr)
         self._q, self._cq_dense, self._obs_fresh = None, None, False
 
-    def _refresh(self, want_sub=None, want_mom=None):
+    def _refresh(self, want_sub=None, want_mom=None, want_marginals=False):
+        """want_marginals: the full marginal arrays (mu, Sig) are wanted.  The ELBO / site-update loop needs only the KL sum and the
+        marginals at the observation nodes, which the backward sweep hands over directly; the [B, T] marginal arrays (216 B per node
+        of writes at d = 6) are produced on demand by one more backward pass over the factor that is still in place."""
         cq = self._cq_state()
         want_sub_ = self._need_sub if want_sub is None else want_sub
         if cq is None or want_sub_ or want_mom:
             return super()._refresh(want_sub=want_sub, want_mom=want_mom)      # dense route (on the materialised naturals in cq mode)
+        pl = self.plan
+        obs = cq.slot is not None
+        lazy = obs and not want_marginals and os.environ.get("VIDP_LAZY_MARGINALS", "1") != "0"
         if self._q is None:
-            pl = self.plan
             f = pl.cq_factor(cq, want_logdet=True, out=self._bufs["f"])
             self._bufs["f"].update(L=f["L"], y=f["y"])
-            obs = cq.slot is not None
             s = pl.cq_selinv_kl(cq, f["L"], f["y"], self._sde_prm, out=self._bufs["s"], obs_mu=self.fx_mus_obs if obs else None,
-                                obs_cov=self.fx_covs_obs if obs else None)
-            self._bufs["s"].update(Sig=s["Sig"], x=s["x"])
-            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=None, mom=None, klpart=s["klpart"])
+                                obs_cov=self.fx_covs_obs if obs else None, want_marginals=not lazy)
+            if not lazy:
+                self._bufs["s"].update(Sig=s["Sig"], x=s["x"])
+            self._q = dict(logdetL=f["logdet"], mu=s["x"], Sig=s["Sig"], Sub=None, mom=None, klpart=s["klpart"], epoch=pl.epoch)
             self._obs_fresh = obs
+        elif self._q["mu"] is None and not lazy:
+            # the marginal arrays after all: the factor of this posterior is in the buffers (and its coarse levels in the workspace,
+            # unless another factorisation ran on the plan since)
+            f = self._bufs["f"]
+            if self._q.get("epoch") != pl.epoch:
+                f = pl.cq_factor(cq, want_logdet=False, out=self._bufs["f"])
+                self._q["epoch"] = pl.epoch
+            s = pl.cq_selinv_kl(cq, f["L"], f["y"], self._sde_prm, out=self._bufs["s"], obs_mu=self.fx_mus_obs if obs else None,
+                                obs_cov=self.fx_covs_obs if obs else None, want_marginals=True)
+            self._bufs["s"].update(Sig=s["Sig"], x=s["x"])
+            self._q.update(mu=s["x"], Sig=s["Sig"])
         return self._q
 
     def variational_expectation(self):
@@ -644,7 +661,7 @@ class CVISitesSDE(CVISitesSSM):
         re-linearised at the current posterior.
         """
         sde = self.prior_sde
-        q = self._refresh()
+        q = self._refresh(want_marginals=True)
         path = (q["mu"].clone(), q["Sig"].clone())
 
         def neg_ve():
