@@ -25,9 +25,11 @@ for c in c1 c2 c3 c5; do python bench.py --config $c > $O/bench_$c.json 2> $O/be
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c5_profiled.json 2> /dev/null
 cp $(find $O/stats_c5 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c5.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 $R/bench.py --config c3 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c3_profiled.json 2> /dev/null
+cp $(find $O/stats_c3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c3.csv
 cd $R
 { for M in 0 1; do echo "== moments_only=$M (d=16)"; PROBE_MOMENTS_ONLY=$M python tools/perf_probe_wide.py 1 200000 16; echo "== moments_only=$M (d=30)"; PROBE_MOMENTS_ONLY=$M python tools/perf_probe_wide.py 1 20000 30; done; } 2>&1 | grep -v amdgpu.ids > $O/mfma_forms.txt
 python tools/inv_accuracy.py 2>&1 | grep -v amdgpu.ids > $O/inv_accuracy.txt
 python tools/c5_cond.py 2>&1 | grep -v amdgpu.ids > $O/c5_cond.txt
-rm -rf $O/pmc_fetch $O/pmc_write $O/stats $O/stats_c5
+rm -rf $O/pmc_fetch $O/pmc_write $O/stats $O/stats_c5 $O/stats_c3
 tail -3 $O/pytest_gpu.log; cat $O/bench.json | cut -c1-400
