@@ -29,7 +29,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 $
 cp $(find $O/stats_c3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c3.csv
 cd $R
 { for M in 0 1; do echo "== moments_only=$M (d=16)"; PROBE_MOMENTS_ONLY=$M python tools/perf_probe_wide.py 1 200000 16; echo "== moments_only=$M (d=30)"; PROBE_MOMENTS_ONLY=$M python tools/perf_probe_wide.py 1 20000 30; done; } 2>&1 | grep -v amdgpu.ids > $O/mfma_forms.txt
-python tools/inv_accuracy.py 2>&1 | grep -v amdgpu.ids > $O/inv_accuracy.txt
-python tools/c5_cond.py 2>&1 | grep -v amdgpu.ids > $O/c5_cond.txt
+python -m pytest tests/test_gpu_accuracy.py -m gpu -s -q 2>&1 | grep -v amdgpu.ids > $O/accuracy_tables.txt
 rm -rf $O/pmc_fetch $O/pmc_write $O/stats $O/stats_c5 $O/stats_c3
 tail -3 $O/pytest_gpu.log; cat $O/bench.json | cut -c1-400
