@@ -308,6 +308,11 @@ typedef struct mfgm_sparse_data {
     const double* c;
     const double* prior_mean;   /* [d]    kernel.initial_mean            (sde_kernel.py:402-419) */
     const double* prior_cov;    /* [d, d] kernel.initial_covariance_matrix */
+    /* One chain shared between processes (mfgm_plan_set_shard_level): the intervals [m_lo, m_hi) this process owns -- interval m belongs
+     * to the owner of inducing state m, the last process also takes interval M.  seg then has m_hi - m_lo + 1 entries and seg, w, c, fmu,
+     * fvar, g1, g2 hold the N data points of the owned intervals only; the arrays over inducing states keep global indices.
+     * m_hi <= 0: every interval (0, M + 1). */
+    int m_lo, m_hi;
 } mfgm_sparse_data;
 /* posterior naturals = prior naturals (plin [T, d] or NULL, pdiag / psub [T, d, d]) + the sites nat1 [M+1, 2d], nat2 [M+1, 2d, 2d]
  * overlap-added into the block-tri-diagonal structure (sparse_variational_cvi.py:140-174); T = M. */
@@ -321,6 +326,19 @@ int mfgm_sparse_theta(int T, int d, const double* nat1, const double* nat2, cons
 int mfgm_sparse_factor(const mfgm_plan* plan, const double* nat1, const double* nat2, const double* plin, const double* pdiag,
                        const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
                        void* stream);
+/* The same factorisation of ONE chain shared between processes (mfgm_plan_set_shard_level; sparse_variational_cvi.py:140-174 with the
+ * time axis cut at separators of a coarse level): phase 0 eliminates the interiors of the owned segments below the exchange level, the
+ * caller sums the region mfgm_plan_exchange_region names over the processes, phase 1 solves the replicated upper levels and walks back
+ * down the owned segments.  A process reads the sites node_lo .. node_hi of its node range [node_lo, node_hi) (site node_hi belongs to its
+ * right neighbour: one [2d + 4d^2] halo per step) and the prior naturals of its own nodes and of node_lo - 1 (psub).  logdet / quad are
+ * the partial sums over the owned nodes. */
+int mfgm_sparse_factor_phase(const mfgm_plan* plan, int phase, const double* nat1, const double* nat2, const double* plin,
+                             const double* pdiag, const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws,
+                             int* info, void* stream);
+/* After mfgm_packed_selinv_form on a shared chain: the marginal (Sig [T, d, d], x [T, d] or NULL) of the separator on the left of the
+ * owned node range, node_lo - 1, copied from the replicated exchange level -- the pair marginal of the first owned interval needs it
+ * (conditionals.py:380-421 with the left conditioning state owned by the neighbour).  No-op on the first process. */
+int mfgm_plan_shard_left_marginal(const mfgm_plan* plan, double* Sig, double* x, const void* ws, void* stream);
 /* q(f(t_i)) at the data points (posterior.py:207-260 through conditionals.py:380-470) from the posterior marginals of the inducing
  * states: mu [M, d], Sig [M, d, d], Sub [M, d, d] (Sigma_{t+1,t} at t); fmu, fvar [N]. */
 int mfgm_sparse_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,

@@ -1498,3 +1498,21 @@ def test_ssm_natgrad_tape_route(amd, rng):
     SSMNaturalGradient(gamma=1.0, momentum=False).minimize(neg_elbo, q)
     ref = np_models.gpr_log_likelihood(t, y, mk(np_kernels), noise)
     np.testing.assert_allclose(float(closed.elbo(q)), ref, rtol=1e-6, atol=1e-5)
+
+
+def test_trainers_two_processes_share_the_batch():
+    """SURVEY 8e first row with the gradient half of the collective: 2 ranks (gloo, one GPU), 4 trajectories spread 2 + 2, both trainers
+    with prior learning -- ELBO / NLPD / RMSE and drift-parameter histories equal the single-process run on all 4 (tests/mp_trainer_shard.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "mp_trainer_shard.py")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]

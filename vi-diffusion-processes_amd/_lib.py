@@ -102,6 +102,8 @@ EXPORTS = {
                         + [ctypes.c_void_p] * 11),
     "mfgm_sparse_predict_kl": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
     "mfgm_sparse_factor": (ctypes.c_int, [ctypes.c_void_p] * 14),
+    "mfgm_sparse_factor_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 13),
+    "mfgm_plan_shard_left_marginal": (ctypes.c_int, [ctypes.c_void_p] * 5),
     "mfgm_batched_cholesky": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4),
     "mfgm_batched_trsm": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
 }
@@ -125,7 +127,8 @@ class CqState(ctypes.Structure):
 class SparseData(ctypes.Structure):
     """mfgm_sparse_data (include/mfgm.h)."""
     _fields_ = [("M", ctypes.c_int), ("d", ctypes.c_int), ("N", ctypes.c_int), ("seg", ctypes.c_void_p), ("w", ctypes.c_void_p),
-                ("c", ctypes.c_void_p), ("prior_mean", ctypes.c_void_p), ("prior_cov", ctypes.c_void_p)]
+                ("c", ctypes.c_void_p), ("prior_mean", ctypes.c_void_p), ("prior_cov", ctypes.c_void_p), ("m_lo", ctypes.c_int),
+                ("m_hi", ctypes.c_int)]
 
 
 class KfSites(ctypes.Structure):

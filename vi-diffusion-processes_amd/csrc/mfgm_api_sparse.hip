@@ -8,11 +8,14 @@ using namespace mfgm;
 namespace {
 SparseArgs sparse_args(const mfgm_sparse_data* s) {
     SparseArgs a;
-    a.M = s->M; a.d = s->d; a.N = s->N; a.seg = s->seg; a.w = s->w; a.c = s->c; a.prior_mean = s->prior_mean; a.prior_cov = s->prior_cov;
+    a.M = s->M; a.d = s->d; a.N = s->N; a.seg = s->seg;
+    a.m_lo = (s->m_hi > 0) ? s->m_lo : 0;
+    a.m_hi = (s->m_hi > 0) ? s->m_hi : s->M + 1; a.w = s->w; a.c = s->c; a.prior_mean = s->prior_mean; a.prior_cov = s->prior_cov;
     return a;
 }
 bool sparse_ok(const mfgm_sparse_data* s) {
-    return s && s->M >= 1 && s->d >= 1 && s->d <= 32 && s->N >= 0 && s->seg && (s->N == 0 || (s->w && s->c));
+    if (!(s && s->M >= 1 && s->d >= 1 && s->d <= 32 && s->N >= 0 && s->seg && (s->N == 0 || (s->w && s->c)))) return false;
+    return s->m_hi <= 0 || (s->m_lo >= 0 && s->m_lo < s->m_hi && s->m_hi <= s->M + 1);
 }
 }  // namespace
 
@@ -32,7 +35,8 @@ namespace {
 int launch_predict(const mfgm_sparse_data* data, const double* mu, const double* Sig, const double* Sub, double* fmu, double* fvar,
                    const SparseKl& kl, hipStream_t st) {
     const int d2 = 2 * data->d;
-#define PREDICT(P_) hipLaunchKernelGGL((k_sparse_predict<P_>), dim3(data->M + 1), dim3(64), 0, st, sparse_args(data), mu, Sig, Sub, fmu, fvar, kl)
+    const SparseArgs sa = sparse_args(data);
+#define PREDICT(P_) hipLaunchKernelGGL((k_sparse_predict<P_>), dim3(sa.m_hi - sa.m_lo), dim3(64), 0, st, sa, mu, Sig, Sub, fmu, fvar, kl)
     if (d2 <= 2) PREDICT(2); else if (d2 <= 4) PREDICT(4); else if (d2 <= 8) PREDICT(8); else if (d2 <= 16) PREDICT(16);
     else if (d2 <= 32) PREDICT(32); else PREDICT(64);
 #undef PREDICT
@@ -60,7 +64,9 @@ int mfgm_sparse_predict_kl(const mfgm_sparse_data* data, const double* mu, const
     SparseKl kl{Pd, Ps, mup, aD, aS, (double*)ws + P.off_part[0]};
     int rc = launch_predict(data, mu, Sig, Sub, fmu, fvar, kl, (hipStream_t)stream);
     if (rc) return rc;
-    return launch_sum_partials(kl.part, data->M + 1, data->M + 1, 1, trace, maha, (double*)ws + P.off_part2, (hipStream_t)stream);
+    // the sums run over the owned intervals (all of them unless the chain is shared between processes, whose partial sums the caller adds)
+    const SparseArgs sa = sparse_args(data);
+    return launch_sum_partials(kl.part + sa.m_lo, sa.m_hi - sa.m_lo, data->M + 1, 1, trace, maha, (double*)ws + P.off_part2, (hipStream_t)stream);
 }
 
 int mfgm_cond_predict(int M, int d, int N, const int* idx, const double* P, const double* T, const double* prior_mean,
@@ -82,9 +88,10 @@ int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, cons
     if (!sparse_ok(data) || !nat1 || !nat2 || (data->N > 0 && (!g1 || !g2))) return 1;
     const int npair = 2 * data->d * data->d;            // entry pairs of a [2d, 2d] block
     const size_t shmem = sizeof(double) * kSitesChunk * (2 * data->d + 2);
+    const SparseArgs sa = sparse_args(data);
 #define SITES(SPI_)                                                                                                                    \
-    hipLaunchKernelGGL((k_sparse_sites<SPI_>), dim3((data->M + 1 + 8 / SPI_ - 1) / (8 / SPI_)), dim3(256), shmem, (hipStream_t)stream,  \
-                       sparse_args(data), g1, g2, lr, nat1, nat2)
+    hipLaunchKernelGGL((k_sparse_sites<SPI_>), dim3((sa.m_hi - sa.m_lo + 8 / SPI_ - 1) / (8 / SPI_)), dim3(256), shmem, (hipStream_t)stream,  \
+                       sa, g1, g2, lr, nat1, nat2)
     if (npair <= 256) SITES(1); else if (npair <= 512) SITES(2); else if (npair <= 1024) SITES(4); else SITES(8);
 #undef SITES
     MFGM_CHECK_LAUNCH();

@@ -631,6 +631,33 @@ int mfgm_sparse_factor(const mfgm_plan* plan, const double* nat1, const double* 
                        nat2);
 }
 
+int mfgm_sparse_factor_phase(const mfgm_plan* plan, int phase, const double* nat1, const double* nat2, const double* plin,
+                             const double* pdiag, const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws,
+                             int* info, void* stream) {
+    if (!plan || !nat1 || !nat2 || !pdiag || !psub || !L || !G || !y || !info || !ws || (phase != 0 && phase != 1)) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide || P.B != 1 || P.shard_level < 1) return 1;
+    return wide_factor(P, pdiag, psub, plin, -2.0, -1.0, 1.0, L, G, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, phase, 1, nat1,
+                       nat2);
+}
+
+int mfgm_plan_shard_left_marginal(const mfgm_plan* plan, double* Sig, double* x, const void* ws, void* stream) {
+    if (!plan || !Sig || !ws) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide || P.shard_level < 1) return 1;
+    if (P.own_lo[0] == 0) return 0;                       // the first process has no left neighbour
+    const int X = P.shard_level, q = P.own_lo[X - 1] - 1, nX = P.lv[X].n, EF = P.d * P.d;
+    const size_t t = (size_t)P.own_lo[0] * P.lv[0].R - 1;
+    const double* w = (const double*)ws;
+    for (int b = 0; b < P.B; ++b) {
+        if (hipMemcpyAsync(Sig + ((size_t)b * P.T + t) * EF, w + P.off_Sig[X] + ((size_t)b * nX + q) * EF, EF * sizeof(double),
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return 3;
+        if (x && hipMemcpyAsync(x + ((size_t)b * P.T + t) * P.d, w + P.off_mu[X] + ((size_t)b * nX + q) * P.d, P.d * sizeof(double),
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return 3;
+    }
+    return 0;
+}
+
 int mfgm_packed_selinv_level(const mfgm_plan* plan, int level, const double* L, const double* G, const double* y, double* Sig,
                              double* Sub, double* x, void* ws, void* stream) {
     if (!plan || !L || !G || !Sig) return 1;

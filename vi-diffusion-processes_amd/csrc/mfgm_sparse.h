@@ -20,7 +20,9 @@ namespace mfgm {
 
 struct SparseArgs {
     int M, d, N;
-    const int* seg;          // [M + 2] CSR offsets of the data points per interval
+    int m_lo, m_hi;          // intervals this process owns (0, M + 1 unless one chain is shared between processes): seg, w, c and every
+                             // per-data-point array hold the data points of these intervals only
+    const int* seg;          // [m_hi - m_lo + 1] CSR offsets of the data points per owned interval
     const double* w;         // [N, 2d]
     const double* c;         // [N]
     const double* prior_mean;  // [d]   the kernel's initial mean (pads the chain at both ends)
@@ -64,8 +66,8 @@ static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, cons
                                                              const double* __restrict__ Sub, double* __restrict__ fmu,
                                                              double* __restrict__ fvar, SparseKl kl) {
     constexpr int H = (64 / D2P < D2P) ? 64 / D2P : D2P, NR = D2P / H;          // row groups (lanes beyond H D2P idle), rows per lane
-    const int m = blockIdx.x, d = a.d, d2 = 2 * d, lane = threadIdx.x;
-    const int i0 = a.seg[m], i1 = a.seg[m + 1];
+    const int m = a.m_lo + blockIdx.x, d = a.d, d2 = 2 * d, lane = threadIdx.x;
+    const int i0 = a.seg[blockIdx.x], i1 = a.seg[blockIdx.x + 1];
     if (i0 >= i1 && !kl.part) return;
     const int c = lane % D2P, h = lane / D2P;
     const bool lo_prior = (m == 0), hi_prior = (m == a.M);
@@ -214,7 +216,7 @@ static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const
                                                             double lr, double* __restrict__ nat1, double* __restrict__ nat2) {
     constexpr int G = 8 / SPI;
     extern __shared__ double sh[];     // kSitesChunk x (w [2d], g1, g2)
-    const int d2 = 2 * a.d, tid = threadIdx.x, m0 = blockIdx.x * G;
+    const int d2 = 2 * a.d, tid = threadIdx.x, m0 = a.m_lo + blockIdx.x * G;
     const int ne = d2 * d2;            // even, and a row never splits a pair
     double2 old[8], acc[8];
     int rr[SPI], cc[SPI];
@@ -227,21 +229,21 @@ static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int gi = k / SPI, p = tid + (k % SPI) * 256;
-        const bool ok = (m0 + gi <= a.M) && 2 * p < ne;
+        const bool ok = (m0 + gi < a.m_hi) && 2 * p < ne;
         old[k] = ok ? reinterpret_cast<const double2*>(nat2 + (size_t)(m0 + gi) * ne)[p] : make_double2(0.0, 0.0);
         acc[k] = make_double2(0.0, 0.0);
     }
     double old1[G], acc1[G];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
-        old1[gi] = (tid < d2 && m0 + gi <= a.M) ? nat1[(size_t)(m0 + gi) * d2 + tid] : 0.0;
+        old1[gi] = (tid < d2 && m0 + gi < a.m_hi) ? nat1[(size_t)(m0 + gi) * d2 + tid] : 0.0;
         acc1[gi] = 0.0;
     }
     const int st = d2 + 2;
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
-        const int m = min(m0 + gi, a.M);
-        const int i0 = a.seg[m], i1 = (m0 + gi <= a.M) ? a.seg[m + 1] : i0;
+        const int m = min(m0 + gi, a.m_hi - 1) - a.m_lo;
+        const int i0 = a.seg[m], i1 = (m0 + gi < a.m_hi) ? a.seg[m + 1] : i0;
         for (int c0 = i0; c0 < i1; c0 += kSitesChunk) {
             const int np = min(kSitesChunk, i1 - c0);
             __syncthreads();
@@ -267,13 +269,13 @@ static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int gi = k / SPI, p = tid + (k % SPI) * 256;
-        if ((m0 + gi <= a.M) && 2 * p < ne)
+        if ((m0 + gi < a.m_hi) && 2 * p < ne)
             reinterpret_cast<double2*>(nat2 + (size_t)(m0 + gi) * ne)[p] =
                 make_double2(__builtin_fma(lr, acc[k].x, (1.0 - lr) * old[k].x), __builtin_fma(lr, acc[k].y, (1.0 - lr) * old[k].y));
     }
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
-        if (tid < d2 && m0 + gi <= a.M) nat1[(size_t)(m0 + gi) * d2 + tid] = __builtin_fma(lr, acc1[gi], (1.0 - lr) * old1[gi]);
+        if (tid < d2 && m0 + gi < a.m_hi) nat1[(size_t)(m0 + gi) * d2 + tid] = __builtin_fma(lr, acc1[gi], (1.0 - lr) * old1[gi]);
 }
 
 }  // namespace mfgm

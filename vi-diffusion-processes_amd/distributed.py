@@ -51,6 +51,29 @@ def allreduce_max_(t):
     return t
 
 
+def sum_over_ranks(values):
+    """Sum each of a short list of Python floats over the ranks in ONE all-reduce and hand the totals back as floats: the
+    ELBO / metric sums that steer a trainer (every rank must take the same learning-rate and convergence decisions) and the
+    hyper-parameter gradients [d/d hyper ...] before an optimiser step (docs/diffusion_processes/cvi_dp_trainer.py:207-235,
+    vi_markov_gp_trainer.py:163-216 sum over the batch axis; here the batch is spread over processes).  Identity without a group."""
+    values = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return values
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor(values, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def allgather_(t):
+    """[world, *t.shape] tensor of every rank's `t` (the tensor itself, with a leading axis of 1, without a process group)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t.contiguous())
+        return torch.stack(parts)
+    return t[None]
+
+
 class ChainShard:
     """
     One long chain over several GPUs (SURVEY 8e second row, config 5): the time axis is cut at segment boundaries of a COARSE level
@@ -64,11 +87,11 @@ class ChainShard:
     [node_lo, node_hi) and the sub-diagonal block at node_lo - 1; its outputs are valid on its own nodes (the cross-covariances
     Sigma_{t+1,t} on [node_lo - 1, node_hi - 1): each is produced together with Sigma_{t+1}).
 
-    `allreduce` defaults to the in-place sum over the torch.distributed group; tests on a single GPU inject one that sums over
-    several shard objects living in the same process.
+    `allreduce` defaults to the in-place sum over the torch.distributed group, `allgather` to its all-gather; tests on a single GPU
+    inject ones that work over several shard objects living in the same process.
     """
 
-    def __init__(self, plan, rank, world, allreduce=None):
+    def __init__(self, plan, rank, world, allreduce=None, allgather=None):
         import ctypes
         from . import _lib
         self.plan, self.rank, self.world = plan, int(rank), int(world)
@@ -94,6 +117,13 @@ class ChainShard:
         self.node_lo, self.node_hi = lo * span, min(hi * span, plan.T)
         self.seg_lo, self.seg_hi = self.node_lo // levels[0][1], -(-self.node_hi // levels[0][1])
         self._allreduce = allreduce if allreduce is not None else allreduce_sum_
+        self._allgather = allgather if allgather is not None else allgather_
+
+    def allreduce(self, t):
+        return self._allreduce(t)
+
+    def allgather(self, t):
+        return self._allgather(t)
 
     def factor(self, D, S, r=None, aD=1.0, aS=1.0, aR=1.0, want_logdet=True, want_quad=False, moments_only=False):
         """Block Cholesky of the sharded chain.  Returns dict(L, G, y, logdet, quad, form) with logdet / quad already summed over ranks.
@@ -121,3 +151,33 @@ class ChainShard:
     def selinv(self, L, G, y=None, want_sub=True, form=0):
         """Selected inverse on the owned nodes (no communication: the levels from the exchange level up are replicated)."""
         return self.plan.selinv(L, G, y, want_sub=want_sub, form=form)
+
+    def sparse_factor(self, nat1, nat2, plin, pdiag, psub, out=None):
+        """Inverse-form factorisation of the sparse-CVI posterior of the shared chain straight from the sites (mfgm_sparse_factor_phase;
+        sparse_variational_cvi.py:140-174): phase 0 on the owned segments, ONE all-reduce of the exchange region, phase 1.  The sites
+        node_lo .. node_hi must be current (site node_hi is the right neighbour's: SparseCVIGaussianProcess passes it on after every
+        update).  `logdet` is the PARTIAL sum over the owned nodes -- the model adds it to the other scalars of the ELBO and reduces
+        them together."""
+        from ._lib import FULL, TRI, VEC, check
+        from .packed import _ptr, _stream
+        pl = self.plan
+        out = {} if out is None else out
+        L = out.get("L") if out.get("L") is not None else pl.empty(TRI)
+        G = out.get("G") if out.get("G") is not None else pl.empty(FULL)
+        y = out.get("y") if out.get("y") is not None else pl.empty(VEC)
+        pl.epoch += 1
+        logdet = torch.empty(pl.B, dtype=torch.float64, device=pl.device)
+        args = (_ptr(nat1), _ptr(nat2), _ptr(plin), _ptr(pdiag), _ptr(psub), _ptr(L), _ptr(G), _ptr(y), _ptr(logdet), None, _ptr(pl.ws),
+                _ptr(pl.info), _stream())
+        check(pl.lib.mfgm_sparse_factor_phase(pl.h, 0, *args), "mfgm_sparse_factor_phase(0)")
+        self._allreduce(self.exchange)
+        check(pl.lib.mfgm_sparse_factor_phase(pl.h, 1, *args), "mfgm_sparse_factor_phase(1)")
+        return dict(L=L, G=G, y=y, logdet=logdet, quad=None, form=1)
+
+    def left_marginal(self, Sig, x=None):
+        """Marginal of the separator on the left of the owned range (node_lo - 1, owned by the left neighbour) from the replicated
+        exchange level, written into the global-index arrays Sig / x (after `selinv`)."""
+        from ._lib import check
+        from .packed import _ptr, _stream
+        check(self.plan.lib.mfgm_plan_shard_left_marginal(self.plan.h, _ptr(Sig), _ptr(x), _ptr(self.plan.ws), _stream()),
+              "mfgm_plan_shard_left_marginal")

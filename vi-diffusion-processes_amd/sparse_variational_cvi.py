@@ -16,16 +16,62 @@ from .variational_cvi import back_project_nats
 
 
 class SparseCVIGaussianProcess:
-    def __init__(self, kernel, inducing_points, likelihood, mean_function=None, learning_rate=0.1):
+    """`shard=(rank, world)` (or `(rank, world, allreduce, allgather)` with stand-ins for the collectives, or a dict with these keys and
+    optionally the partition `R0`, `Rup`): ONE chain shared between
+    `world` processes along time (SURVEY 8e second row, config 5; distributed.ChainShard).  Process k owns the inducing states
+    [node_lo, node_hi), the sites / intervals m in [node_lo, node_hi) (interval m lies between states m - 1 and m; the last process also
+    takes interval M) and the data points inside them.  Per step three small collectives cross processes: the site on the right edge
+    (one [2d + 4d^2] block per neighbour pair, all-gathered after `update_sites`), the exchange level of the factorisation
+    (n_X (3d^2 + 2d) doubles) and the four scalars of the ELBO.  Every process is handed the same (time_points, observations) and keeps
+    its own slice; the arrays over inducing states keep global indices and are valid on the owned range.  State dimension > 8 only."""
+
+    def __init__(self, kernel, inducing_points, likelihood, mean_function=None, learning_rate=0.1, shard=None):
         self._kernel, self._likelihood = kernel, likelihood
         self.learning_rate = learning_rate
         self.inducing_inputs = inducing_points
         M, sd = inducing_points.shape[-1], kernel.state_dim
         dev, dt = inducing_points.device, torch.float64
+        self._version = 0          # bumped by every site update: keys the cached posterior marginals
         self.nat1 = torch.zeros((M + 1, 2 * sd), dtype=dt, device=dev)
         self.nat2 = torch.zeros((M + 1, 2 * sd, 2 * sd), dtype=dt, device=dev)
         self._dist_p = None
-        self._version = 0          # bumped by every site update: keys the cached posterior marginals
+        self._shard = None
+        if shard is not None:
+            from .distributed import ChainShard
+            from .packed import Plan
+            if sd <= 8 or inducing_points.dim() != 1:
+                raise ValueError("a chain is shared between processes on the wide path only (state dimension > 8, one chain)")
+            if not isinstance(shard, dict):
+                shard = dict(zip(("rank", "world", "allreduce", "allgather"), shard))
+            rank, world = int(shard["rank"]), int(shard["world"])
+            # a plan of its own: the prior's plan keeps serving whole-chain calls (dist_p, dist_q of gathered sites)
+            self._shard = ChainShard(Plan(1, M, sd, R0=shard.get("R0", 0), Rup=shard.get("Rup", 0), device=dev), rank, world,
+                                     shard.get("allreduce"), shard.get("allgather"))
+            self._m_lo = self._shard.node_lo
+            self._m_hi = self._shard.node_hi + (1 if rank == world - 1 else 0)
+
+    # the sites are public tensors, as the reference's `sites.nat1 / nat2`: assigning them, or editing them in place through torch, moves
+    # the key of every cached posterior quantity (the library's own in-place updates bump `_version`)
+    @property
+    def nat1(self):
+        return self._nat1
+
+    @nat1.setter
+    def nat1(self, value):
+        self._nat1 = value
+        self._version += 1
+
+    @property
+    def nat2(self):
+        return self._nat2
+
+    @nat2.setter
+    def nat2(self, value):
+        self._nat2 = value
+        self._version += 1
+
+    def _key(self):
+        return (self._version, id(self._nat1), self._nat1._version, id(self._nat2), self._nat2._version)
 
     @property
     def kernel(self):
@@ -45,6 +91,8 @@ class SparseCVIGaussianProcess:
     def dist_q(self):
         """Prior naturals + overlap-added site naturals (sparse_variational_cvi.py:140-174) as a StateSpaceModel."""
         p = self.dist_p
+        if self._shard is not None:
+            self._gather_sites()
         lin, diag, sub = (x.clone() for x in self._theta())      # _theta() reuses its buffers
         q = naturals_to_ssm_params_packed(p.plan, lin, diag, sub)
         q.batch_shape = p.batch_shape
@@ -74,20 +122,35 @@ class SparseCVIGaussianProcess:
         z = self.inducing_inputs
         if (time_points.dim() == 1 and z.dim() == 1 and time_points.is_cuda and os.environ.get("VIDP_FUSED_SPARSE", "1") != "0"
                 and (time_points.numel() < 2 or bool((time_points[1:] >= time_points[:-1]).all()))):
-            M, d, N = int(z.shape[0]), self._kernel.state_dim, int(time_points.shape[0])
-            P, Tc, idx = _conditional_statistics(time_points, z, self._kernel)
-            H = self._kernel.generate_emission_model(time_points[:1]).emission_matrix[0]          # [1, d], time-invariant
-            w = (H @ P)[:, 0, :].contiguous()                                                      # [N, 2d]
-            cc = (H @ Tc @ H.transpose(-1, -2))[:, 0, 0].contiguous()                              # [N]
-            seg = torch.zeros(M + 2, dtype=torch.int32, device=z.device)
-            seg[1:] = torch.cumsum(torch.bincount(idx, minlength=M + 1), 0).to(torch.int32)
+            M, d = int(z.shape[0]), self._kernel.state_dim
+            m_lo, m_hi, own = 0, M + 1, slice(None)
+            if self._shard is not None:
+                # the data points of the owned intervals: a contiguous slice of the sorted time points
+                m_lo, m_hi = self._m_lo, self._m_hi
+                edges = torch.searchsorted(torch.searchsorted(z.contiguous(), time_points.contiguous()),
+                                           torch.tensor([m_lo, m_hi], device=z.device), right=False)
+                own = slice(int(edges[0]), int(edges[1]))
+                time_points = time_points[own]
+            N = int(time_points.shape[0])
+            if N > 0:
+                P, Tc, idx = _conditional_statistics(time_points, z, self._kernel)
+                H = self._kernel.generate_emission_model(time_points[:1]).emission_matrix[0]      # [1, d], time-invariant
+                w = (H @ P)[:, 0, :].contiguous()                                                  # [N, 2d]
+                cc = (H @ Tc @ H.transpose(-1, -2))[:, 0, 0].contiguous()                          # [N]
+            else:
+                idx = torch.zeros(0, dtype=torch.int64, device=z.device)
+                w, cc = (torch.zeros((1, 2 * d), dtype=torch.float64, device=z.device), torch.zeros(1, dtype=torch.float64, device=z.device))
+            seg = torch.zeros(m_hi - m_lo + 1, dtype=torch.int32, device=z.device)
+            seg[1:] = torch.cumsum(torch.bincount(idx - m_lo, minlength=m_hi - m_lo), 0).to(torch.int32)
             pm = self._kernel.initial_mean(()).to(z.device, torch.float64).contiguous()
             pc = self._kernel.initial_covariance_matrix().to(z.device, torch.float64).contiguous()
             sd = _lib.SparseData()
-            sd.M, sd.d, sd.N = M, d, N
+            sd.M, sd.d, sd.N, sd.m_lo, sd.m_hi = M, d, N, m_lo, m_hi
             sd.seg, sd.w, sd.c, sd.prior_mean, sd.prior_cov = seg.data_ptr(), w.data_ptr(), cc.data_ptr(), pm.data_ptr(), pc.data_ptr()
-            val = dict(struct=sd, keep=(seg, w, cc, pm, pc), N=N)
-        self._data_cache = dict(ref=weakref.ref(time_points), ver=time_points._version, val=val)
+            val = dict(struct=sd, keep=(seg, w, cc, pm, pc), N=N, own=own)
+        if val is None and self._shard is not None:
+            raise ValueError("a shared chain needs sorted, un-batched time points on the device")
+        self._data_cache = dict(ref=weakref.ref(input_data[0]), ver=input_data[0]._version, val=val)
         return val
 
     def _prior_natural(self):
@@ -142,12 +205,17 @@ class SparseCVIGaussianProcess:
         """Posterior marginals of the inducing states for the current sites: one factorisation + selected inverse, cached until the
         sites move.  dict(mu [T, d], Sig [T, d, d], Sub [T, d, d] natural; packed Sig / Sub / x; log|L|)."""
         m = getattr(self, "_marg", None)
-        if m is not None and m["version"] == self._version:
+        if m is not None and m["version"] == self._key():
             return m
         p = self.dist_p
         pl, T, d = p.plan, p.T, p.d
         bufs = self.__dict__.setdefault("_sweep_bufs", dict(f={}, s={}))
-        if self._fused_theta():
+        if self._shard is not None:
+            # one chain shared between processes: the same passes on the owned segments, one exchange (distributed.ChainShard)
+            sh, pn = self._shard, self._prior_natural()
+            pl = sh.plan
+            f = sh.sparse_factor(self._nat1, self._nat2, pn["lin"], pn["diag"], pn["sub"], out=bufs["f"])
+        elif self._fused_theta():
             # the level-0 passes of the factorisation form  prior + overlap-added sites  while loading: no posterior naturals in memory
             pn = self._prior_natural()
             f = pl.sparse_factor(self.nat1, self.nat2, pn["lin"], pn["diag"], pn["sub"], want_logdet=True, out=bufs["f"])
@@ -157,6 +225,8 @@ class SparseCVIGaussianProcess:
         bufs["f"].update(L=f["L"], G=f["G"], y=f["y"], form=f["form"])
         s = pl.selinv(f["L"], f["G"], f["y"], want_sub=True, out=bufs["s"], form=f["form"])
         bufs["s"].update(Sig=s["Sig"], Sub=s["Sub"], x=s["x"])
+        if self._shard is not None:
+            self._shard.left_marginal(s["Sig"], s["x"])      # the pair marginal of the first owned interval reaches one node to the left
         if pl.d > 8:
             mu, Sig, Sub = s["x"].view(T, d), s["Sig"].view(T, d, d), s["Sub"].view(T, d, d)
         else:
@@ -164,7 +234,7 @@ class SparseCVIGaussianProcess:
             Sub = torch.zeros((T, d, d), dtype=torch.float64, device=pl.device)
             if T > 1:
                 Sub[:T - 1] = pl.unpack(FULL, s["Sub"], T - 1)[0]
-        self._marg = dict(version=self._version, mu=mu, Sig=Sig, Sub=Sub, packed=s, logdetL=f["logdet"])
+        self._marg = dict(version=self._key(), mu=mu, Sig=Sig, Sub=Sub, packed=s, logdetL=f["logdet"])
         return self._marg
 
     def _predict_f_data(self, data):
@@ -173,14 +243,14 @@ class SparseCVIGaussianProcess:
         from . import _lib
         from .packed import _ptr, _stream
         c = getattr(self, "_pred_cache", None)
-        if c is not None and c[0] == self._version and c[1] is data:
+        if c is not None and c[0] == self._key() and c[1] is data:
             return c[2]          # the sites have not moved since these were computed (the ELBO of the previous iteration)
         m = self._marginals()
-        pl = self.dist_p.plan
+        pl = self.dist_p.plan if self._shard is None else self._shard.plan
         N = data["N"]
-        out = torch.empty((2, N), dtype=torch.float64, device=pl.device)
+        out = torch.empty((2, max(N, 1)), dtype=torch.float64, device=pl.device)[:, :N]
         import os
-        if pl.wide and os.environ.get("VIDP_FUSED_SPARSE_KL", "1") != "0":
+        if pl.wide and (self._shard is not None or os.environ.get("VIDP_FUSED_SPARSE_KL", "1") != "0"):
             # the pass over the pair covariances also takes the trace / Mahalanobis terms of KL[q || p] (what classic_elbo asks for next)
             pn = self._prior_natural()
             kt = torch.empty(2, dtype=torch.float64, device=pl.device)
@@ -188,12 +258,12 @@ class SparseCVIGaussianProcess:
                                                      _ptr(out[1]), pl.h, _ptr(pn["nat"]["diag"]), _ptr(pn["nat"]["sub"]), -2.0, -1.0,
                                                      _ptr(self._prior_mean_packed()), _ptr(kt[0:1]), _ptr(kt[1:2]), _ptr(pl.ws), _stream()),
                        "mfgm_sparse_predict_kl")
-            self._kl_cache = (self._version, kt[0:1], kt[1:2])
+            self._kl_cache = (self._key(), kt[0:1], kt[1:2])
         else:
             _lib.check(pl.lib.mfgm_sparse_predict(ctypes.byref(data["struct"]), _ptr(m["mu"]), _ptr(m["Sig"]), _ptr(m["Sub"]), _ptr(out[0]),
                                                   _ptr(out[1]), _stream()), "mfgm_sparse_predict")
         res = (out[0][:, None], out[1][:, None])
-        self._pred_cache = (self._version, data, res)
+        self._pred_cache = (self._key(), data, res)
         return res
 
     def update_sites(self, input_data):
@@ -206,11 +276,35 @@ class SparseCVIGaussianProcess:
         from .packed import _ptr, _stream
         time_points, observations = input_data
         fx_mus, fx_covs = self._predict_f_data(data)
-        _, grads = self.local_objective_and_gradients(fx_mus, fx_covs, observations)
+        _, grads = self.local_objective_and_gradients(fx_mus, fx_covs, observations[data["own"]])
         g1, g2 = grads[0].reshape(-1).contiguous(), grads[1].reshape(-1).contiguous()
         pl = self.dist_p.plan
-        _lib.check(pl.lib.mfgm_sparse_site_update(ctypes.byref(data["struct"]), _ptr(g1), _ptr(g2), float(self.learning_rate), _ptr(self.nat1),
-                                                  _ptr(self.nat2), _stream()), "mfgm_sparse_site_update")
+        _lib.check(pl.lib.mfgm_sparse_site_update(ctypes.byref(data["struct"]), _ptr(g1), _ptr(g2), float(self.learning_rate), _ptr(self._nat1),
+                                                  _ptr(self._nat2), _stream()), "mfgm_sparse_site_update")
+        self._version += 1
+        if self._shard is not None:
+            self._pass_edge_site()
+
+    def _pass_edge_site(self):
+        """A shared chain: the factorisation of the owned nodes reads the site node_hi, which the right neighbour owns and has just
+        updated -- every process publishes its first owned site, one all-gather of [2d + 4d^2] doubles per process."""
+        sh = self._shard
+        lo, hi = sh.node_lo, sh.node_hi
+        mine = torch.cat([self._nat1[lo], self._nat2[lo].reshape(-1)])
+        every = sh.allgather(mine)
+        if sh.rank + 1 < sh.world:
+            d2 = self._nat1.shape[-1]
+            self._nat1[hi].copy_(every[sh.rank + 1, :d2])
+            self._nat2[hi].copy_(every[sh.rank + 1, d2:].view(d2, d2))
+            self._version += 1
+
+    def _gather_sites(self):
+        """A shared chain: the sites of every process on every process (dist_q / posterior of the whole chain; not on the training path)."""
+        sh = self._shard
+        for t in (self._nat1, self._nat2):
+            own = torch.zeros_like(t)
+            own[self._m_lo:self._m_hi] = t[self._m_lo:self._m_hi]
+            t.copy_(sh.allreduce(own))
         self._version += 1
 
     def _update_sites_generic(self, input_data):
@@ -238,14 +332,20 @@ class SparseCVIGaussianProcess:
             ve = self._likelihood.variational_expectations(fx_mus, fx_covs, observations).sum()
             return ve - q.kl_divergence(self.dist_p).sum()
         fx_mus, fx_covs = self._predict_f_data(data)
-        ve = self._likelihood.variational_expectations(fx_mus, fx_covs, observations).sum()
+        ve = self._likelihood.variational_expectations(fx_mus, fx_covs, observations[data["own"]]).sum()
         # KL[q || p] from the marginal blocks of q and the prior's naturals (state_space_model.py:528-593); the prior mean is zero
         m, pn = self._marginals(), self._prior_natural()
         p = self.dist_p
         pl = p.plan
         s = m["packed"]
         kc = getattr(self, "_kl_cache", None)
-        if kc is not None and kc[0] == self._version:
+        if self._shard is not None:
+            # partial sums over the owned data points, intervals and nodes: one all-reduce of four doubles
+            kc = self._kl_cache
+            tot = self._shard.allreduce(torch.cat([ve.reshape(1), kc[1], kc[2], m["logdetL"].reshape(1)]))
+            kl = 0.5 * (tot[1] + tot[2] - float(p.T * p.d) + 2.0 * pn["nat"]["sumlogchol"].sum() + 2.0 * tot[3])
+            return tot[0] - kl
+        if kc is not None and kc[0] == self._key():
             tr, mh = kc[1], kc[2]          # taken together with the predictions (mfgm_sparse_predict_kl)
         else:
             tr, mh = pl.kl_terms(s["Sig"], s["Sub"], s["x"], pn["nat"]["diag"], pn["nat"]["sub"], self._prior_mean_packed(), aD=-2.0, aS=-1.0)

@@ -6,6 +6,11 @@ convergence rules, NLPD / RMSE on held-out grid points (exp_dp_utils.py:189-224)
 (cvi_dp_trainer.py:138-250, vi_markov_gp_trainer.py:163-215: Adam on the drift parameters).  The wandb / hydra
 plumbing is out of scope.  One host synchronisation per iteration remains (the ELBO scalar decides
 the learning-rate decay), everything else stays on the device.
+
+Trajectories spread over processes (SURVEY 8e first row; each process builds its model on its own shard of the batch): every scalar
+that steers a loop -- the ELBO, the NLPD / RMSE sums -- and every hyper-parameter gradient is summed over the ranks
+(`distributed.sum_over_ranks`, one all-reduce of a few doubles per use) BEFORE it is used, so that all ranks take the same Adam step
+and the same learning-rate / convergence decisions as a single process holding all trajectories.
 """
 import logging
 import math
@@ -14,6 +19,7 @@ import torch
 
 from . import linalg
 from ._lib import SYM, VEC
+from .distributed import sum_over_ranks
 from .variational_cvi_sde import grid_indices
 
 logger = logging.getLogger(__name__)
@@ -34,9 +40,10 @@ class _Metrics:
         self.idx = grid_indices(time_grid, t_test).to(y_test.device)
         self.node_ids = model.plan.node_ids(self.idx)
 
-    def __call__(self, mu_packed, Sig_packed):
+    def sums(self, mu_packed, Sig_packed):
+        """(sum of log predictive densities, sum of squared errors, number of points, number of entries) over the local trajectories."""
         if self.idx is None:
-            return float("nan"), float("nan")
+            return 0.0, 0.0, 0.0, 0.0
         pl, lik = self.model.plan, self.model.likelihood
         B, n, d = self.y.shape
         m = pl.gather_nodes(VEC, mu_packed, self.node_ids)
@@ -46,9 +53,16 @@ class _Metrics:
         chol = linalg.cholesky(S + R)
         z = linalg.solve_lower(chol, self.y.reshape(B * n, d) - m)
         logp = -0.5 * (z * z).sum(-1) - torch.log(torch.diagonal(chol, dim1=-2, dim2=-1)).sum(-1) - 0.5 * d * math.log(2 * math.pi)
-        nlpd = float(-logp.mean())
-        rmse = float(torch.sqrt(((m - self.y.reshape(B * n, d)) ** 2).mean()))
-        return nlpd, rmse
+        return float(logp.sum()), float(((m - self.y.reshape(B * n, d)) ** 2).sum()), float(B * n), float(B * n * d)
+
+    @staticmethod
+    def finish(logp_sum, se_sum, n_points, n_entries):
+        if n_points == 0:
+            return float("nan"), float("nan")
+        return -logp_sum / n_points, math.sqrt(se_sum / n_entries)
+
+    def __call__(self, mu_packed, Sig_packed):
+        return self.finish(*sum_over_ranks(self.sums(mu_packed, Sig_packed)))
 
 
 class _Adam:
@@ -98,19 +112,21 @@ class CVISitesTrainer:
         """cvi_dp_trainer.py:207-250: Adam steps on the drift parameters with d(KL - VE)/d params until the ELBO settles."""
         from .sde import OrnsteinUhlenbeckSDE
         model, sde = self.model, self.model.prior_sde
-        elbo_vals, nlpd_vals, rmse_vals = [float(model.classic_elbo())], [], []
+        elbo_vals, nlpd_vals, rmse_vals = [self._elbo()], [], []
         for _ in range(self.learning_max_itr):
             grads_kl = model.grad_KL_wrt_prior_params()
             grads_ve = model.grad_VE_wrt_prior_params()
             names = sde.trainable_variables
-            new = self.prior_sde_optim.step([sde.get(n) for n in names], [a + b for a, b in zip(grads_kl, grads_ve)])
+            # the gradient of the whole batch: summed over the ranks before the optimiser sees it
+            grads = sum_over_ranks([a + b for a, b in zip(grads_kl, grads_ve)])
+            new = self.prior_sde_optim.step([sde.get(n) for n in names], grads)
             for n, v in zip(names, new):
                 sde.assign(n, v)
             # the reference's sequence (cvi_dp_trainer.py:221-235): the iteration's ELBO / NLPD / RMSE are taken with the new drift
             # parameters but the OLD p(x0); only then is p(x0) reset to the stationary OU covariance
             model._refresh_sde_params()
-            elbo_vals.append(float(model.classic_elbo()))
-            nl, rm = self._nlpd_rmse()
+            el, nl, rm = self._elbo_nlpd_rmse()
+            elbo_vals.append(el)
             nlpd_vals.append(nl)
             rmse_vals.append(rm)
             self.store_prior_param_vals()
@@ -127,19 +143,32 @@ class CVISitesTrainer:
                 break
         return elbo_vals[1:], nlpd_vals, rmse_vals
 
+    def _elbo(self):
+        """The ELBO of all trajectories of all ranks."""
+        return sum_over_ranks([float(self.model.classic_elbo())])[0]
+
     def _nlpd_rmse(self):
         q = self.model._refresh(want_marginals=True)
         return self._metrics(q["mu"], q["Sig"])
 
+    def _elbo_nlpd_rmse(self):
+        """ELBO, NLPD and RMSE of the whole batch from ONE all-reduce."""
+        e = float(self.model.classic_elbo())
+        if self._metrics.idx is None:
+            return sum_over_ranks([e])[0], float("nan"), float("nan")
+        q = self.model._refresh(want_marginals=True)
+        tot = sum_over_ranks([e, *self._metrics.sums(q["mu"], q["Sig"])])
+        return (tot[0], *self._metrics.finish(*tot[1:]))
+
     def _optimize_sites_under_stable_prior(self):
         """cvi_dp_trainer.py:63-95."""
-        elbos = [float(self.model.classic_elbo())]
+        elbos = [self._elbo()]
         nlpds, rmses = [], []
         while (len(elbos) - 1) < self.max_itr_sites_optim:
             self.model.update_data_sites(self.data_sites_lr)
             self.model.update_girsanov_sites(self.girsanov_sites_lr)
-            elbos.append(float(self.model.classic_elbo()))
-            nl, rm = self._nlpd_rmse()
+            el, nl, rm = self._elbo_nlpd_rmse()
+            elbos.append(el)
             nlpds.append(nl)
             rmses.append(rm)
             if len(elbos) > 2 and elbos[-2] > elbos[-1]:
@@ -153,14 +182,14 @@ class CVISitesTrainer:
 
     def perform_inference(self):
         """cvi_dp_trainer.py:97-136: site optimisation under the stabilised prior, then re-linearisation with site transformation."""
-        elbo_vals, nlpd_vals, rmse_vals = [float(self.model.classic_elbo())], [], []
+        elbo_vals, nlpd_vals, rmse_vals = [self._elbo()], [], []
         relin = hasattr(self.model, "relinearize")
         for i in range(self.max_itr):
-            before = float(self.model.classic_elbo())
+            before = self._elbo()
             e, n, r = self._optimize_sites_under_stable_prior()
             # (the reference swaps to the unclipped linearised prior here; the posterior, hence the ELBO under the SDE
             #  prior, is unchanged by the site transformation)
-            after = float(self.model.classic_elbo())
+            after = self._elbo()
             elbo_vals += e
             nlpd_vals += n
             rmse_vals += r
@@ -173,9 +202,8 @@ class CVISitesTrainer:
 
     def optimize(self):
         """cvi_dp_trainer.py:138-187: inference, then (optionally) alternate with prior-parameter learning."""
-        elbo_vals = [float(self.model.classic_elbo())]
-        n0, r0 = self._nlpd_rmse()
-        nlpd_vals, rmse_vals = [n0], [r0]
+        e0, n0, r0 = self._elbo_nlpd_rmse()
+        elbo_vals, nlpd_vals, rmse_vals = [e0], [n0], [r0]
         previous = []
         for _ in range(self.max_itr):
             e, n, r = self.perform_inference()
@@ -226,7 +254,7 @@ class VIMarkovGPTrainer:
         """vi_markov_gp_trainer.py:50-92."""
         mdl = self.model
         mS = mdl._forward_packed()
-        elbos, nlpds, rmses = [float(mdl.elbo(mS))], [], []
+        elbos, nlpds, rmses = [self._elbo_nlpd_rmse(mS)[0]], [], []
         q_lr, x0_lr = self.q_lr, self.x0_lr
         for i in range(self.max_itr):
             # the marginals that close an iteration (for its ELBO) are those the next one starts from: the parameters do not change
@@ -235,8 +263,8 @@ class VIMarkovGPTrainer:
             if i > self.warmup_x0_itr:
                 mdl.update_initial_statistics(lr=x0_lr)
             mS = mdl._forward_packed()
-            elbos.append(float(mdl.elbo(mS)))
-            nl, rm = self._metrics(*mS)
+            el, nl, rm = self._elbo_nlpd_rmse(mS)
+            elbos.append(el)
             nlpds.append(nl)
             rmses.append(rm)
             if elbos[-2] > elbos[-1] or abs(elbos[-2] - elbos[-1]) < self.lr_tol:
@@ -245,6 +273,16 @@ class VIMarkovGPTrainer:
             if abs(elbos[-2] - elbos[-1]) < self.optim_tol:
                 break
         return elbos[1:], nlpds, rmses
+
+    def _elbo_nlpd_rmse(self, mS=None):
+        """ELBO, NLPD and RMSE of all trajectories of all ranks from ONE all-reduce."""
+        mdl = self.model
+        mS = mS if mS is not None else mdl._forward_packed()
+        e = float(mdl.elbo(mS))
+        if self._metrics.idx is None:
+            return sum_over_ranks([e])[0], float("nan"), float("nan")
+        tot = sum_over_ranks([e, *self._metrics.sums(*mS)])
+        return (tot[0], *self._metrics.finish(*tot[1:]))
 
     def optimize_prior_x0(self):
         """
@@ -260,6 +298,10 @@ class VIMarkovGPTrainer:
             M = (torch.diag(torch.tensor(sde.q_diag, dtype=torch.float64)) / (2.0 * sde.decay)).numpy()
         else:
             g_loc, g_scale = mdl.grad_initial_state()
+            # sums over the trajectories: of every rank
+            g = sum_over_ranks(torch.cat([g_loc.reshape(-1), g_scale.reshape(-1)]).tolist())
+            g_loc = torch.tensor(g[:g_loc.numel()], dtype=torch.float64, device=g_loc.device).view_as(g_loc)
+            g_scale = torch.tensor(g[g_loc.numel():], dtype=torch.float64, device=g_scale.device).view_as(g_scale)
             P0 = torch.from_numpy(mdl.p0_cov).to(mdl.device)
             mean = mdl.p0_mu - self.prior_initial_state_lr * g_loc.cpu().numpy()
             M = (linalg.cholesky(P0) - self.prior_initial_state_lr * g_scale).cpu().numpy()
@@ -268,9 +310,9 @@ class VIMarkovGPTrainer:
     def optimize_prior_sde(self):
         """vi_markov_gp_trainer.py:163-201: Adam on the drift parameters with dE_sde/d params at the current (m, S)."""
         mdl, sde = self.model, self.model.prior_sde
-        elbo_vals, nlpd_vals, rmse_vals = [float(mdl.elbo())], [], []
+        elbo_vals, nlpd_vals, rmse_vals = [self._elbo_nlpd_rmse()[0]], [], []
         for _ in range(self.learning_max_itr):
-            grads = mdl.grad_prior_sde_params()
+            grads = sum_over_ranks(mdl.grad_prior_sde_params())      # of the whole batch, before the optimiser sees it
             names = sde.trainable_variables
             for n, v in zip(names, self.prior_sde_optim.step([sde.get(n) for n in names], grads)):
                 sde.assign(n, v)
@@ -278,8 +320,8 @@ class VIMarkovGPTrainer:
             if self.optimize_prior_initial_state:
                 self.optimize_prior_x0()
             mS = mdl._forward_packed()
-            elbo_vals.append(float(mdl.elbo(mS)))
-            nl, rm = self._metrics(*mS)
+            el, nl, rm = self._elbo_nlpd_rmse(mS)
+            elbo_vals.append(el)
             nlpd_vals.append(nl)
             rmse_vals.append(rm)
             self.store_prior_param_vals()
@@ -296,9 +338,8 @@ class VIMarkovGPTrainer:
             mdl.update_lagrange(mS)
             mdl.update_param(mS, lr=1e-6)
         mS = mdl._forward_packed()
-        elbo_vals = [float(mdl.elbo(mS))]
-        n0, r0 = self._metrics(*mS)
-        nlpd_vals, rmse_vals = [n0], [r0]
+        e0, n0, r0 = self._elbo_nlpd_rmse(mS)
+        elbo_vals, nlpd_vals, rmse_vals = [e0], [n0], [r0]
         for _ in range(self.max_itr):
             e, n, r = self.perform_inference()
             elbo_vals, nlpd_vals, rmse_vals = elbo_vals + e, nlpd_vals + n, rmse_vals + r
