@@ -418,34 +418,44 @@ def bench_sparse(h, data_rank):
     from vidp_amd.packed import _ptr, _stream
     from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
     a, device = h.args, h.device
-    M, d = 200000, 16
+    M, d = a.c5_M, 16
     # grid spacing 0.1: rho = spacing / lengthscale >= 0.05 as in config 2 ("value ranges keep every Q_k SPD with cond <~ 1e8";
     # at spacing 0.01 the Matern-5/2 component with lengthscale 2 makes the prior precision numerically singular in fp64, cond ~ 1e15)
     N, span = 2 * M, 0.1 * M
-    rng = np.random.default_rng(71892305 + 5 + data_rank)
+    shared = h.world > 1          # config 5 as BASELINE states it: ONE chain over the GPUs of the node, cut along time (strong scaling)
+    rng = np.random.default_rng(71892305 + 5 + (0 if shared else data_rank))
     z = torch.linspace(0, span, M, dtype=torch.float64, device=device)
     t = torch.from_numpy(np.sort(rng.uniform(0, span, size=N))).to(device)
     y = (torch.sin(3 * t) + 0.1 * torch.from_numpy(rng.normal(size=N)).to(device))[:, None]
     kern = sum16_kernel(K)
     assert kern.state_dim == d
-    m = SparseCVIGaussianProcess(kern, z, Gaussian(0.01), learning_rate=0.5)
+    # shared: every rank owns a contiguous range of inducing states, their sites and the data points between them; per step the
+    # ranks exchange the edge sites (all-gather), the exchange level of the factorisation and the four ELBO scalars (distributed.ChainShard)
+    m = SparseCVIGaussianProcess(kern, z, Gaussian(0.01), learning_rate=0.5, shard=(h.rank, h.world) if shared else None)
     state = {"e": None}
 
     def step():
         m.update_sites((t, y))
-        state["e"] = h.vdist.allreduce_sum_(m.classic_elbo((t, y)))
+        state["e"] = m.classic_elbo((t, y))              # shared: already the sum over the ranks
 
     elapsed = h.run(step)
-    pl = m.dist_p.plan
+    pl = m._shard.plan if shared else m.dist_p.plan
     pl.check_info()
     e = float(state["e"])
     assert np.isfinite(e), "non-finite ELBO"
     out = h.line(elapsed, f"sparse / inducing-state CVI (SparseCVIGaussianProcess.update_sites + classic_elbo), Sum-of-Matern kernel d={d}, "
-                          f"{M} inducing states, {N} observations, one chain per GPU", "c5",
-                 {"trajectories_per_gpu": 1, "T": M, "d": d, "observations": N, "total_trajectories": h.world,
+                          f"{M} inducing states, {N} observations, " + (f"ONE chain shared between {h.world} GPUs along time" if shared
+                                                                         else "one chain on one GPU"), "c5",
+                 {"trajectories_per_gpu": 1.0 / h.world, "T": M, "d": d, "observations": N, "total_trajectories": 1,
                   "partition": {"levels": pl.nlevels, "segment_len": pl.R, "segments": pl.P}})
+    if shared:
+        sh = m._shard
+        out["scaling"] = "strong"
+        out["config"]["parallelism"] = (f"time-sharded chain: exchange level {sh.level} ({sh.exchange.numel()} doubles all-reduced per "
+                                        f"factorisation), edge sites all-gathered ({m.nat1.shape[-1] + m.nat2.shape[-1] ** 2} doubles per rank), "
+                                        f"4 ELBO scalars all-reduced; rank 0 owns inducing states [{sh.node_lo}, {sh.node_hi})")
     out["elbo_last"] = e
-    if h.rank == 0:
+    if h.rank == 0 and not shared:
         # the level-0 kernels of the MFMA sweeps alone (mfgm_wide_stage), on the model's own arrays, in the form the model uses
         lib = vidp_amd._lib.load()
         m._marginals()
@@ -535,6 +545,7 @@ def main():
     ap.add_argument("--no-vdp", action="store_true", help="skip the secondary VDP step measurement")
     ap.add_argument("--config", default="headline", choices=["headline", "c1", "c2", "c3", "c5"],
                     help="BASELINE.json configuration (default: the size the metric is quoted on)")
+    ap.add_argument("--c5-M", type=int, default=200000, help="inducing states of config c5 (tests use a smaller chain)")
     ap.add_argument("--data-rank", type=int, default=None,
                     help="generate the synthetic trajectories of this rank (default: the process's own rank); lets a single-rank run "
                          "reproduce one shard of a multi-rank run")

@@ -40,6 +40,13 @@ def load():
         lib.ref_cvi_dp_step.restype = ctypes.c_double
         lib.ref_cvi_dp_step.argtypes = ([ctypes.c_int] * 4 + [_ip, _dp, _dp, ctypes.c_double] + [_dp] * 6 + [ctypes.c_double]
                                         + [_dp] * 7 + [ctypes.c_double, ctypes.c_double, _dp, _dp])
+        lib.ref_vdp_work_doubles.restype = ctypes.c_size_t
+        lib.ref_vdp_work_doubles.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.ref_vdp_forward.restype = None
+        lib.ref_vdp_forward.argtypes = [ctypes.c_int] * 3 + [_dp] * 3 + [ctypes.c_double, _dp, _dp, ctypes.c_int, _dp, _dp]
+        lib.ref_vdp_step.restype = ctypes.c_double
+        lib.ref_vdp_step.argtypes = ([ctypes.c_int] * 4 + [_ip, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp,
+                                     ctypes.c_double] + [_dp] * 8 + [ctypes.c_double, ctypes.c_int, _dp, _dp])
         lib.ref_num_threads.restype = ctypes.c_int
         lib.ref_set_num_threads.argtypes = [ctypes.c_int]
         lib.ref_set_num_threads.restype = None
@@ -147,3 +154,33 @@ class CviDpStepState(CviStepState):
                                    self.logdetR, _p(self.p1), _p(self.pd), _p(self.ps), _p(self.alpha), _p(self.beta),
                                    _p(self.qdiag), self.dt, _p(self.init_mu), _p(self.init_cov), _p(self.g1), _p(self.g2d),
                                    _p(self.g2s), _p(self.d1), _p(self.d2), lr_d, lr_g, _p(self.work), _p(self.elbo))
+
+
+class VdpStepState:
+    """Host arrays for ref_vdp_step: B trajectories of the VDP model (oracle/np_models.VariationalMarkovGP, closed_form=True) with a
+    per-dimension cubic drift af x - bf x^3, diagonal q, Gaussian likelihood; q(x0) fixed at the prior's initial state."""
+
+    def __init__(self, A, b, idx, y, Rinv, logdetR, af, bf, qdiag, dt, p0_mu, p0_cov, stabilize=True):
+        self.A, self.b = c64(A).copy(), c64(b).copy()
+        self.B, N, self.d = self.b.shape
+        self.T = N + 1
+        self.idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.n = self.idx.shape[0]
+        self.y, self.Rinv, self.logdetR = c64(y), c64(Rinv), float(logdetR)
+        self.af, self.bf, self.qdiag, self.dt = float(af), float(bf), c64(qdiag), float(dt)
+        self.p0_mu, self.p0_cov = c64(p0_mu), c64(p0_cov)
+        self.q0_mu, self.q0_chol = self.p0_mu.copy(), np.linalg.cholesky(self.p0_cov)
+        self.stabilize = int(bool(stabilize))
+        lib = load()
+        self.m, self.S = np.zeros((self.B, self.T, self.d)), np.zeros((self.B, self.T, self.d, self.d))
+        self.work = np.zeros(self.B * lib.ref_vdp_work_doubles(self.T, self.d))
+        self.elbo = np.zeros(self.B)
+        lib.ref_vdp_forward(self.B, self.T, self.d, _p(self.A), _p(self.b), _p(self.qdiag), self.dt, _p(self.q0_mu), _p(self.q0_chol),
+                            self.stabilize, _p(self.m), _p(self.S))
+
+    def step(self, lr):
+        lib = load()
+        return lib.ref_vdp_step(self.B, self.T, self.d, self.n, self.idx.ctypes.data_as(_ip), _p(self.y), _p(self.Rinv), self.logdetR,
+                                self.af, self.bf, _p(self.qdiag), self.dt, _p(self.q0_mu), _p(self.q0_chol), _p(self.p0_mu),
+                                _p(self.p0_cov), _p(self.A), _p(self.b), _p(self.m), _p(self.S), float(lr), self.stabilize,
+                                _p(self.work), _p(self.elbo))

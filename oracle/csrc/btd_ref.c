@@ -13,6 +13,9 @@
  *   ref_kl_terms            StateSpaceModel.kl_divergence         (state_space_model.py:557-593)
  *   ref_cvi_step            one CVISitesSSM iteration: update_data_sites, update_girsanov_sites, classic_elbo
  *                           (variational_cvi_sde.py:161-192, 279-352; docs/diffusion_processes/cvi_dp_trainer.py:72-75)
+ *   ref_vdp_forward / ref_vdp_step   VariationalMarkovGP: forward_pass, update_lagrange + update_param, elbo
+ *                           (markovflow/models/vi_sde.py:171-204, 289-414, 436-455; the loop body of
+ *                           docs/diffusion_processes/vi_markov_gp_trainer.py:50-75), closed-form cubic-drift moments
  * banded-matrices (the native dependency that holds these loops in the reference) is not vendored in
  * /root/reference; its published algorithms are restated here in block form.
  */
@@ -513,6 +516,244 @@ double ref_cvi_dp_step(int B, int T, int d, int n, const int* idx, const double*
         double kl = ref_sde_kl(mu, Sd, Ss, alpha, beta, qdiag, dt, init_mu, init_cov, T, d, 0, NULL, NULL, NULL);
         elbo_out[b] = ve - kl;
         total += ve - kl;
+    }
+    return total;
+}
+
+
+/* ---- VDP (VariationalMarkovGP, markovflow/models/vi_sde.py) for a per-dimension cubic drift f_i(x) = af x_i - bf x_i^3 and diagonal q ----
+ * Restates oracle/np_models.VariationalMarkovGP (closed_form = True), which restates the reference line by line.
+ * Layout per trajectory: A [N,d,d], b [N,d] (the posterior drift is -A x + b), m [T,d], S [T,d,d] with T = N + 1. */
+static double vdp_fix(double x, double lo, double hi) {
+    if (isnan(x)) x = 1e-8;
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+/* E u, E u', Var u of u(x) = af x - bf x^3 under N(m, v) and the partials the gradients need (oracle/np_sde.cubic_moments) */
+static void vdp_cubic(double af, double bf, double m, double v, double* ubar, double* J, double* V, double* ubar_v, double* J_m,
+                      double* J_v, double* V_m, double* V_v) {
+    const double a = m * m + v;
+    *ubar = af * m - bf * (m * m * m + 3 * m * v);
+    *J = af - 3 * bf * a;
+    *V = af * af * v - 6 * af * bf * v * a + bf * bf * (9 * m * m * m * m * v + 36 * m * m * v * v + 15 * v * v * v);
+    *ubar_v = -3 * bf * m;
+    *J_m = -6 * bf * m;
+    *J_v = -3 * bf;
+    *V_m = -12 * af * bf * m * v + bf * bf * (36 * m * m * m * v + 72 * m * v * v);
+    *V_v = af * af - 6 * af * bf * (m * m + 2 * v) + bf * bf * (9 * m * m * m * m + 72 * m * m * v + 45 * v * v);
+}
+/* forward_pass (vi_sde.py:171-204): marginals of x_{k+1} = (I - A_k dt) x_k + b_k dt + N(0, q dt), by the moment recursion;
+ * stabilize: NaN -> 1e-8 and clipping of the transition parameters to [-1, 1] (vi_sde.py:186-200) */
+static void vdp_forward_one(int T, int d, const double* A, const double* b, const double* qdiag, double dt, const double* q0_mu,
+                            const double* q0_chol, int stabilize, double* m, double* S, double* tmp) {
+    const int dd = d * d, N = T - 1;
+    double *At = tmp, *AS = tmp + dd;
+    memcpy(m, q0_mu, (size_t)d * sizeof(double));
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double t = 0.0;
+            for (int k = 0; k < d; ++k) t += q0_chol[IDX(i, k, d)] * q0_chol[IDX(j, k, d)];
+            S[IDX(i, j, d)] = t;
+        }
+    for (int k = 0; k < N; ++k) {
+        const double *Ak = A + (size_t)k * dd, *bk = b + (size_t)k * d, *mk = m + (size_t)k * d, *Sk = S + (size_t)k * dd;
+        double *mn = m + (size_t)(k + 1) * d, *Sn = S + (size_t)(k + 1) * dd;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double a = -Ak[IDX(i, j, d)] * dt + (i == j ? 1.0 : 0.0);
+                At[IDX(i, j, d)] = stabilize ? vdp_fix(a, -1.0, 1.0) : a;
+            }
+        for (int i = 0; i < d; ++i) {
+            double bt = bk[i] * dt;
+            if (stabilize) bt = vdp_fix(bt, -1.0, 1.0);
+            double t = bt;
+            for (int j = 0; j < d; ++j) t += At[IDX(i, j, d)] * mk[j];
+            mn[i] = t;
+        }
+        gemm_d(1.0, At, 0, Sk, 0, 0.0, AS, d);
+        gemm_d(1.0, AS, 0, At, 1, 0.0, Sn, d);
+        for (int i = 0; i < d; ++i) Sn[IDX(i, i, d)] += qdiag[i] * dt;
+    }
+}
+/* E_sde (vi_sde.py:416-434 via oracle/np_sde.e_sde_closed_form) and, when dm / dS are given, its gradients divided by dt */
+static double vdp_esde_one(int N, int d, double af, double bf, const double* qdiag, double dt, const double* A, const double* b,
+                           const double* m, const double* S, double* dEdm, double* dEdS, double* tmp) {
+    const int dd = d * d;
+    double* LS = tmp;
+    double E = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const double *An = A + (size_t)n * dd, *bn = b + (size_t)n * d, *mn = m + (size_t)n * d, *Sn = S + (size_t)n * dd;
+        double* gm = dEdm ? dEdm + (size_t)n * d : NULL;
+        double* gS = dEdS ? dEdS + (size_t)n * dd : NULL;
+        if (gm) memset(gm, 0, (size_t)d * sizeof(double));
+        if (gS) memset(gS, 0, (size_t)dd * sizeof(double));
+        for (int i = 0; i < d; ++i)                                  /* L = -A */
+            for (int j = 0; j < d; ++j) {
+                double t = 0.0;
+                for (int k = 0; k < d; ++k) t -= An[IDX(i, k, d)] * Sn[IDX(k, j, d)];
+                LS[IDX(i, j, d)] = t;
+            }
+        for (int i = 0; i < d; ++i) {
+            double El = bn[i], LSL = 0.0;
+            for (int k = 0; k < d; ++k) {
+                El -= An[IDX(i, k, d)] * mn[k];
+                LSL -= LS[IDX(i, k, d)] * An[IDX(i, k, d)];
+            }
+            const double LSii = LS[IDX(i, i, d)];
+            double Ef, Jf, Vf, ubar_v, J_m, J_v, V_m, V_v;
+            vdp_cubic(af, bf, mn[i], Sn[IDX(i, i, d)], &Ef, &Jf, &Vf, &ubar_v, &J_m, &J_v, &V_m, &V_v);
+            const double r = El - Ef, w = 1.0 / qdiag[i];
+            E += 0.5 * dt * w * (LSL - 2.0 * LSii * Jf + Vf + r * r);
+            if (gm) {
+                for (int k = 0; k < d; ++k) gm[k] += 0.5 * w * 2.0 * r * (-An[IDX(i, k, d)] - (k == i ? Jf : 0.0));
+                gm[i] += 0.5 * w * (-2.0 * LSii * J_m + V_m);
+                for (int j = 0; j < d; ++j)
+                    for (int k = 0; k < d; ++k) {
+                        const double lj = -An[IDX(i, j, d)], lk = -An[IDX(i, k, d)];
+                        gS[IDX(j, k, d)] += 0.5 * w * (lj * lk - Jf * (lj * (k == i ? 1.0 : 0.0) + (j == i ? 1.0 : 0.0) * lk));
+                    }
+                gS[IDX(i, i, d)] += 0.5 * w * (-2.0 * LSii * J_v + V_v - 2.0 * r * ubar_v);
+            }
+        }
+    }
+    return E;
+}
+
+size_t ref_vdp_work_doubles(int T, int d) { return (size_t)T * (2 * d * d + 2 * d) + 8 * d * d; }
+
+/* marginals of the current (A, b) for B trajectories */
+void ref_vdp_forward(int B, int T, int d, const double* A, const double* b, const double* qdiag, double dt, const double* q0_mu,
+                     const double* q0_chol, int stabilize, double* m, double* S) {
+    const int dd = d * d, N = T - 1;
+#pragma omp parallel for schedule(static)
+    for (int bb = 0; bb < B; ++bb) {
+        double tmp[2 * 64];
+        double* t = (2 * dd <= 128) ? tmp : (double*)malloc((size_t)2 * dd * sizeof(double));
+        vdp_forward_one(T, d, A + (size_t)bb * N * dd, b + (size_t)bb * N * d, qdiag, dt, q0_mu, q0_chol, stabilize, m + (size_t)bb * T * d,
+                        S + (size_t)bb * T * dd, t);
+        if (t != tmp) free(t);
+    }
+}
+
+/*
+ * One iteration of VIMarkovGPTrainer.perform_inference's loop body (vi_markov_gp_trainer.py:55-75) for B trajectories:
+ *   update_lagrange(m, S); update_param(m, S, lr); (m, S) = forward_pass(); elbo()
+ * m, S: on entry the marginals of the current (A, b) (ref_vdp_forward), on return those of the updated ones.  Gaussian likelihood with
+ * precision Rinv at the grid indices idx [n] (sorted).  q(x0) = N(q0_mu, q0_chol q0_chol^T) is kept fixed, p(x0) = N(p0_mu, p0_cov).
+ */
+double ref_vdp_step(int B, int T, int d, int n, const int* idx, const double* y, const double* Rinv, double logdetR, double af,
+                    double bf, const double* qdiag, double dt, const double* q0_mu, const double* q0_chol, const double* p0_mu,
+                    const double* p0_cov, double* A, double* b, double* m, double* S, double lr, int stabilize, double* work,
+                    double* elbo_out) {
+    const int dd = d * d, N = T - 1;
+    const size_t W = ref_vdp_work_doubles(T, d);
+    const double CLO = -5000.0, CHI = 5000.0;                     /* vi_sde.py:59-60 */
+    double total = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+    for (int bb = 0; bb < B; ++bb) {
+        double* w = work + (size_t)bb * W;
+        double* dEdm = w; w += (size_t)T * d;
+        double* dEdS = w; w += (size_t)T * dd;
+        double* lam = w; w += (size_t)T * d;
+        double* psi = w; w += (size_t)T * dd;
+        double* tmp = w;
+        double *Ab = A + (size_t)bb * N * dd, *bv = b + (size_t)bb * N * d, *mb = m + (size_t)bb * T * d, *Sb = S + (size_t)bb * T * dd;
+        const double* Y = y + (size_t)bb * n * d;
+        /* update_lagrange (vi_sde.py:289-347) */
+        vdp_esde_one(N, d, af, bf, qdiag, dt, Ab, bv, mb, Sb, dEdm, dEdS, tmp);
+        if (stabilize) {
+            for (size_t i = 0; i < (size_t)N * d; ++i) dEdm[i] = vdp_fix(dEdm[i], CLO, CHI);
+            for (size_t i = 0; i < (size_t)N * dd; ++i) dEdS[i] = vdp_fix(dEdS[i], CLO, CHI);
+        }
+        memset(lam, 0, (size_t)N * d * sizeof(double));
+        memset(psi, 0, (size_t)N * dd * sizeof(double));
+        for (int t = 0; t < N; ++t)
+            for (int i = 0; i < d; ++i) psi[(size_t)t * dd + IDX(i, i, d)] = 1e-10;
+        int io = n - 1;
+        for (int t = N - 1; t >= 1; --t) {
+            const double *At = Ab + (size_t)t * dd, *pt = psi + (size_t)t * dd, *lt = lam + (size_t)t * d;
+            double *pp = psi + (size_t)(t - 1) * dd, *lp = lam + (size_t)(t - 1) * d;
+            while (io >= 0 && idx[io] > t) --io;
+            const int has = (io >= 0 && idx[io] == t);
+            for (int i = 0; i < d; ++i) {
+                double dl = -dEdm[(size_t)t * d + i];
+                for (int k = 0; k < d; ++k) dl += At[IDX(i, k, d)] * lt[k];
+                double om = 0.0;
+                if (has) {
+                    for (int c = 0; c < d; ++c) om += Rinv[IDX(i, c, d)] * (Y[(size_t)io * d + c] - mb[(size_t)t * d + c]);
+                    if (stabilize) om = vdp_fix(om, CLO, CHI);
+                }
+                lp[i] = lt[i] - dt * dl - om;
+                for (int j = 0; j < d; ++j) {
+                    double dp = -dEdS[(size_t)t * dd + IDX(i, j, d)];
+                    for (int k = 0; k < d; ++k) dp += 2.0 * pt[IDX(i, k, d)] * At[IDX(k, j, d)];       /* psi A + psi A, as written there */
+                    double oS = has ? -0.5 * Rinv[IDX(i, j, d)] : 0.0;
+                    if (has && stabilize) oS = vdp_fix(oS, CLO, CHI);
+                    pp[IDX(i, j, d)] = pt[IDX(i, j, d)] - dt * dp - oS;
+                }
+            }
+        }
+        /* update_param (vi_sde.py:349-414) */
+        for (int t = 0; t < N; ++t) {
+            double *At = Ab + (size_t)t * dd, *bt = bv + (size_t)t * d;
+            const double *mt = mb + (size_t)t * d, *St = Sb + (size_t)t * dd;
+            double *pt = psi + (size_t)t * dd, *lt = lam + (size_t)t * d;
+            double Atil[64], Ef[8];
+            double* At_ = (dd <= 64) ? Atil : tmp;
+            for (int i = 0; i < d; ++i) {
+                double Jf, Vf, u1, u2, u3, u4, u5, ef;
+                vdp_cubic(af, bf, mt[i], St[IDX(i, i, d)], &ef, &Jf, &Vf, &u1, &u2, &u3, &u4, &u5);
+                if (d <= 8) Ef[i] = ef; else tmp[dd + i] = ef;
+                for (int j = 0; j < d; ++j) {
+                    double p = pt[IDX(i, j, d)];
+                    if (stabilize) p = vdp_fix(p, CLO, CHI);
+                    At_[IDX(i, j, d)] = (i == j ? -Jf : 0.0) + 2.0 * qdiag[i] * p;
+                }
+            }
+            for (int i = 0; i < d; ++i) {
+                double l = lt[i];
+                if (stabilize) l = vdp_fix(l, CLO, CHI);
+                double bt_ = ((d <= 8) ? Ef[i] : tmp[dd + i]) - qdiag[i] * l;
+                for (int j = 0; j < d; ++j) bt_ += At_[IDX(i, j, d)] * mt[j];
+                bt[i] = (1.0 - lr) * bt[i] + lr * bt_;
+            }
+            for (int e = 0; e < dd; ++e) At[e] = (1.0 - lr) * At[e] + lr * At_[e];
+        }
+        /* forward_pass and elbo (vi_sde.py:171-204, 436-455) */
+        vdp_forward_one(T, d, Ab, bv, qdiag, dt, q0_mu, q0_chol, stabilize, mb, Sb, tmp);
+        double ve = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double* mm = mb + (size_t)idx[i] * d;
+            const double* SS = Sb + (size_t)idx[i] * dd;
+            double quad = 0.0, trc = 0.0;
+            for (int r = 0; r < d; ++r)
+                for (int c = 0; c < d; ++c) {
+                    quad += (Y[(size_t)i * d + r] - mm[r]) * Rinv[IDX(r, c, d)] * (Y[(size_t)i * d + c] - mm[c]);
+                    trc += Rinv[IDX(r, c, d)] * SS[IDX(r, c, d)];
+                }
+            ve += -0.5 * trc - 0.5 * quad - 0.5 * logdetR - 0.5 * d * log(2.0 * M_PI);
+        }
+        const double esde = vdp_esde_one(N, d, af, bf, qdiag, dt, Ab, bv, mb, Sb, NULL, NULL, tmp);
+        /* KL[q(x0) || p(x0)] */
+        double *S0 = tmp, *Pinv = tmp + dd, *t2 = tmp + 2 * dd;
+        double ld0 = 0.0, ldp = 0.0;
+        for (int i = 0; i < d; ++i) {
+            ld0 += 2.0 * log(fabs(q0_chol[IDX(i, i, d)]));
+            for (int j = 0; j < d; ++j) {
+                double t = 0.0;
+                for (int k = 0; k < d; ++k) t += q0_chol[IDX(i, k, d)] * q0_chol[IDX(j, k, d)];
+                S0[IDX(i, j, d)] = t;
+            }
+        }
+        inv_spd(p0_cov, Pinv, &ldp, d, t2);
+        double tr0 = 0.0, mah = 0.0;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                tr0 += Pinv[IDX(i, j, d)] * S0[IDX(j, i, d)];
+                mah += (p0_mu[i] - q0_mu[i]) * Pinv[IDX(i, j, d)] * (p0_mu[j] - q0_mu[j]);
+            }
+        const double kl0 = 0.5 * (tr0 + mah - d + ldp - ld0);
+        elbo_out[bb] = ve - esde - kl0;
+        total += elbo_out[bb];
     }
     return total;
 }

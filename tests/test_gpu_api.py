@@ -1387,6 +1387,32 @@ def test_bench_gpus_2_launches_two_ranks(amd):
     np.testing.assert_allclose(two["elbo_last"], sum(s["elbo_last"] for s in singles), rtol=1e-12)
 
 
+def test_bench_c5_gpus_2_is_one_shared_chain(amd):
+    """`python bench.py --config c5 --gpus 2`: config 5 as BASELINE states it -- ONE chain shared between the ranks (gloo on the one GPU
+    here), strong scaling -- and its ELBO equals the single-GPU run's on the same chain."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VIDP_DIST_BACKEND"] = "gloo"
+    common = ["--config", "c5", "--c5-M", "20000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra + common, env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+
+    two, one = run(["--gpus", "2"]), run(["--gpus", "1"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["total_trajectories"] == 1
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak"
+    np.testing.assert_allclose(two["elbo_last"], one["elbo_last"], rtol=1e-9)
+
+
 @pytest.mark.parametrize("tag,bs", [("b0", ()), ("b3", (3,))])
 def test_kalman_filter_sites_fused_output_dim_2(amd, tag, bs):
     """KA2's fixture (T = 8, d = 3, o = 2, non-zero prior mean) as a filter with per-step sites nat1 = R^{-1} y, nat2 = -1/2 R^{-1}

@@ -102,3 +102,41 @@ def test_c_cvi_dp_step(rng, d, T):
             ref.append(m.classic_elbo())
         np.testing.assert_allclose(st.elbo, ref, rtol=1e-7, atol=1e-7)
         np.testing.assert_allclose(total, np.sum(ref), rtol=1e-7)
+
+
+@pytest.mark.parametrize("d,T,stabilize", [(2, 40, False), (6, 60, True)])
+def test_c_vdp_step(rng, d, T, stabilize):
+    """The C port of the VDP inference step (ref_vdp_step: update_lagrange + update_param, forward_pass, elbo -- bench.py's config-3
+    cpu_baseline) against the NumPy oracle model (oracle/np_models.VariationalMarkovGP, closed-form cubic-drift moments, pinned to the
+    reference's quadrature at d <= 2 in tests/test_oracle_sde.py), started at the OU drift -4 x as the bench starts it."""
+    from oracle import np_sde
+    B, n, dt = 2, 6, 0.01
+    sde = np_sde.DoubleWellSDE(np.eye(d))
+    grid = np.arange(T) * dt
+    idx = np.sort(rng.choice(np.arange(1, T - 1), size=n, replace=False))
+    y = np.sign(rng.normal(size=(B, n, d))) + 0.2 * rng.normal(size=(B, n, d))
+    cholR = 0.3 * (np.eye(d) + 0.3 * np.eye(d, k=-1))
+    init = (np.zeros(d), np.eye(d))
+    models = [np_models.VariationalMarkovGP(idx, y[b], sde, grid, np_models.MultivariateGaussianLik(cholR), *init,
+                                            stabilize_system=stabilize, closed_form=True) for b in range(B)]
+    for m in models:
+        m.A = np.broadcast_to(4.0 * np.eye(d), m.A.shape).copy()
+    af, bf = np_sde.drift_cubic(sde)
+    st = c_ref.VdpStepState(np.stack([m.A for m in models]), np.stack([m.b for m in models]), idx, y, np.linalg.inv(cholR @ cholR.T),
+                            2 * np.sum(np.log(np.diag(cholR))), af, bf, np.ones(d), dt, *init, stabilize=stabilize)
+    for b, m in enumerate(models):
+        mm, SS = m.forward_pass()
+        np.testing.assert_allclose(st.m[b], mm, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(st.S[b], SS, rtol=1e-9, atol=1e-12)
+    for lr in (0.05, 0.02, 0.02):
+        total = st.step(lr)
+        ref = []
+        for b, m in enumerate(models):
+            mm, SS = m.forward_pass()
+            m.update_lagrange(mm, SS)
+            m.update_param(mm, SS, lr)
+            ref.append(m.elbo())
+            np.testing.assert_allclose(st.A[b], m.A, rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(st.b[b], m.b, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(st.elbo, ref, rtol=1e-8)
+        np.testing.assert_allclose(total, np.sum(ref), rtol=1e-8)
