@@ -83,24 +83,26 @@ def synth_double_well(B, T, d, dt, obs_every, noise, seed):
     return idx, ys
 
 
-def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
-    """The plain-C port (oracle/csrc/btd_ref.c) of the same CVI-DP step on a bounded sample of trajectories."""
+def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None, drift=None, Lc=None):
+    """The plain-C port (oracle/csrc/btd_ref.c) of the same CVI-DP step on a bounded sample of trajectories.
+    drift = (alpha, beta, init_var): the Euler map x + dt f(x) = alpha x - beta x^3 and the variance of p(x0) = of the initial posterior
+    path the prior is linearised on (default: the headline's double well, N(0, I))."""
     from oracle import c_ref
     lib = c_ref.load()
     threads = int(lib.ref_num_threads())
     Bs = max(1, min(args.B, threads))
     T, d = args.T, args.d
-    alpha, beta = 1.0 + dt * 4.0, dt * 4.0
-    Jlin = alpha - 3.0 * beta                       # linearisation on N(0, I): A = J, b = 0
+    alpha, beta, v0 = drift if drift is not None else (1.0 + dt * 4.0, dt * 4.0, 1.0)
+    Jlin = alpha - 3.0 * beta * v0                  # linearisation on N(0, v0 I): A = E u'(x) = alpha - 3 beta v0, b = 0
     A = np.broadcast_to(Jlin * np.eye(d), (T - 1, d, d))
     off = np.zeros((T, d))
-    chol = np.concatenate([np.eye(d)[None], np.broadcast_to(np.sqrt(dt) * np.eye(d), (T - 1, d, d))], axis=0)
+    chol = np.concatenate([np.sqrt(v0) * np.eye(d)[None], np.broadcast_to(np.sqrt(dt) * np.eye(d), (T - 1, d, d))], axis=0)
     lin, diag, sub = c_ref.ssm_to_naturals(A, off, chol)
     rep = lambda a: np.broadcast_to(a, (Bs,) + a.shape).copy()
-    Lc = obs_chol(d, noise)
+    Lc = obs_chol(d, noise) if Lc is None else Lc
     Rinv = np.linalg.inv(Lc @ Lc.T)
     st = c_ref.CviDpStepState(rep(lin), rep(diag), rep(sub), idx, ys[:Bs], Rinv, 2 * np.sum(np.log(np.diag(Lc))), alpha, beta,
-                              np.ones(d), dt, np.zeros(d), np.eye(d))
+                              np.ones(d), dt, np.zeros(d), v0 * np.eye(d))
     st.step(args.lr_data, args.lr_girsanov)         # first step doubles as warm-up and as a parity probe
     first = st.elbo.copy()
     n, t0 = 0, time.perf_counter()
@@ -115,7 +117,7 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
     # one thread, one trajectory (the OpenMP loop runs over trajectories: a single trajectory is the single-thread figure)
     lib.ref_set_num_threads(1)
     st1 = c_ref.CviDpStepState(lin[None].copy(), diag[None].copy(), sub[None].copy(), idx, ys[:1], Rinv, 2 * np.sum(np.log(np.diag(Lc))),
-                               alpha, beta, np.ones(d), dt, np.zeros(d), np.eye(d))
+                               alpha, beta, np.ones(d), dt, np.zeros(d), v0 * np.eye(d))
     st1.step(args.lr_data, args.lr_girsanov)
     t1 = time.perf_counter()
     st1.step(args.lr_data, args.lr_girsanov)
@@ -130,7 +132,37 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None):
     if gpu_first_elbo is not None:
         ref = first[:Bs]
         out["first_step_elbo_max_rel_diff_vs_gpu"] = float(np.max(np.abs(gpu_first_elbo[:Bs] - ref) / np.abs(ref)))
-    out["lapack_banded"] = lapack_banded_comparator(T, d, dt)
+    if T * d >= 100000:
+        out["lapack_banded"] = lapack_banded_comparator(T, d, dt)
+    return out
+
+
+def cpu_baseline_vdp(B, T, d, dt, noise, idx, ys, gpu_first_elbo=None):
+    """The plain-C port (oracle/csrc/btd_ref.c: ref_vdp_step, OpenMP over trajectories) of the same VDP inference step -- update_lagrange +
+    update_param, forward_pass, elbo (vi_markov_gp_trainer.py:55-75) -- on a bounded sample, started at the OU drift -4 x like the GPU run."""
+    from oracle import c_ref
+    lib = c_ref.load()
+    threads = int(lib.ref_num_threads())
+    Bs = max(1, min(B, threads))
+    Lc = obs_chol(d, noise)
+    A0 = np.broadcast_to(4.0 * np.eye(d), (Bs, T - 1, d, d))
+    st = c_ref.VdpStepState(A0, np.zeros((Bs, T - 1, d)), idx, ys[:Bs], np.linalg.inv(Lc @ Lc.T), 2 * np.sum(np.log(np.diag(Lc))), 4.0, 4.0,
+                            np.ones(d), dt, np.zeros(d), np.eye(d), stabilize=True)
+    st.step(0.01)
+    first = st.elbo.copy()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        st.step(0.01)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 8.0 or n >= 20:
+            break
+    per = el / n
+    out = {"value": 1.0 / (per * B / Bs), "unit": "ELBO steps/s", "cores": threads, "threads_used": Bs, "kind": "port",
+           "sample": f"{n} steps of {Bs} of the {B} trajectories (T={T}, d={d}), OpenMP over trajectories; {per:.3f} s per sampled step, scaled "
+                     f"linearly to {B} trajectories; closed-form cubic-drift moments as on the GPU"}
+    if gpu_first_elbo is not None:
+        out["first_step_elbo_max_rel_diff_vs_gpu"] = float(np.max(np.abs(gpu_first_elbo[:Bs] - first) / np.abs(first)))
     return out
 
 
@@ -295,11 +327,13 @@ def bench_vdp(h, data_rank):
     eye = (4.0 * torch.eye(d, dtype=torch.float64, device=device)).expand(B, T, d, d).contiguous()
     m.plan.pack(vidp_amd.FULL, eye, out=m.A)
     del eye
-    state = {"mS": m._forward_packed(), "e": None}
+    state = {"mS": m._forward_packed(), "e": None, "first": None}
 
     def step():
         m.update_lagrange_and_param(state["mS"], lr=0.01)
         state["mS"] = m._forward_packed()
+        if state["first"] is None:
+            state["first"] = m.elbo_per_trajectory(state["mS"]).clone()      # parity probe against the C port's first step
         state["e"] = h.vdist.allreduce_sum_(m.elbo(state["mS"]))
 
     elapsed = h.run(step)
@@ -330,6 +364,11 @@ def bench_vdp(h, data_rank):
         out["roofline"] = h.roofline(f"void mfgm::k_vdp_lagrange<{d}, 4>(...)",
                                      "final Lagrange sweep with the parameter update: reads m, S, A, b, R^-1 y, writes psi, lambda, A, b",
                                      h.timed(final), 8 * doubles * B * T, 1, out["ms_per_step"])
+        if h.world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline_vdp(B, T, d, dt, noise, idx, ys, state["first"].cpu().numpy())
+            except OSError as e:  # library not built
+                out["cpu_baseline"] = {"value": None, "unit": "ELBO steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
     return out
 
 
@@ -530,60 +569,16 @@ def cpu_baseline_sparse(M, N, sample=300):
 OTHER_CONFIGS = {"c3": bench_vdp, "c2": bench_cvigp, "c5": bench_sparse}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--B", type=int, default=64, help="trajectories per GPU")
-    ap.add_argument("--T", type=int, default=100000)
-    ap.add_argument("--d", type=int, default=6)
-    ap.add_argument("--lr-data", type=float, default=0.5)
-    ap.add_argument("--lr-girsanov", type=float, default=0.1)
-    ap.add_argument("--obs-every", type=int, default=50)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-vdp", action="store_true", help="skip the secondary VDP step measurement")
-    ap.add_argument("--config", default="headline", choices=["headline", "c1", "c2", "c3", "c5"],
-                    help="BASELINE.json configuration (default: the size the metric is quoted on)")
-    ap.add_argument("--c5-M", type=int, default=200000, help="inducing states of config c5 (tests use a smaller chain)")
-    ap.add_argument("--data-rank", type=int, default=None,
-                    help="generate the synthetic trajectories of this rank (default: the process's own rank); lets a single-rank run "
-                         "reproduce one shard of a multi-rank run")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        launch_ranks(args.gpus)          # does not return
-    env_world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != env_world:
-        print(f"bench.py: --gpus {args.gpus} but the launcher started {env_world} rank(s); refusing to report a mislabelled number",
-              file=sys.stderr)
-        sys.exit(2)
-
+def bench_cvidp(h, data_rank):
+    """The headline configuration (CVI-DP site-update loop on double-well trajectories, B = 64, T = 100 000, d = 6) and config 1 (the
+    reference's own CPU-runnable case: 1-d Ornstein-Uhlenbeck, T = 1001, 32 observations): CVISitesSDE.update_data_sites +
+    update_girsanov_sites + classic_elbo (docs/diffusion_processes/cvi_dp_trainer.py:72-75)."""
     import torch
     import vidp_amd
-    from vidp_amd import distributed as vdist
-    # "nccl" is RCCL on ROCm; VIDP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path only)
-    rank, world = vdist.init_from_env(backend=os.environ.get("VIDP_DIST_BACKEND", "nccl"))
-    if world > 1:
-        import torch.distributed as dist
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", torch.cuda.current_device())
-
     from vidp_amd.likelihoods import MultivariateGaussian
     from vidp_amd.sde import DoubleWellSDE, OrnsteinUhlenbeckSDE
     from vidp_amd.variational_cvi_sde import CVISitesSDE
-
-    data_rank = rank if args.data_rank is None else args.data_rank
-    harness = Harness(args, rank, world, device, dist, vdist)
-    if args.config in OTHER_CONFIGS:
-        out = OTHER_CONFIGS[args.config](harness, data_rank)
-        if rank == 0:
-            print(json.dumps(out))
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+    args, rank, world, device, dist, vdist = h.args, h.rank, h.world, h.device, h.dist, h.vdist
 
     dt, noise = 0.01, 0.1
     if args.config == "c1":
@@ -768,24 +763,131 @@ def main():
         # the whole step against SURVEY 8d's own byte count for it (full CVI step: 8 (11 d^2 + 5 d) B per trajectory-time-step, dense
         # naturals): 21.8 GB at the headline size, i.e. 2.73 ms at the HBM peak
         step_bytes = 8 * (11 * d * d + 5 * d) * B * T
-        out["roofline"]["step"] = {"survey_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
-                                   "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "level0_share_of_step": sum(r["share_of_step"] for r in rows)}
+        # what the step actually moves: the algorithmic bytes of its level-0 launches (PMC traffic agrees to 3 %, profiles/); the coarse
+        # levels and the small kernels add < 1 GB
+        actual = sum(r["algorithmic_bytes_per_launch"] * r["launches_per_step"] for r in rows)
+        level0_share = sum(r["share_of_step"] for r in rows)
+        out["roofline"]["step"] = {
+            "actual_bytes": actual, "actual_GBps": actual / (ms_per_step * 1e-3) / 1e9, "actual_frac": actual / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "survey_dense_bytes_per_step": step_bytes,
+            # a normalised speed, NOT an HBM utilisation: SURVEY 8d's byte count assumes dense naturals, which the cq state does not move
+            "effective_vs_survey_dense_bytes": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "level0_share_of_step": level0_share,
+            "coarse_levels_and_small_kernels_share_of_step": 1.0 - level0_share}
+        if cq is not None:
+            # the coarse levels (one launch per pass: separator systems of 1021 -> 4 nodes per chain, latency-bound) timed as
+            # whole call - level-0 kernels of the call
+            def whole_factor():
+                plan.cq_factor(cq, want_logdet=True, out=f)
+            t_fac = timed(whole_factor)
+            by = {r["kernel"].split("(")[0].split("::")[-1].split("<")[0]: r["kernel_ms"] for r in rows}
+            coarse_f = t_fac - by.get("k_reduce_cq", 0.0) - by.get("k_forward_cq", 0.0)
+
+            def whole_selinv():
+                assert lib.mfgm_cq_selinv_kl(plan.h, -1, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), ctypes.byref(model._sde_prm),
+                                             None if lazy else _ptr(s["Sig"]), None if lazy else _ptr(s["x"]), _ptr(klbuf),
+                                             _ptr(model.fx_mus_obs), _ptr(model.fx_covs_obs), _ptr(plan.ws), _stream()) == 0
+            coarse_b = timed(whole_selinv) - by.get("k_backward_kl_cq", 0.0)
+            out["roofline"]["step"].update(coarse_factor_ms_per_refresh=coarse_f, coarse_backward_ms_per_refresh=coarse_b,
+                                           coarse_levels_share_of_step=2 * (coarse_f + coarse_b) / ms_per_step)
         if world == 1 and not args.no_vdp and args.config == "headline":
             # free the CVI-DP state first: the VDP model keeps its own ~15 GB resident
             del model, f, s, cand, cq
             tq = sp = cst = None
             torch.cuda.empty_cache()
             out["vdp"] = vdp_step_rate(B, T, d, dt, noise, idx, ys, device)
-        if world == 1 and not args.no_cpu_baseline and args.config == "headline":
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise, first_elbo[0].cpu().numpy())
+                if args.config == "c1":
+                    out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise, first_elbo[0].cpu().numpy(),
+                                                       drift=(1.0 - 1.2 * dt, 0.0, 1.0 / 2.4), Lc=np.array([[noise]]))
+                else:
+                    out["cpu_baseline"] = cpu_baseline(args, idx, ys, dt, noise, first_elbo[0].cpu().numpy())
             except OSError as e:  # library not built
                 out["cpu_baseline"] = {"value": None, "unit": "ELBO steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    return out
+
+
+
+def other_configs(args, harness, data_rank):
+    """BASELINE.json's other configurations, each as a short run of the same contract (value, ms_per_step, roofline, cpu_baseline), so
+    that the driver's one default invocation records them all: c1 (the reference's CPU-runnable case), c2, c3 and c5 on one GPU."""
+    import copy
+    import gc
+    import torch
+    res = {}
+    for name in ("c1", "c2", "c3", "c5"):
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup, a.no_vdp = name, args.other_steps, 2, True
+        a.B, a.T, a.d, a.lr_data, a.lr_girsanov = 64, 100000, 6, 0.5, 0.1      # (c1 / c3 set their own sizes)
+        h = Harness(a, harness.rank, harness.world, harness.device, harness.dist, harness.vdist)
+        fn = bench_cvidp if name == "c1" else OTHER_CONFIGS[name]
+        try:
+            o = fn(h, data_rank)
+            res[name] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "elbo_last", "roofline", "cpu_baseline")
+                         if k in o}
+        except Exception as e:      # one configuration failing must not lose the headline line
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--B", type=int, default=64, help="trajectories per GPU")
+    ap.add_argument("--T", type=int, default=100000)
+    ap.add_argument("--d", type=int, default=6)
+    ap.add_argument("--lr-data", type=float, default=0.5)
+    ap.add_argument("--lr-girsanov", type=float, default=0.1)
+    ap.add_argument("--obs-every", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vdp", action="store_true", help="skip the secondary VDP step measurement")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="headline run only: do not append the short runs of BASELINE.json's other configurations (other_configs)")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each configuration under other_configs")
+    ap.add_argument("--config", default="headline", choices=["headline", "c1", "c2", "c3", "c5"],
+                    help="BASELINE.json configuration (default: the size the metric is quoted on)")
+    ap.add_argument("--c5-M", type=int, default=200000, help="inducing states of config c5 (tests use a smaller chain)")
+    ap.add_argument("--data-rank", type=int, default=None,
+                    help="generate the synthetic trajectories of this rank (default: the process's own rank); lets a single-rank run "
+                         "reproduce one shard of a multi-rank run")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)          # does not return
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != env_world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {env_world} rank(s); refusing to report a mislabelled number",
+              file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import vidp_amd
+    from vidp_amd import distributed as vdist
+    # "nccl" is RCCL on ROCm; VIDP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path only)
+    rank, world = vdist.init_from_env(backend=os.environ.get("VIDP_DIST_BACKEND", "nccl"))
+    if world > 1:
+        import torch.distributed as dist
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    data_rank = rank if args.data_rank is None else args.data_rank
+    harness = Harness(args, rank, world, device, dist, vdist)
+    fn = bench_cvidp if args.config in ("headline", "c1") else OTHER_CONFIGS[args.config]
+    out = fn(harness, data_rank)
+    if rank == 0 and world == 1 and args.config == "headline" and not args.no_other_configs:
+        out["other_configs"] = other_configs(args, harness, data_rank)
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
 
 
 if __name__ == "__main__":
