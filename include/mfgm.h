@@ -91,6 +91,14 @@ int mfgm_packed_factor_form(const mfgm_plan* plan, int form, const double* D, co
 int mfgm_packed_selinv_form(const mfgm_plan* plan, int form, const double* L, const double* G, const double* y, double* Sig,
                             double* Sub, double* x, void* ws, void* stream);
 
+/* The scalar assembly of a bound from its per-chain terms in one launch (kalman_filter.py:229-255: cst + term1 + term2 + term3;
+ * state_space_model.py:557-593): out[i] = c + ce * extra[i] + sum_k w[k] * terms[k][i] for i < n chains (terms device [n_terms, n],
+ * n_terms <= 8, w HOST [n_terms], extra device [n] or NULL), total = sum_i out[i] (out or total may be NULL).  info (device, may be
+ * NULL): when non-zero -- a pivot block of the factorisation behind the terms was not positive definite -- every value is NaN, so
+ * that a hot loop needs no host synchronisation to notice (mfgm_packed_factor conventions). */
+int mfgm_combine_terms(int n_terms, int n, const double* terms, const double* w, double c, const double* extra, double ce, const int* info,
+                       double* out, double* total, void* stream);
+
 /* out = a*x + b*y + c*z over n doubles (y and z may be NULL): the element-wise site / natural-parameter
  * arithmetic of the CVI updates (variational_cvi_sde.py:161-174, 279-317) on packed arrays. */
 int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, const double* y, double c,
@@ -295,6 +303,14 @@ int mfgm_kf_sites_loglik(const mfgm_plan* plan, const mfgm_kf_sites* sites, cons
 int mfgm_kf_sites_predict(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, const double* plin,
                           double* D, double* r, double* L, double* y, double* Sig, double* x, double* Fmu, double* Fvar, void* ws,
                           int* info, void* stream);
+
+/* The same marginals and projections from a factorisation that is already in place: (L, y) as mfgm_kf_sites_loglik /
+ * mfgm_kf_sites_predict left them for THESE sites (and the coarse levels of that factorisation still in ws), Ps the prior's sub-diagonal
+ * precision blocks.  With a zero-mean prior the log-likelihood and the prediction factorise the same system with the same right-hand
+ * side, H^T nat1 (kalman_filter.py:184-255 vs posterior.py:207-260 at the data): CVIGaussianProcess.update_sites after elbo()
+ * (variational_cvi.py:351-379) needs the selected inverse and the projection only. */
+int mfgm_kf_sites_predict_factored(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Ps, const double* L, const double* y,
+                                   double* Sig, double* x, double* Fmu, double* Fvar, void* ws, void* stream);
 
 /* ---- sparse / inducing-state CVI (markovflow/models/sparse_variational_cvi.py; csrc/mfgm_sparse.h) ----------------------------------------
  * One chain, M inducing states, N data points sorted in time; natural-layout arrays, d <= 32.  Interval m = 0..M lies between inducing

@@ -211,6 +211,38 @@ int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, con
     return 0;
 }
 
+namespace {
+struct CombineW { double w[8]; };
+// out[i] = c + ce extra[i] + sum_k w[k] terms[k][i]  (NaN when *info != 0: a pivot block was not positive definite), total = sum_i out[i]
+__global__ void k_combine_terms(int n_terms, int n, const double* __restrict__ terms, CombineW w, double c, const double* __restrict__ extra,
+                                double ce, const int* __restrict__ info, double* __restrict__ out, double* __restrict__ total) {
+    __shared__ double sh[4];
+    const bool bad = info && *info != 0;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double v = c + (extra ? ce * extra[i] : 0.0);
+        for (int k = 0; k < n_terms; ++k) v = __builtin_fma(w.w[k], terms[(size_t)k * n + i], v);
+        if (bad) v = __builtin_nan("");
+        if (out) out[i] = v;
+        acc += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && total) *total = sh[0] + sh[1] + sh[2] + sh[3];
+}
+}  // namespace
+
+int mfgm_combine_terms(int n_terms, int n, const double* terms, const double* w, double c, const double* extra, double ce, const int* info,
+                       double* out, double* total, void* stream) {
+    if (n_terms < 0 || n_terms > 8 || n < 1 || (n_terms > 0 && (!terms || !w)) || (!out && !total)) return 1;
+    CombineW cw;
+    for (int k = 0; k < 8; ++k) cw.w[k] = k < n_terms ? w[k] : 0.0;
+    hipLaunchKernelGGL(k_combine_terms, dim3(1), dim3(256), 0, (hipStream_t)stream, n_terms, n, terms, cw, c, extra, ce, info, out, total);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 int mfgm_node_io(const mfgm_plan* plan, int kind, double* packed, double* packed2, const long long* node_ids, int n,
                  double* values, int mode, double scale, void* stream) {
     if (!plan || !packed || kind < 0 || kind > 3 || mode < 0 || mode > 2 || n < 0) return 1;

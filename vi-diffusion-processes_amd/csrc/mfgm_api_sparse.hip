@@ -36,6 +36,15 @@ int launch_predict(const mfgm_sparse_data* data, const double* mu, const double*
                    const SparseKl& kl, hipStream_t st) {
     const int d2 = 2 * data->d;
     const SparseArgs sa = sparse_args(data);
+    static const bool vec = [] { const char* e = getenv("MFGM_SPARSE_PREDICT_V"); return !(e && atoi(e) == 0); }();
+    if (vec && data->d % 2 == 0 && data->d <= 32) {
+        // even d: the coalesced form (rows of a block and the blocks themselves are 16-byte aligned)
+        const int np = data->d * data->d / 2;
+        if (np <= 128) hipLaunchKernelGGL((k_sparse_predict_v<2>), dim3(sa.m_hi - sa.m_lo), dim3(64), 0, st, sa, mu, Sig, Sub, fmu, fvar, kl);
+        else hipLaunchKernelGGL((k_sparse_predict_v<8>), dim3(sa.m_hi - sa.m_lo), dim3(64), 0, st, sa, mu, Sig, Sub, fmu, fvar, kl);
+        MFGM_CHECK_LAUNCH();
+        return 0;
+    }
 #define PREDICT(P_) hipLaunchKernelGGL((k_sparse_predict<P_>), dim3(sa.m_hi - sa.m_lo), dim3(64), 0, st, sa, mu, Sig, Sub, fmu, fvar, kl)
     if (d2 <= 2) PREDICT(2); else if (d2 <= 4) PREDICT(4); else if (d2 <= 8) PREDICT(8); else if (d2 <= 16) PREDICT(16);
     else if (d2 <= 32) PREDICT(32); else PREDICT(64);

@@ -141,9 +141,8 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
         if (rc) return rc;
     }
     if (only_stage < 0 && (logdet || quad)) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad,
-                           logdet, quad);
-        MFGM_CHECK_LAUNCH();
+        if (launch_sum_partials(ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, P.B, logdet, quad, P.B == 1 ? ws + P.off_part2 : nullptr, st))
+            return 3;
     }
     return 0;
 }
@@ -389,8 +388,8 @@ int kf_assemble_impl(const Plan& P, const KfArgs& k, const double* Pd, const dou
     hipLaunchKernelGGL((k_kf_assemble<D, O>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], P.T, k, Pd, plin, Dg, rg, part);
     MFGM_CHECK_LAUNCH();
     if (part) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, P.lv[0].P, P.lv[0].Lpad, t1, ldR);
-        MFGM_CHECK_LAUNCH();
+        // (a single chain has thousands of per-lane partials: two deterministic stages when it pays)
+        if (launch_sum_partials(part, P.lv[0].P, P.lv[0].Lpad, P.B, t1, ldR, P.B == 1 ? ws + P.off_part2 : nullptr, st)) return 3;
     }
     return 0;
 }
@@ -409,6 +408,16 @@ int kf_predict_impl(const Plan& P, const KfArgs& k, const double* Pd, const doub
     rc = factor_impl<D>(P, Dg, Ps, rg, 1.0, 1.0, 1.0, L, nullptr, y, nullptr, nullptr, ws, info, st);
     if (rc) return rc;
     rc = selinv_impl<D>(P, L, nullptr, y, Sig, nullptr, x, ws, st, -1, nullptr, Ps, 1.0);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_kf_project<D, O>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], P.T, k, (const double*)x,
+                       (const double*)Sig, Fmu, Fvar);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+template <int D, int O>
+int kf_predict_factored_impl(const Plan& P, const KfArgs& k, const double* Ps, const double* L, const double* y, double* Sig, double* x,
+                             double* Fmu, double* Fvar, double* ws, hipStream_t st) {
+    int rc = selinv_impl<D>(P, L, nullptr, y, Sig, nullptr, x, ws, st, -1, nullptr, Ps, 1.0);
     if (rc) return rc;
     hipLaunchKernelGGL((k_kf_project<D, O>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], P.T, k, (const double*)x,
                        (const double*)Sig, Fmu, Fvar);
@@ -535,6 +544,16 @@ int mfgm_kf_sites_predict(const mfgm_plan* plan, const mfgm_kf_sites* sites, con
     if (P.T > 1 && !Ps) return 1;
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_DO(P.d, sites->o, (kf_predict_impl<DD, OO>(P, k, Pd, Ps, plin, D, r, L, y, Sig, x, Fmu, Fvar, (double*)ws, info, st)));
+}
+
+int mfgm_kf_sites_predict_factored(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Ps, const double* L, const double* y,
+                                   double* Sig, double* x, double* Fmu, double* Fvar, void* ws, void* stream) {
+    KfArgs k;
+    if (!kf_args(plan, sites, 1, k) || !L || !y || !Sig || !x || !Fmu || !Fvar || !ws) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !Ps) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_DO(P.d, sites->o, (kf_predict_factored_impl<DD, OO>(P, k, Ps, L, y, Sig, x, Fmu, Fvar, (double*)ws, st)));
 }
 
 int mfgm_mvn_ve_compact(int B, int n_per, int d, const double* mu, const double* cov, const double* y, const double* Sinv, double cst,

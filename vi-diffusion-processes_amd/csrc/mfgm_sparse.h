@@ -148,6 +148,102 @@ static __global__ __launch_bounds__(64) void k_sparse_predict(SparseArgs a, cons
     }
 }
 
+// The same pass for even d with every load coalesced (the route of config 5; k_sparse_predict above stays for odd d).  One wavefront per
+// interval; the three blocks of the pair covariance that matter -- Sigma_{m-1}, Sigma_m and the cross block C = Sigma_{m,m-1}: the upper
+// right block is C^T, so  w^T PC w = w_lo^T S_lo w_lo + w_hi^T S_hi w_hi + 2 w_hi^T C w_lo  -- are read as 16-byte pairs, pair p = lane +
+// 64 j of each block to lane `lane` (k_sparse_predict's column-per-lane mapping read C^T with a stride of a row: 16 sectors per request,
+// and fetched w from memory inside the point loop; 0.88 ms at config 5, ~2 TB/s).  The KL terms are element-wise products with the
+// prior's blocks in the same mapping; the vectors a lane needs by row / column (w, the pair mean, mu_prior - mu) go through LDS.
+template <int NJ>
+static __global__ __launch_bounds__(64) void k_sparse_predict_v(SparseArgs a, const double* __restrict__ mu, const double* __restrict__ Sig,
+                                                               const double* __restrict__ Sub, double* __restrict__ fmu,
+                                                               double* __restrict__ fvar, SparseKl kl) {
+    __shared__ double sh_w[64], sh_pm[64], sh_dv[64];
+    const int m = a.m_lo + blockIdx.x, d = a.d, d2 = 2 * d, dd = d * d, np = dd / 2, lane = threadIdx.x;
+    const int i0 = a.seg[blockIdx.x], i1 = a.seg[blockIdx.x + 1];
+    if (i0 >= i1 && !kl.part) return;
+    const bool lo_prior = (m == 0), hi_prior = (m == a.M);
+    const double2* S_lo = reinterpret_cast<const double2*>(lo_prior ? a.prior_cov : Sig + (size_t)(m - 1) * dd);
+    const double2* S_hi = reinterpret_cast<const double2*>(hi_prior ? a.prior_cov : Sig + (size_t)m * dd);
+    const double2* C = (lo_prior || hi_prior) ? nullptr : reinterpret_cast<const double2*>(Sub + (size_t)(m - 1) * dd);
+    double2 lo[NJ], hi[NJ], cc[NJ];
+    int row[NJ], col[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int p = lane + 64 * j;
+        const bool ok = p < np;
+        row[j] = ok ? (2 * p) / d : 0;
+        col[j] = ok ? 2 * p - row[j] * d : 0;
+        lo[j] = ok ? S_lo[p] : make_double2(0.0, 0.0);
+        hi[j] = ok ? S_hi[p] : make_double2(0.0, 0.0);
+        cc[j] = (ok && C) ? C[p] : make_double2(0.0, 0.0);
+    }
+    if (lane < d2) {
+        const bool h = lane >= d;
+        const int kk = h ? lane - d : lane;
+        sh_pm[lane] = h ? (hi_prior ? a.prior_mean[kk] : mu[(size_t)m * d + kk]) : (lo_prior ? a.prior_mean[kk] : mu[(size_t)(m - 1) * d + kk]);
+    }
+    if (kl.part) {
+        // node m: aD Pd_m . (Sigma_m + dv_m dv_m^T);  pair (m, m-1): 2 aS Ps_{m-1} . (Sigma_{m,m-1} + dv_m dv_{m-1}^T);  dv = mu_prior - mu
+        double tr = 0.0, mh = 0.0;
+        if (!hi_prior) {
+            if (lane < d2) {
+                const bool h = lane >= d;
+                const int kk = h ? lane - d : lane;
+                const size_t t = h ? (size_t)m : (size_t)(lo_prior ? 0 : m - 1);
+                sh_dv[lane] = (h || !lo_prior) ? kl.mup[t * d + kk] - mu[t * d + kk] : 0.0;
+            }
+            __syncthreads();
+            const double2* Pd = reinterpret_cast<const double2*>(kl.Pd + (size_t)m * dd);
+            const double2* Ps = lo_prior ? nullptr : reinterpret_cast<const double2*>(kl.Ps + (size_t)(m - 1) * dd);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int p = lane + 64 * j;
+                if (p < np) {
+                    const double2 pd = Pd[p];
+                    const double2 ps = Ps ? Ps[p] : make_double2(0.0, 0.0);
+                    const double dr = sh_dv[d + row[j]];
+                    tr += kl.aD * (pd.x * hi[j].x + pd.y * hi[j].y) + 2.0 * kl.aS * (ps.x * cc[j].x + ps.y * cc[j].y);
+                    mh += dr * (kl.aD * (pd.x * sh_dv[d + col[j]] + pd.y * sh_dv[d + col[j] + 1])
+                                + 2.0 * kl.aS * (ps.x * sh_dv[col[j]] + ps.y * sh_dv[col[j] + 1]));
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            tr += __shfl_down(tr, off, 64);
+            mh += __shfl_down(mh, off, 64);
+        }
+        if (lane == 0) {
+            kl.part[m] = tr;
+            kl.part[a.M + 1 + m] = mh;
+        }
+    }
+    for (int i = i0; i < i1; ++i) {
+        __syncthreads();                                   // the previous point's (and sh_pm's) readers / writers
+        const double wl = (lane < d2) ? a.w[(size_t)i * d2 + lane] : 0.0;
+        if (lane < d2) sh_w[lane] = wl;
+        __syncthreads();
+        double qv = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const double wlr = sh_w[row[j]], whr = sh_w[d + row[j]];
+            const double wl0 = sh_w[col[j]], wl1 = sh_w[col[j] + 1], wh0 = sh_w[d + col[j]], wh1 = sh_w[d + col[j] + 1];
+            qv += wlr * (lo[j].x * wl0 + lo[j].y * wl1) + whr * (hi[j].x * wh0 + hi[j].y * wh1) + 2.0 * whr * (cc[j].x * wl0 + cc[j].y * wl1);
+        }
+        double qm = (lane < d2) ? wl * sh_pm[lane] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            qm += __shfl_down(qm, off, 64);
+            qv += __shfl_down(qv, off, 64);
+        }
+        if (lane == 0) {
+            fmu[i] = qm;
+            fvar[i] = a.c[i] + qv;
+        }
+    }
+}
+
 // State prediction at arbitrary sorted query points (conditional_predict + base_conditional_predict, conditionals.py:29-76, 380-421;
 // posterior.py:207-229): p(x(t_i)) = N(P_i m_pair, T_i + P_i S_pair P_i^T) with the pair of conditioning states around t_i taken
 // straight from the marginal blocks (the prior pads both ends).  Pm [N, d, 2d], Tm [N, d, d], idx [N] = interval of query i;

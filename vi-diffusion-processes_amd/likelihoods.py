@@ -77,5 +77,10 @@ class Gaussian:
         return -0.5 * math.log(2 * math.pi) - 0.5 * math.log(v) - 0.5 * ((observations - f_means) ** 2 + f_vars) / v
 
     def ve_gradients_expectation(self, f_means, f_vars, observations):
+        # (y / v, -1/2 / v) depend on the observations only: computed once per observation tensor object and version
         v = self.variance
-        return observations / v, torch.full_like(f_vars, -0.5 / v)
+        c = getattr(self, "_g_cache", None)
+        if c is None or c[0]() is not observations or c[1] != observations._version or c[2] != tuple(f_vars.shape) or c[3] != v:
+            c = self._g_cache = (weakref.ref(observations), observations._version, tuple(f_vars.shape), v, observations / v,
+                                 torch.full_like(f_vars, -0.5 / v))
+        return c[4], c[5]

@@ -161,11 +161,21 @@ def _predict_f_fused(self):
     o = sv.o
     Fmu = torch.empty((ssm.B, ssm.T, o), dtype=torch.float64, device=pl.device)
     Fvar = torch.empty_like(Fmu)
-    pl.epoch += 1
-    _lib.check(pl.lib.mfgm_kf_sites_predict(pl.h, ctypes.byref(sv), _ptr(pr["diag"]), _ptr(pr["sub"]),
-                                            None if cache["zero_mean"] else _ptr(pr["lin"]), _ptr(b["D"]), _ptr(b["r"]), _ptr(b["L"]),
-                                            _ptr(b["y"]), _ptr(b["Sig"]), _ptr(b["x"]), _ptr(Fmu), _ptr(Fvar), _ptr(pl.ws),
-                                            _ptr(pl.info), _stream()), "mfgm_kf_sites_predict")
+    fo = cache.get("factor_of")
+    if (fo is not None and fo[0] is keep[0] and fo[1] == keep[0]._version and fo[2] is keep[1] and fo[3] == keep[1]._version
+            and fo[4] == pl.epoch):
+        # elbo() has just factorised exactly this system (same sites, zero-mean prior, nothing else ran on the plan since): the
+        # selected inverse and the projection are all that is left (variational_cvi.py:351-379 calls the two back to back)
+        _lib.check(pl.lib.mfgm_kf_sites_predict_factored(pl.h, ctypes.byref(sv), _ptr(pr["sub"]), _ptr(b["L"]), _ptr(b["y"]), _ptr(b["Sig"]),
+                                                         _ptr(b["x"]), _ptr(Fmu), _ptr(Fvar), _ptr(pl.ws), _stream()),
+                   "mfgm_kf_sites_predict_factored")
+    else:
+        pl.epoch += 1
+        _lib.check(pl.lib.mfgm_kf_sites_predict(pl.h, ctypes.byref(sv), _ptr(pr["diag"]), _ptr(pr["sub"]),
+                                                None if cache["zero_mean"] else _ptr(pr["lin"]), _ptr(b["D"]), _ptr(b["r"]), _ptr(b["L"]),
+                                                _ptr(b["y"]), _ptr(b["Sig"]), _ptr(b["x"]), _ptr(Fmu), _ptr(Fvar), _ptr(pl.ws),
+                                                _ptr(pl.info), _stream()), "mfgm_kf_sites_predict")
+        cache["factor_of"] = (keep[0], keep[0]._version, keep[1], keep[1]._version, pl.epoch) if cache["zero_mean"] else None
     shp = ssm.batch_shape + (ssm.T, o)
     return Fmu.reshape(shp), Fvar.reshape(shp)
 
@@ -193,12 +203,34 @@ class CVIGaussianProcess(GaussianProcessWithSitesBase):
         fx_mus, fx_covs = self.predict_f_at_data()
         _, grads = self.local_objective_and_gradients(fx_mus, fx_covs)
         lr = self.learning_rate
-        self.sites.nat1 = (1 - lr) * self.sites.nat1 + lr * grads[0]
-        self.sites.nat2 = (1 - lr) * self.sites.nat2 + lr * grads[1][..., None]
+        # (1 - lr) theta + lr g assigned to the site variables in place (tf.Variable.assign in the reference, :366-368), one launch each
+        self.sites.nat1.lerp_(grads[0], lr)
+        self.sites.nat2.lerp_(grads[1][..., None], lr)
 
     def elbo(self):
         """The marginal likelihood of the model whose likelihood terms are the Gaussian sites (variational_cvi.py:370-379)."""
         return self.log_likelihood()
+
+    def step_graph(self):
+        """`update_sites(); elbo()` -- the inner loop of CVI (variational_cvi.py:351-379) -- captured ONCE in a HIP graph: returns a
+        callable that replays it and hands back the ELBO (a device scalar that every replay overwrites).  On one chain the step is a
+        sequence of ~20 short dependent launches (level sweeps of a few microseconds each): replayed from a graph they cost no host time
+        at all.  The caches the step relies on (prior, scratch, the factorisation of the current sites) are warmed WITHOUT moving the
+        sites; afterwards eager calls and replays can be mixed freely."""
+        fx_mus, fx_covs = self.predict_f_at_data()
+        self.local_objective_and_gradients(fx_mus, fx_covs)
+        self.elbo()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.update_sites()
+            e = self.elbo()
+
+        def step():
+            graph.replay()
+            return e
+        step.graph = graph
+        return step
 
     def classic_elbo(self):
         """sum_i E_q log p(y_i | f_i) - KL[q(s) || p(s)] (variational_cvi.py:381-404)."""
