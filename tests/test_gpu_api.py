@@ -1476,12 +1476,15 @@ def test_tape_gradients_through_the_sweeps(amd, rng):
             idx = tuple(gen.integers(0, s) for s in p.shape)
             if k in (1, 4) and idx[-1] > idx[-2]:
                 continue              # strictly upper entries of the Cholesky factors are not parameters
-            h = 1e-5
-            up, dn = [x.clone() for x in prm], [x.clone() for x in prm]
-            up[k][idx] += h
-            dn[k][idx] -= h
-            fd = (value(up) - value(dn)) / (2 * h)
-            np.testing.assert_allclose(g[idx], fd, rtol=1e-6, atol=1e-6 * max(1.0, abs(fd)))
+            def cd(h):
+                up, dn = [x.clone() for x in prm], [x.clone() for x in prm]
+                up[k][idx] += h
+                dn[k][idx] -= h
+                return (value(up) - value(dn)) / (2 * h)
+            # fourth-order central difference; the backward pass is exact (congruence scans), so what is left is the rounding of the
+            # difference quotient itself (~ eps |f| / h)
+            fd = (4.0 * cd(5e-4) - cd(1e-3)) / 3.0
+            np.testing.assert_allclose(g[idx], fd, rtol=2e-9, atol=2e-9 * max(1.0, abs(fd)))
 
 
 def test_ssm_natgrad_tape_route(amd, rng):
@@ -1542,3 +1545,103 @@ def test_trainers_two_processes_share_the_batch():
            "--master-port", str(port), os.path.join(root, "tests", "mp_trainer_shard.py")]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+@pytest.mark.parametrize("B,T,d", [(2, 9, 3), (1, 130, 2), (3, 33, 6)])
+def test_exact_band_of_sigma_dP_sigma(amd, rng, B, T, d):
+    """The covariance half of the Fisher-vector product behind `tape.NaturalsToExpectations.backward` (ssm_natgrad.py:142-172 takes it
+    from a GradientTape through the banded ops): the band of Sigma dP Sigma from the band of Sigma alone (congruence scans), against the
+    dense product on a random SPD block-tri-diagonal precision -- including a badly scaled chain (blocks spanning six orders of
+    magnitude), where a finite difference of factorisations has no usable step."""
+    import torch
+    from vidp_amd import tape
+    for scale in (None, "bad"):
+        diag, sub = random_dominant_btd(rng, (B,), T, d)
+        if scale == "bad":
+            sc = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), size=(B, T, d)))
+            diag = sc[..., :, None] * diag * sc[..., None, :]
+            sub = sc[:, 1:, :, None] * sub * sc[:, :-1, None, :]
+        dPd = rng.normal(size=(B, T, d, d))
+        dPd = dPd + np.swapaxes(dPd, -1, -2)
+        dPs = rng.normal(size=(B, T - 1, d, d))
+        if scale == "bad":
+            dPd = sc[..., :, None] * dPd * sc[..., None, :]
+            dPs = sc[:, 1:, :, None] * dPs * sc[:, :-1, None, :]
+        covs, subs, Xd, Xs = [], [], [], []
+        for b in range(B):
+            P = np_btd.to_dense(diag[b], sub[b], symmetric=True)
+            dP = np_btd.to_dense(dPd[b], dPs[b], symmetric=True)
+            S = np.linalg.inv(P)
+            X = S @ dP @ S
+            blk = lambda M, i, j: M[i * d:(i + 1) * d, j * d:(j + 1) * d]
+            covs.append(np.stack([blk(S, t, t) for t in range(T)]))
+            subs.append(np.stack([blk(S, t + 1, t) for t in range(T - 1)]))
+            Xd.append(np.stack([blk(X, t, t) for t in range(T)]))
+            Xs.append(np.stack([blk(X, t + 1, t) for t in range(T - 1)]))
+        gd, gs = tape.band_of_sigma_dP_sigma(dev(np.stack(covs)), dev(np.stack(subs)), dev(dPd), dev(dPs))
+        assert_close(host(gd), np.stack(Xd), rtol=1e-8)
+        assert_close(host(gs), np.stack(Xs), rtol=1e-8)
+
+
+def test_tape_exact_backward_agrees_with_richardson(amd, rng):
+    """The exact backward of theta -> eta against the round-2 Richardson evaluation on a well-conditioned chain (where that one is
+    accurate): 1e-7 on every block, and the linear part -- which the difference quotient only reached to 1e-4 -- tighter than that."""
+    import torch
+    from vidp_amd import tape
+    B, T, d = 2, 40, 3
+    prm = [dev(a) for a in random_ssm_params(rng, (B,), T, d)]
+    w = [dev(rng.normal(size=s)) for s in ((B, T, d), (B, T, d, d), (B, T - 1, d, d))]
+
+    def grads(flag):
+        tape.NaturalsToExpectations.richardson = flag
+        try:
+            q = tape.TapeSSM(*[p.clone().requires_grad_(True) for p in prm])
+            e = q.expectations()
+            loss = sum((a * b).sum() for a, b in zip(e, w)) + (e[1] ** 2).sum()
+            return [host(g) for g in torch.autograd.grad(loss, q.parameters)]
+        finally:
+            tape.NaturalsToExpectations.richardson = False
+    for a, b in zip(grads(False), grads(True)):
+        assert_close(a, b, rtol=1e-6, scale_atol=1e-7)
+
+
+@pytest.mark.parametrize("kname", ["m12", "sum"])
+def test_cvi_classic_elbo_site_gradient_vanishes_at_optimum(amd, rng, kname):
+    """KA7's third clause (reference tests/integration/models/test_variational_cvi.py:93-110, kernel and likelihood frozen at :58-59):
+    after one site update with learning rate 1 and a Gaussian likelihood the gradient of classic_elbo with respect to the site
+    parameters is zero and a further update leaves the ELBO where it is; away from the optimum the same tape gradient matches central
+    differences of classic_elbo() evaluated through the ordinary (HIP, tape-free) path."""
+    import torch
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.variational_cvi import CVIGaussianProcess
+    mk = {"m12": (lambda m: m.Matern12(2.0, 2.25)), "sum": (lambda m: m.Sum([m.Matern32(1.1, 0.7), m.Matern12(0.5, 1.2)]))}[kname]
+    t = np.sort(rng.uniform(0, 4, size=8))
+    y = np.cos(3 * t)[:, None] + 0.1 * rng.normal(size=(8, 1))
+    g = CVIGaussianProcess((dev(t), dev(y)), mk(K), Gaussian(1.0), learning_rate=1.0)
+    g.update_sites()
+    optim = float(g.elbo())
+    g.update_sites()
+    np.testing.assert_allclose(float(g.elbo()), optim, atol=1e-9)
+    e, (n1, n2) = g.classic_elbo_tape()
+    np.testing.assert_allclose(float(e.detach()), float(g.classic_elbo()), rtol=1e-9)
+    g1, g2 = torch.autograd.grad(e, [n1, n2])
+    np.testing.assert_allclose(host(g1), 0.0, atol=2e-8)
+    np.testing.assert_allclose(host(g2), 0.0, atol=2e-8)
+    # away from the optimum: one damped step
+    h = CVIGaussianProcess((dev(t), dev(y)), mk(K), Gaussian(0.3), learning_rate=0.4)
+    h.update_sites()
+    e, (n1, n2) = h.classic_elbo_tape()
+    g1, g2 = (host(x) for x in torch.autograd.grad(e, [n1, n2]))
+    assert np.abs(g1).max() > 1e-2
+    base1, base2 = h.sites.nat1.clone(), h.sites.nat2.clone()
+    for which, idx, got in ((1, (3, 0), g1[3, 0]), (2, (5, 0, 0), g2[5, 0, 0]), (1, (0, 0), g1[0, 0])):
+        def val(eps):
+            h.sites.nat1, h.sites.nat2 = base1.clone(), base2.clone()
+            (h.sites.nat1 if which == 1 else h.sites.nat2)[idx] += eps
+            return float(h.classic_elbo())
+        step = 1e-4
+        fd = (8 * (val(step / 2) - val(-step / 2)) - (val(step) - val(-step))) / (6 * step)
+        # (the Matern-3/2 component loses digits to cancellation in Q = Pinf - A Pinf A^T, as in KA7 above: the difference quotient of the
+        #  ordinary path carries that noise divided by the step)
+        np.testing.assert_allclose(got, fd, rtol=1e-6 if kname == "m12" else 1e-4, atol=1e-8)

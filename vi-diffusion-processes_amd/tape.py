@@ -8,10 +8,16 @@ F = d^2 A / d theta^2, which is SYMMETRIC: the vector-Jacobian product autograd 
 
         (d eta / d theta)^T g  =  F g  =  d/d eps  eta(theta + eps g) |_{eps = 0} .
 
-`NaturalsToExpectations.backward` evaluates that derivative with the HIP sweeps themselves: the mean part exactly (one more solve
-with the same precision), the covariance part as a fourth-order (Richardson) central difference of factor + selected inverse (four
-passes, agreement with the closed-form gradients of the path at 1e-10) -- so no second set of adjoint kernels has to be kept in
-step with the forward ones.  Everything else on
+`NaturalsToExpectations.backward` evaluates that derivative EXACTLY (round 3; it was a Richardson difference of four extra
+factorisations): the mean part with one more solve with the same precision, the covariance part  d Sigma = -Sigma dP Sigma  restricted
+to the band from the Markov structure of Sigma.  With the forward gains A_t = Sigma_{t+1,t} Sigma_t^{-1} and the backward gains
+J_t = Sigma_{t,t+1} Sigma_{t+1}^{-1} every block of Sigma factors through its band (Sigma_{t+1,s} = A_t Sigma_{t,s} for s <= t,
+Sigma_{t,s} = J_t Sigma_{t+1,s} for s > t), so the sums over (a, b) in  X_tt = sum_ab Sigma_ta dP_ab Sigma_bt  split into a part
+with a, b <= t and a part with a, b >= t that obey CONGRUENCE recurrences
+        L_{t+1} = A_t L_t A_t^T + QL_{t+1},        R_t = J_t R_{t+1} J_t^T + QR_t
+(the moment recursion S <- T S T^T + Q of a linear chain, the form the VDP forward pass has: csrc/mfgm_vdp.h), evaluated here as
+associative scans over the maps X -> Phi X Phi^T + Q in O(log T) batched d x d products (`_congruence_scan`), plus local terms.
+No step size, no re-factorisation, nothing that can go indefinite on a badly scaled chain.  Everything else on
 the path (ssm -> naturals, expectations -> ssm, the KL and likelihood terms) is per-time-step d x d algebra, written here with
 autograd-traceable torch operations (explicit Cholesky / substitution loops over the d <= 8 block dimension: the vendor's batched
 factorisations are not used).
@@ -117,29 +123,73 @@ def _precision_times(plan, g_diag, g_sub, x):
     return out
 
 
+def _congruence_scan(Phi, Q, reverse=False):
+    """X_t of the recurrence  X_t = Phi_t X_{t-1} Phi_t^T + Q_t  (X_{-1} = 0; reverse: X_t = Phi_t X_{t+1} Phi_t^T + Q_t from the far
+    end) for Phi, Q [B, T, d, d]: an inclusive scan over the maps X -> Phi X Phi^T + Q, whose composition
+    (later after earlier) is (Phi_2 Phi_1, Phi_2 Q_1 Phi_2^T + Q_2) -- ceil(log2 T) rounds of three batched d x d products."""
+    if reverse:
+        return _congruence_scan(Phi.flip(1), Q.flip(1)).flip(1)
+    T = Phi.shape[1]
+    Phi, Q = Phi.clone(), Q.clone()
+    s = 1
+    while s < T:
+        P2, P1, Q1 = Phi[:, s:], Phi[:, :-s], Q[:, :-s]
+        Qn = P2 @ Q1 @ _T(P2) + Q[:, s:]
+        Pn = P2 @ P1
+        Phi = torch.cat([Phi[:, :s], Pn], dim=1)
+        Q = torch.cat([Q[:, :s], Qn], dim=1)
+        s *= 2
+    return Q
+
+
+def band_of_sigma_dP_sigma(cov, csub, dPd, dPs):
+    """Diagonal and sub-diagonal blocks of  X = Sigma dP Sigma  for the covariance Sigma of a Gauss-Markov chain given by its band
+    (cov [B,T,d,d] = Sigma_tt, csub [B,T-1,d,d] = Sigma_{t+1,t}) and a symmetric block-tri-diagonal dP (dPd [B,T,d,d] symmetric,
+    dPs [B,T-1,d,d] = dP_{t+1,t}).  Exact (module docstring); d x d solves through vidp_amd.linalg (HIP batched Cholesky / trsm)."""
+    from . import linalg
+    B, T, d, _ = cov.shape
+    loc = cov @ dPd @ cov                                               # Sigma_t dP_tt Sigma_t
+    if T == 1:
+        return loc, csub
+    chol = linalg.cholesky(cov)
+    A = _T(linalg.cholesky_solve(_T(csub), chol[:, :-1]))              # A_t = C_t Sigma_t^{-1}
+    J = _T(linalg.cholesky_solve(csub, chol[:, 1:]))                   # J_t = C_t^T Sigma_{t+1}^{-1}
+    hi, lo = cov[:, 1:], cov[:, :-1]
+    m1 = hi @ dPs @ _T(csub)                                            # Sigma_{t+1} dP_{t+1,t} Sigma_{t,t+1}
+    m2 = _T(csub) @ dPs @ lo                                            # Sigma_{t,t+1} dP_{t+1,t} Sigma_t
+    zero = torch.zeros_like(cov[:, :1])
+    QL = loc + torch.cat([zero, m1 + _T(m1)], dim=1)
+    QR = loc + torch.cat([m2 + _T(m2), zero], dim=1)
+    L = _congruence_scan(torch.cat([zero, A], dim=1), QL)               # pairs (a, b) <= t
+    R = _congruence_scan(torch.cat([J, zero], dim=1), QR, reverse=True)  # pairs (a, b) >= t
+    Xd = L + R - loc
+    Xs = A @ L[:, :-1] + R[:, 1:] @ _T(J) + csub @ _T(dPs) @ csub + hi @ dPs @ lo
+    return Xd, Xs
+
+
 class NaturalsToExpectations(torch.autograd.Function):
     """
     eta(theta) for theta = (theta_lin [B,T,d], theta_diag [B,T,d,d] symmetric, theta_sub [B,T-1,d,d]).  backward = the Fisher-vector
     product F g = D eta(theta)[g] (module docstring), assembled from
-      d mu     = P^{-1} (g_lin - dP mu)                       one more solve with the precision P, exact (dP = (-2 g_diag, -g_sub));
-      d Sigma  = derivative of the selected inverse along dP  fourth-order (Richardson) central difference of factor + selected
-                                                              inverse WITHOUT a right-hand side: the covariance blocks are far
-                                                              better conditioned than the solves, and the difference quotient
-                                                              of the means would amplify the rounding of the solves by 1 / step.
+      d mu     = P^{-1} (g_lin - dP mu)           one more solve with the precision P (dP = (-2 g_diag, -g_sub));
+      d Sigma  = -band(Sigma dP Sigma)            exact, from the band of Sigma (`band_of_sigma_dP_sigma`).
+    `richardson = True` selects the round-2 evaluation of d Sigma (fourth-order central difference of four extra factorisations), kept
+    as an independent cross-check.
     """
 
     rel_step = 3e-4
+    richardson = False
 
     @staticmethod
     def forward(ctx, lin, diag, sub, plan):
         ctx.plan = plan
         mu, cov, csub = _marginals(plan, lin.detach(), diag.detach(), sub.detach())
-        ctx.save_for_backward(lin, diag, sub, mu)
+        ctx.save_for_backward(lin, diag, sub, mu, cov, csub)
         return _eta(mu, cov, csub)
 
     @staticmethod
     def backward(ctx, g_lin, g_diag, g_sub):
-        lin, diag, sub, mu = ctx.saved_tensors
+        lin, diag, sub, mu, cov, csub = ctx.saved_tensors
         plan = ctx.plan
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g
         g_lin, g_diag, g_sub = z(g_lin, lin), z(g_diag, diag), z(g_sub, sub)
@@ -149,10 +199,13 @@ class NaturalsToExpectations(torch.autograd.Function):
             return torch.zeros_like(lin), torch.zeros_like(diag), torch.zeros_like(sub), None
         # d mu: one solve with the unperturbed precision
         dmu = _marginals(plan, g_lin - _precision_times(plan, g_diag, g_sub, mu), diag, sub)[0]
-        # d Sigma (diagonal and sub-diagonal blocks): Richardson central difference along (g_diag, g_sub)
+        # d Sigma (diagonal and sub-diagonal blocks) = -band(Sigma dP Sigma)
         dcov, dsub = torch.zeros_like(diag), torch.zeros_like(sub)
         gm = max(float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
-        if gm > 0.0:
+        if gm > 0.0 and not NaturalsToExpectations.richardson:
+            Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub)
+            dcov, dsub = -Xd, -Xs
+        elif gm > 0.0:
             h = NaturalsToExpectations.rel_step * float(diag.abs().max()) / gm
 
             def central(e):
@@ -165,6 +218,28 @@ class NaturalsToExpectations(torch.autograd.Function):
         d_diag = dcov + dmu[..., :, None] * mu[..., None, :] + mu[..., :, None] * dmu[..., None, :]
         d_sub = dsub + dmu[:, 1:, :, None] * mu[:, :-1, None, :] + mu[:, 1:, :, None] * dmu[:, :-1, None, :]
         return dmu, 0.5 * (d_diag + _T(d_diag)), d_sub, None
+
+
+class LogDetPrecision(torch.autograd.Function):
+    """log det P for P = (-2 theta_diag, -theta_sub) (twice the log-determinant of the block Cholesky factor, block_tri_diag.py:353-367),
+    differentiable:  d log det P = tr(Sigma dP)  gives  d/d theta_diag = -2 Sigma_tt,  d/d theta_sub = -2 Sigma_{t+1,t}  -- the band of the
+    selected inverse again."""
+
+    @staticmethod
+    def forward(ctx, diag, sub, plan):
+        ctx.plan = plan
+        ctx.save_for_backward(diag, sub)
+        T = plan.T
+        f = plan.factor(plan.pack(SYM, diag.detach()), plan.pack(FULL, sub.detach()) if T > 1 else plan.zeros(FULL), None, aD=-2.0, aS=-1.0,
+                        want_logdet=True)
+        plan.check_info()
+        return 2.0 * f["logdet"]
+
+    @staticmethod
+    def backward(ctx, g):
+        diag, sub = ctx.saved_tensors
+        _, cov, csub = _marginals(ctx.plan, None, diag, sub)
+        return -2.0 * g[:, None, None, None] * cov, -2.0 * g[:, None, None, None] * csub, None
 
 
 # ---- per-step maps, autograd-traceable ---------------------------------------------------------------------------------------------------
@@ -192,7 +267,69 @@ def expectations_to_ssm_params(eta_lin, eta_diag, eta_sub):
     return As, offsets, chols[:, 0], cholesky(0.5 * (cond + _T(cond))), m[:, 0, :, 0]
 
 
-class TapeSSM:
+class _TapeChain:
+    """What a differentiable Gauss-Markov chain offers once its natural parameters are nodes of a torch graph (`naturals()`) and its
+    log-determinant is differentiable (`log_det_precision()`): marginals, cross-covariances, KL -- StateSpaceModel's names."""
+
+    def expectations(self):
+        """ssm_to_expectations (ssm_gaussian_transformations.py:32-89), differentiable."""
+        if self._eta is None:
+            self._eta = NaturalsToExpectations.apply(*self.naturals(), self.plan)
+        return self._eta
+
+    @property
+    def marginal_means(self):
+        return self.expectations()[0]
+
+    @property
+    def marginal_covariances(self):
+        mu, ed, _ = self.expectations()
+        return ed - mu[..., :, None] * mu[..., None, :]
+
+    @property
+    def marginals(self):
+        return self.marginal_means, self.marginal_covariances
+
+    def subsequent_covariances(self, marginal_covariances=None):
+        mu, _, es = self.expectations()
+        return es - mu[:, 1:, :, None] * mu[:, :-1, None, :]
+
+    def kl_divergence(self, dist):
+        """KL(self || dist) for a (non-differentiated) StateSpaceModel `dist` (state_space_model.py:528-593)."""
+        pl = dist.plan
+        pp = dist._precision_packed()
+        Pd, Ps = pl.unpack(SYM, pp["diag"]), pl.unpack(FULL, pp["sub"], self.T - 1)
+        mup = pl.unpack(VEC, dist._posterior_packed()["s"]["x"])
+        mu, cov = self.marginals
+        sub = self.subsequent_covariances()
+        dm = mu - mup
+        tr = (Pd * cov).sum(dim=(-1, -2, -3)) + 2.0 * (Ps * sub).sum(dim=(-1, -2, -3))
+        mh = ((dm[..., None, :] @ Pd @ dm[..., :, None]).sum(dim=(-1, -2, -3))
+              + 2.0 * (dm[:, 1:, None, :] @ Ps @ dm[:, :-1, :, None]).sum(dim=(-1, -2, -3)))
+        dim = float(self.T * self.d)
+        return 0.5 * (tr + mh - dim + 2.0 * pp["sumlogchol"] + self.log_det_precision())
+
+
+class TapeNaturals(_TapeChain):
+    """A chain given by NATURAL parameters that are nodes of a torch graph -- e.g. the CVI posterior  prior naturals + back-projected
+    sites  (variational_cvi.py:106-135) with the sites as leaves: what the reference differentiates in
+    tests/integration/models/test_variational_cvi.py:104-107.  lin [B,T,d], diag [B,T,d,d] symmetric, sub [B,T-1,d,d]."""
+
+    def __init__(self, lin, diag, sub, plan):
+        self._nat = (lin, diag, sub)
+        self.B, self.T, self.d = lin.shape
+        self.batch_shape = (self.B,)
+        self.plan = plan
+        self._eta = None
+
+    def naturals(self):
+        return self._nat
+
+    def log_det_precision(self):
+        return LogDetPrecision.apply(self._nat[1], self._nat[2], self.plan)
+
+
+class TapeSSM(_TapeChain):
     """A StateSpaceModel whose parameters are torch leaves (requires_grad) and whose derived quantities are differentiable; batch
     shape [B].  Property / method names follow StateSpaceModel (state_space_model.py:35-664)."""
 
@@ -224,48 +361,10 @@ class TapeSSM:
     def naturals(self):
         return ssm_to_naturals(self.A, self.b, self.cholP0, self.cholQ, self.mu0)
 
-    def expectations(self):
-        """ssm_to_expectations (ssm_gaussian_transformations.py:32-89), differentiable."""
-        if self._eta is None:
-            self._eta = NaturalsToExpectations.apply(*self.naturals(), self.plan)
-        return self._eta
-
-    @property
-    def marginal_means(self):
-        return self.expectations()[0]
-
-    @property
-    def marginal_covariances(self):
-        mu, ed, _ = self.expectations()
-        return ed - mu[..., :, None] * mu[..., None, :]
-
-    @property
-    def marginals(self):
-        return self.marginal_means, self.marginal_covariances
-
-    def subsequent_covariances(self, marginal_covariances=None):
-        mu, _, es = self.expectations()
-        return es - mu[:, 1:, :, None] * mu[:, :-1, None, :]
-
     def log_det_precision(self):
         """-2 (log|chol P0| + sum log|chol Q_k|) (state_space_model.py:343-373)."""
         ld = lambda c: torch.log(torch.abs(torch.diagonal(c, dim1=-2, dim2=-1))).sum(-1)
         return -2.0 * (ld(self.cholP0) + ld(self.cholQ).sum(-1))
-
-    def kl_divergence(self, dist):
-        """KL(self || dist) for a (non-differentiated) StateSpaceModel `dist` (state_space_model.py:528-593)."""
-        pl = dist.plan
-        pp = dist._precision_packed()
-        Pd, Ps = pl.unpack(SYM, pp["diag"]), pl.unpack(FULL, pp["sub"], self.T - 1)
-        mup = pl.unpack(VEC, dist._posterior_packed()["s"]["x"])
-        mu, cov = self.marginals
-        sub = self.subsequent_covariances()
-        dm = mu - mup
-        tr = (Pd * cov).sum(dim=(-1, -2, -3)) + 2.0 * (Ps * sub).sum(dim=(-1, -2, -3))
-        mh = ((dm[..., None, :] @ Pd @ dm[..., :, None]).sum(dim=(-1, -2, -3))
-              + 2.0 * (dm[:, 1:, None, :] @ Ps @ dm[:, :-1, :, None]).sum(dim=(-1, -2, -3)))
-        dim = float(self.T * self.d)
-        return 0.5 * (tr + mh - dim + 2.0 * pp["sumlogchol"] + self.log_det_precision())
 
 
 def natgrad_wrt_expectations(loss_fn, ssm):

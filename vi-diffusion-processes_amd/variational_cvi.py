@@ -7,7 +7,7 @@ sites, refreshed by the HIP sweeps.
 """
 import torch
 
-from ._lib import SYM, VEC
+from ._lib import FULL, SYM, VEC
 from .kalman_filter import GaussianSitesNat, KalmanFilter, KalmanFilterWithSites
 from .ssm_gaussian_transformations import naturals_to_ssm_params_packed
 
@@ -210,6 +210,34 @@ class CVIGaussianProcess(GaussianProcessWithSitesBase):
     def elbo(self):
         """The marginal likelihood of the model whose likelihood terms are the Gaussian sites (variational_cvi.py:370-379)."""
         return self.log_likelihood()
+
+    def classic_elbo_tape(self, nat1=None, nat2=None):
+        """classic_elbo as a differentiable function of the site parameters (leaves of a torch graph; default: detached copies of the
+        model's sites with requires_grad) -- the gradient the reference takes with a GradientTape over `trainable_variables` in
+        tests/integration/models/test_variational_cvi.py:104-110 (kernel and likelihood frozen there).  Returns (elbo, (nat1, nat2)).
+        One chain per batch entry; the posterior naturals  prior + back-projected sites  go through vidp_amd.tape."""
+        from . import tape
+        ssm = self.dist_p
+        pl, B, T, d = ssm.plan, ssm.B, ssm.T, ssm.d
+        if pl.d != d or d > 8:
+            raise NotImplementedError("the tape route runs on the lane-per-segment plans (state dimension <= 8)")
+        n1 = (self.sites.nat1.detach().clone() if nat1 is None else nat1).requires_grad_(True)
+        n2 = (self.sites.nat2.detach().clone() if nat2 is None else nat2).requires_grad_(True)
+        pk = ssm.packed
+        nat = pl.ssm_to_naturals(pk.A, pk.off, pk.chol, precision=False)
+        plin, pdiag = pl.unpack(VEC, nat["lin"]), pl.unpack(SYM, nat["diag"])
+        psub = pl.unpack(FULL, nat["sub"], T - 1)
+        H = self._emission().emission_matrix
+        bp1, bp2 = back_project_nats(n1, n2[..., 0], H)
+        q = tape.TapeNaturals(plin + bp1.expand(ssm.batch_shape + (T, d)).reshape(B, T, d),
+                              pdiag + bp2.expand(ssm.batch_shape + (T, d, d)).reshape(B, T, d, d), psub, pl)
+        mu, cov = q.marginals
+        Hb = H.expand(ssm.batch_shape + tuple(H.shape[-3:])).reshape(B, T, H.shape[-2], d)
+        fmu = (Hb @ mu[..., None])[..., 0]
+        fvar = torch.diagonal(Hb @ cov @ Hb.transpose(-1, -2), dim1=-2, dim2=-1)
+        obs = self._observations.expand(ssm.batch_shape + tuple(self._observations.shape[-2:])).reshape(B, T, -1)
+        ve = self._likelihood.variational_expectations(fmu, fvar, obs).sum()
+        return ve - q.kl_divergence(ssm).sum(), (n1, n2)
 
     def step_graph(self):
         """`update_sites(); elbo()` -- the inner loop of CVI (variational_cvi.py:351-379) -- captured ONCE in a HIP graph: returns a
