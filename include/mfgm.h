@@ -534,6 +534,15 @@ int mfgm_plan_set_shard(mfgm_plan* plan, int seg_lo, int seg_hi);
  * and phase 1 solves the levels >= level on every process and sweeps back down its own segments.  No other data cross processes
  * (the forward sweep stores the factor blocks of the separator on the left of the range, which it reconstructs anyway). */
 int mfgm_plan_set_shard_level(mfgm_plan* plan, int level, int node_lo, int node_hi);
+/* Not positive definite: the factorisation kernels leave in the caller's `info` word (zeroed by the caller) the FIRST failing location --
+ * lowest level, then lowest (chain, segment) -- instead of a bare flag.  mfgm_plan_decode_info turns a copy of the word into
+ * out4 = (chain b, first node k_lo, one past the last node k_hi, level): the pivot block that failed belongs to a node in [k_lo, k_hi) of
+ * chain b (level > 0: a separator system that stands for those nodes).  Returns 0 when the word is 0 (out4 = -1), 2 when a failure was
+ * reported (out4 = -1 if the reporting kernel had no location to give), as TF's Cholesky op fails the step in the reference
+ * (block_tri_diag.py:428-440).  mfgm_plan_check_info copies the word from the device (synchronises `stream`) and decodes it. */
+int mfgm_plan_decode_info(const mfgm_plan* plan, int info_value, int* out4);
+int mfgm_plan_check_info(const mfgm_plan* plan, const int* info, int* out4, void* stream);
+
 /* out[0..3] = n, R, P, Lpad of a level */
 int mfgm_plan_level(const mfgm_plan* plan, int level, int* out4);
 int mfgm_plan_exchange_region(const mfgm_plan* plan, size_t* offset_doubles, size_t* count_doubles);

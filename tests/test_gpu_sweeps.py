@@ -269,3 +269,30 @@ def test_random_partitions(amd):
                     assert_close(plan.unpack(amd.FULL, s["Sub"], T - 1).cpu().numpy(), Ss)
         except AssertionError as e:
             raise AssertionError(ctx + "\n" + str(e)) from None
+
+
+@pytest.mark.parametrize("d,moments_only", [(3, False), (6, False), (16, False), (16, True)])
+def test_not_pd_report_names_the_first_failing_chain_and_nodes(amd, rng, d, moments_only):
+    """SURVEY 8b's error contract: a pivot block that is not positive definite is reported with its location -- status 2 from
+    mfgm_plan_check_info and (chain, node range) of the FIRST failure, not a bare flag (TF's Cholesky op fails the step in the reference,
+    block_tri_diag.py:428-440).  One indefinite diagonal block is planted in chain 1 (and a later one in chain 2)."""
+    import ctypes
+    B, T = 3, 203
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    diag[1, 77] = -np.eye(d)
+    diag[2, 150] = -np.eye(d)
+    plan = amd.Plan(B, T, d, R0=8)
+    plan.factor(plan.pack(amd.SYM, _dev(diag)), plan.pack(amd.FULL, _dev(sub)), moments_only=moments_only)
+    out = (ctypes.c_int * 4)()
+    from vidp_amd.packed import _ptr, _stream
+    assert plan.lib.mfgm_plan_check_info(plan.h, _ptr(plan.info), out, _stream()) == 2
+    b, lo, hi, level = tuple(out)
+    assert b == 1 and lo <= 77 < hi and hi - lo <= 8 and level == 0
+    with pytest.raises(ArithmeticError, match=r"chain 1, a node in \[72, 80\)") as ei:
+        plan.check_info()
+    assert ei.value.location[:3] == (1, 72, 80)
+    # the word is cleared: a clean factorisation on the same plan passes, status 0
+    diag2, sub2 = random_dominant_btd(rng, (B,), T, d)
+    plan.factor(plan.pack(amd.SYM, _dev(diag2)), plan.pack(amd.FULL, _dev(sub2)), moments_only=moments_only)
+    assert plan.lib.mfgm_plan_check_info(plan.h, _ptr(plan.info), out, _stream()) == 0
+    plan.check_info()

@@ -10,7 +10,8 @@ using namespace mfgm;
 
 namespace {
 
-void fill_level(LevelDesc& lv, int B, int n, int R) {
+void fill_level(LevelDesc& lv, int B, int n, int R, int level) {
+    lv.level = level;
     lv.n = n;
     lv.R = R;
     lv.P = ceil_div(n, R);
@@ -56,11 +57,11 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
         if (R < 2) R = 2;
         const bool single = (n <= R) || (l > 0 && n <= top) || (l == kMaxLevels - 1);
         if (single) {
-            fill_level(P.lv[l], B, n, n);  // one segment per chain: plain sequential sweep
+            fill_level(P.lv[l], B, n, n, l);  // one segment per chain: plain sequential sweep
             ++l;
             break;
         }
-        fill_level(P.lv[l], B, n, R);
+        fill_level(P.lv[l], B, n, R, l);
         n = P.lv[l].P;
         ++l;
     }
@@ -128,6 +129,31 @@ int mfgm_plan_exchange_region(const mfgm_plan* plan, size_t* offset_doubles, siz
     *offset_doubles = P.off_Dhat[l];
     *count_doubles = P.off_L[l] - P.off_Dhat[l];
     return 0;
+}
+
+int mfgm_plan_decode_info(const mfgm_plan* plan, int info_value, int* out4) {
+    if (!plan || !out4) return 1;
+    out4[0] = out4[1] = out4[2] = out4[3] = -1;
+    if (info_value == 0) return 0;
+    const Plan& P = plan->p;
+    const int code = 0x7fffffff - info_value;              // flag_not_pd (mfgm_math.h): 1 + lane + (level << 27), smallest wins
+    const int level = code >> 27, lane = (code & ((1 << 27) - 1)) - 1;
+    if (info_value < (1 << 20) || level < 0 || level >= P.nlevels || lane < 0 || lane >= P.lv[level].L) return 2;   // flagged without a location
+    const LevelDesc& lv = P.lv[level];
+    const int b = lane / lv.P, p = lane - b * lv.P;
+    long long span = 1;                                     // level-0 nodes one node of this level stands for
+    for (int l = 0; l < level; ++l) span *= P.lv[l].R;
+    const long long lo = (long long)p * lv.R * span, hi = std::min<long long>((long long)(p + 1) * lv.R * span, P.T);
+    out4[0] = b; out4[1] = (int)lo; out4[2] = (int)hi; out4[3] = level;
+    return 2;
+}
+
+int mfgm_plan_check_info(const mfgm_plan* plan, const int* info, int* out4, void* stream) {
+    if (!plan || !info || !out4) return 1;
+    int v = 0;
+    if (hipMemcpyAsync(&v, info, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 3;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 3;
+    return mfgm_plan_decode_info(plan, v, out4);
 }
 
 int mfgm_plan_level(const mfgm_plan* plan, int level, int* out4) {

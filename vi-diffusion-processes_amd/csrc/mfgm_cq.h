@@ -221,7 +221,7 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
         st_node<ET, true>(a.uRsub, uR, us, LaneRef::of(ul), Racc);
         st_node<D, true>(a.urho, uR, us, LaneRef::of(ul), rho);
     }
-    if (bad) atomicMax(a.info, 1);
+    if (bad) flag_not_pd(a.info, a.lv.level, lane);
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------------------
@@ -357,7 +357,7 @@ static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q)
         a.part[lane] = la.value();
         a.part[Lp + lane] = quad;
     }
-    if (bad) atomicMax(a.info, 1);
+    if (bad) flag_not_pd(a.info, a.lv.level, lane);
 }
 
 // ---- backward helpers ------------------------------------------------------------------------------------------------------------

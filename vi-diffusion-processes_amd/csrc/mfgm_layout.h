@@ -25,6 +25,7 @@ struct LevelDesc {
     int P;      // segments per chain
     int L;      // lanes = B * P
     int Lpad;   // lanes padded to a multiple of 64
+    int level;  // index of this level in its plan (0 = finest): part of the location a not-positive-definite report carries
 };
 
 constexpr int kMaxLevels = 8;

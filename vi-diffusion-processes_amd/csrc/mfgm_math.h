@@ -13,6 +13,11 @@
 
 namespace mfgm {
 
+// Not-positive-definite report.  `info` keeps the FIRST failing location -- the smallest code = 1 + lane + (level << 27), lane = chain *
+// segments + segment at that level -- stored as INT_MAX - code so that one atomicMax does it.  0: no failure; 1: flagged by a kernel
+// that has no location to give.  mfgm_plan_decode_info turns the word into (chain, node range).
+MFGM_DEV void flag_not_pd(int* info, int level, int lane) { atomicMax(info, 0x7fffffff - (1 + lane + (level << 27))); }
+
 MFGM_DEV constexpr int tix(int i, int j) { return i * (i + 1) / 2 + j; }          // j <= i
 MFGM_DEV constexpr int six(int i, int j) { return i >= j ? tix(i, j) : tix(j, i); }  // symmetric access
 

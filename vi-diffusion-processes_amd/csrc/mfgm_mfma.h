@@ -395,7 +395,7 @@ static __global__ __launch_bounds__(64) void km_reduce(WideArgs a) {
         st_mat<NT, false>(wblk(a.uRsub, b, un, p - 1, EF), d, L, Racc);
         st_vec<NT>(wblk(a.urho, b, un, p - 1, d), d, L, rho);
     }
-    if (bad && L.lane == 0) atomicMax(a.info, 1);
+    if (bad && L.lane == 0) flag_not_pd(a.info, a.lv.level, b * a.lv.P + p);
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------------------------
@@ -473,7 +473,7 @@ static __global__ __launch_bounds__(64) void km_forward(WideArgs a) {
         a.part[b * P + p] = -la.value();
         a.part[a.lv.Lpad + b * P + p] = quad;
     }
-    if (bad && L.lane == 0) atomicMax(a.info, 1);
+    if (bad && L.lane == 0) flag_not_pd(a.info, a.lv.level, b * a.lv.P + p);
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------------------------
@@ -531,7 +531,7 @@ static __global__ __launch_bounds__(64) void km_backward(WideArgs a) {
     };
     for (int s = len - 2; s >= 0; --s) step(t0 + s, true);
     if (WANT_SUB && p > 0) step(t0 - 1, false);
-    if (bad && L.lane == 0) atomicMax(a.info, 1);
+    if (bad && L.lane == 0) flag_not_pd(a.info, a.lv.level, b * a.lv.P + p);
 }
 
 // ---- SSM parameters -> naturals / precision blocks, one wavefront per node (same outputs as k_ssm_to_naturals) ------------------------

@@ -489,7 +489,7 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
         st_mat<NT, false>(wblk(a.uRsub, b, un, p - 1, EF), d, L, Racc);
         st_col<NT>(wblk(a.urho, b, un, p - 1, d), d, L, rho);
     }
-    if (bad && L.lane == 0) atomicMax(a.info, 1);
+    if (bad && L.lane == 0) flag_not_pd(a.info, a.lv.level, b * a.lv.P + p);
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------------------------
@@ -576,7 +576,7 @@ static __global__ __launch_bounds__(64) void kmi_forward(WideArgs a) {
             a.part[a.lv.Lpad + b * P + p] = quad;
         }
     }
-    if (bad && L.lane == 0) atomicMax(a.info, 1);
+    if (bad && L.lane == 0) flag_not_pd(a.info, a.lv.level, b * a.lv.P + p);
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------------------------

@@ -239,7 +239,7 @@ MFGM_DEV void reduce_body(const SweepArgs& a, const int lane, const LaneRef me) 
         st_node<ET, true>(a.uRsub, uR, us, LaneRef::of(ul), Racc);
         st_node<D, true>(a.urho, uR, us, LaneRef::of(ul), rho);
     }
-    if (bad) atomicMax(a.info, 1);
+    if (bad) flag_not_pd(a.info, a.lv.level, lane);
 }
 template <int D, bool HAS_RHS, bool HAS_CORR>
 static __global__ __launch_bounds__(64) void k_reduce(SweepArgs a) {
@@ -361,7 +361,7 @@ MFGM_DEV void forward_body(const SweepArgs& a, const int lane, const LaneRef me)
         a.part[lane] = la.value();
         a.part[Lp + lane] = quad;
     }
-    if (bad) atomicMax(a.info, 1);
+    if (bad) flag_not_pd(a.info, a.lv.level, lane);
 }
 template <int D, bool HAS_RHS, bool HAS_CORR, bool HAS_UP>
 static __global__ __launch_bounds__(64) void k_forward(SweepArgs a) {

@@ -245,7 +245,7 @@ static __global__ __launch_bounds__(64) void kw_reduce(WideArgs a) {
         st_row<DM>(wblk(a.uRsub, b, un, p - 1, EF), d, lane, Racc);
         if (lane < d) wblk(a.urho, b, un, p - 1, d)[lane] = rho;
     }
-    if (bad && lane == 0) atomicMax(a.info, 1);
+    if (bad && lane == 0) flag_not_pd(a.info, a.lv.level, b * a.lv.P + p);
 }
 
 // ---- forward --------------------------------------------------------------------------------------------------------
@@ -338,7 +338,7 @@ static __global__ __launch_bounds__(64) void kw_forward(WideArgs a) {
         a.part[b * P + p] = logacc;
         a.part[a.lv.Lpad + b * P + p] = quad;
     }
-    if (bad && lane == 0) atomicMax(a.info, 1);
+    if (bad && lane == 0) flag_not_pd(a.info, a.lv.level, b * a.lv.P + p);
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------

@@ -373,10 +373,18 @@ class Plan:
         return ve.sum(-1)
 
     def check_info(self):
-        """Raise ArithmeticError if a pivot block was not positive definite (synchronises)."""
-        if int(self.info.item()) != 0:
+        """Raise ArithmeticError if a pivot block was not positive definite (synchronises); the message names the first failing chain and
+        node range (mfgm_plan_check_info: status 2 with the location the kernels left in the info word)."""
+        out = (ctypes.c_int * 4)()
+        rc = self.lib.mfgm_plan_check_info(self.h, _ptr(self.info), out, _stream())
+        if rc == 2:
             self.info.zero_()
-            raise ArithmeticError("block-tri-diagonal matrix is not positive definite")
+            where = (f": chain {out[0]}, a node in [{out[1]}, {out[2]})" + (f" (separator system of level {out[3]})" if out[3] > 0 else "")
+                     if out[0] >= 0 else "")
+            err = ArithmeticError("block-tri-diagonal matrix is not positive definite" + where)
+            err.location = tuple(out) if out[0] >= 0 else None
+            raise err
+        _lib.check(rc, "mfgm_plan_check_info")
 
 
 class CqState:
