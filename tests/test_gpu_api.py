@@ -758,6 +758,22 @@ def test_prior_parameter_gradients_and_learning(amd, rng):
             return -float(mm.variational_expectation().sum())
         h = 1e-4
         np.testing.assert_allclose(gve, [(neg_ve(0.7 + h) - neg_ve(0.7 - h)) / (2 * h)], rtol=1e-5)
+    # the exact chain rule (one Fisher-vector product for all parameters) against the round-2 evaluation (two re-linearised posterior
+    # refreshes per parameter): double-well prior with both parameters trainable, d = 2, two trajectories, stabilised (clipped) prior
+    d2 = 2
+    y2 = np.sign(rng.normal(size=(2, len(idx), d2))) + 0.1 * rng.normal(size=(2, len(idx), d2))
+
+    def dw_model():
+        sd = gsde.DoubleWellSDE(q=torch.eye(d2, dtype=torch.float64), scale_trainable=True, c_trainable=True, scale=3.0, c=0.8)
+        mm = CVISitesSDE(sd, grid, (grid[idx], dev(y2)), MultivariateGaussian(dev(0.3 * np.eye(d2))), prior_initial_state=(np.zeros(d2), np.eye(d2)))
+        for _ in range(3):
+            mm.update_data_sites(0.5)
+            mm.update_girsanov_sites(0.2)
+        return mm
+    exact = dw_model().grad_VE_wrt_prior_params()
+    fd = dw_model().grad_VE_wrt_prior_params(finite_difference=True)
+    assert len(exact) == 2 and max(abs(v) for v in exact) > 1e-3
+    np.testing.assert_allclose(exact, fd, rtol=2e-5, atol=1e-8)
 
     # learning loop: data from an OU process with decay 2, prior initialised at decay 0.3
     Tl, decay_true = 400, 2.0

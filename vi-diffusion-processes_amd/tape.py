@@ -190,34 +190,40 @@ class NaturalsToExpectations(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lin, g_diag, g_sub):
         lin, diag, sub, mu, cov, csub = ctx.saved_tensors
-        plan = ctx.plan
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g
-        g_lin, g_diag, g_sub = z(g_lin, lin), z(g_diag, diag), z(g_sub, sub)
-        g_diag = 0.5 * (g_diag + _T(g_diag))        # eta_diag is symmetric: only the symmetric part of its cotangent acts
-        gmax = max(float(g_lin.abs().max()), float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
-        if gmax == 0.0:
-            return torch.zeros_like(lin), torch.zeros_like(diag), torch.zeros_like(sub), None
-        # d mu: one solve with the unperturbed precision
-        dmu = _marginals(plan, g_lin - _precision_times(plan, g_diag, g_sub, mu), diag, sub)[0]
-        # d Sigma (diagonal and sub-diagonal blocks) = -band(Sigma dP Sigma)
-        dcov, dsub = torch.zeros_like(diag), torch.zeros_like(sub)
-        gm = max(float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
-        if gm > 0.0 and not NaturalsToExpectations.richardson:
-            Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub)
-            dcov, dsub = -Xd, -Xs
-        elif gm > 0.0:
-            h = NaturalsToExpectations.rel_step * float(diag.abs().max()) / gm
+        return (*fisher_vector_product(ctx.plan, diag, sub, mu, cov, csub, z(g_lin, lin), z(g_diag, diag), z(g_sub, sub)), None)
 
-            def central(e):
-                up = _marginals(plan, None, diag + e * g_diag, sub + e * g_sub)
-                dn = _marginals(plan, None, diag - e * g_diag, sub - e * g_sub)
-                return (up[1] - dn[1]) / (2.0 * e), (up[2] - dn[2]) / (2.0 * e)
 
-            (c1, s1), (c2, s2) = central(h), central(0.5 * h)
-            dcov, dsub = (4.0 * c2 - c1) / 3.0, (4.0 * s2 - s1) / 3.0
-        d_diag = dcov + dmu[..., :, None] * mu[..., None, :] + mu[..., :, None] * dmu[..., None, :]
-        d_sub = dsub + dmu[:, 1:, :, None] * mu[:, :-1, None, :] + mu[:, 1:, :, None] * dmu[:, :-1, None, :]
-        return dmu, 0.5 * (d_diag + _T(d_diag)), d_sub, None
+def fisher_vector_product(plan, diag, sub, mu, cov, csub, g_lin, g_diag, g_sub):
+    """F g = D eta(theta)[g] for the chain with naturals (., diag, sub), marginals (mu, cov = Sigma_tt, csub = Sigma_{t+1,t}), all in
+    natural layout [B, T, ...]: the directional derivative of (mu, Sigma_tt + mu mu^T, Sigma_{t+1,t} + mu_{t+1} mu_t^T) along
+    g = (g_lin, g_diag, g_sub), which is also the vector-Jacobian product (F is symmetric).  Used by the tape and by
+    CVISitesSDE.grad_VE_wrt_prior_params (variational_cvi_sde.py:508-518)."""
+    g_diag = 0.5 * (g_diag + _T(g_diag))        # eta_diag is symmetric: only the symmetric part of its cotangent acts
+    gmax = max(float(g_lin.abs().max()), float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
+    if gmax == 0.0:
+        return torch.zeros_like(g_lin), torch.zeros_like(g_diag), torch.zeros_like(g_sub)
+    # d mu: one solve with the unperturbed precision
+    dmu = _marginals(plan, g_lin - _precision_times(plan, g_diag, g_sub, mu), diag, sub)[0]
+    # d Sigma (diagonal and sub-diagonal blocks) = -band(Sigma dP Sigma)
+    dcov, dsub = torch.zeros_like(g_diag), torch.zeros_like(g_sub)
+    gm = max(float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
+    if gm > 0.0 and not NaturalsToExpectations.richardson:
+        Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub)
+        dcov, dsub = -Xd, -Xs
+    elif gm > 0.0:
+        h = NaturalsToExpectations.rel_step * float(diag.abs().max()) / gm
+
+        def central(e):
+            up = _marginals(plan, None, diag + e * g_diag, sub + e * g_sub)
+            dn = _marginals(plan, None, diag - e * g_diag, sub - e * g_sub)
+            return (up[1] - dn[1]) / (2.0 * e), (up[2] - dn[2]) / (2.0 * e)
+
+        (c1, s1), (c2, s2) = central(h), central(0.5 * h)
+        dcov, dsub = (4.0 * c2 - c1) / 3.0, (4.0 * s2 - s1) / 3.0
+    d_diag = dcov + dmu[..., :, None] * mu[..., None, :] + mu[..., :, None] * dmu[..., None, :]
+    d_sub = dsub + dmu[:, 1:, :, None] * mu[:, :-1, None, :] + mu[:, 1:, :, None] * dmu[:, :-1, None, :]
+    return dmu, 0.5 * (d_diag + _T(d_diag)), d_sub
 
 
 class LogDetPrecision(torch.autograd.Function):

@@ -653,35 +653,80 @@ class CVISitesSDE(CVISitesSSM):
         jac = self.prior_sde.cubic_jacobian(self.dt)
         return [dal * jac[n][0] + dbe * jac[n][1] for n in self.prior_sde.trainable_variables]
 
-    def grad_VE_wrt_prior_params(self, rel_step=1e-6):
+    def _prior_naturals_on(self, path):
+        """Naturals (lin [B,T,d], diag [B,T,d,d], sub [B,T-1,d,d], natural layout) of the prior linearised on the packed path (mu, Sigma)
+        with the CURRENT drift parameters -- the (stabilised) prior `set_linearized_prior` installs; the model's state is not touched."""
+        pl = self.plan
+        prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1],
+                                    clip=self.clip_state_transitions if self.stabilize_ssm else None)
+        A, off, chol = pl.linearize_cubic(prm, path[0], path[1])
+        nat = pl.ssm_to_naturals(A, off, chol)
+        return pl.unpack(VEC, nat["lin"]), pl.unpack(SYM, nat["diag"]), pl.unpack(FULL, nat["sub"], self.T - 1)
+
+    def grad_VE_wrt_prior_params(self, rel_step=1e-6, finite_difference=False):
         """
-        d(-E_q log p(Y | X)) / d (trainable drift parameters) with q = linearised prior + sites (variational_cvi_sde.py:508-518).
-        The reference differentiates through set_linearized_prior and dist_q with a tape; here each parameter gets a central
-        difference of two re-linearised posterior refreshes on the same path.  Like the reference's, the call leaves the prior
-        re-linearised at the current posterior.
+        d(-E_q log p(Y | X)) / d (trainable drift parameters) with q = linearised prior + sites (variational_cvi_sde.py:508-518: the
+        reference re-linearises the prior on the current posterior inside a GradientTape and differentiates -VE of the resulting q).
+        Exact chain rule, no re-factorisation per parameter (round 3):
+            theta_q(kappa) = theta_p(kappa; path) + sites        (sites fixed, path = the current posterior marginals, fixed),
+            d(-VE) / d kappa = -< d VE / d eta , F_q d theta_p / d kappa > = -< F_q g , d theta_p / d kappa >,
+        with g = d VE / d eta the likelihood's site gradient at the observation nodes, F_q the Fisher matrix of the re-linearised q
+        (symmetric: ONE Fisher-vector product, tape.fisher_vector_product, serves every parameter) and d theta_p / d kappa the derivative
+        of the LOCAL linearisation map on the fixed path -- a polynomial of degree two in the Euler-map coefficients, for which the
+        central difference used here is exact up to rounding.  `finite_difference=True` is the round-2 evaluation (two re-linearised
+        posterior refreshes per parameter), kept as a cross-check.  Like the reference's, the call leaves the prior re-linearised at
+        the current posterior.
         """
-        sde = self.prior_sde
+        from . import tape
+        sde, pl = self.prior_sde, self.plan
         q = self._refresh(want_marginals=True)
         path = (q["mu"].clone(), q["Sig"].clone())
 
-        def neg_ve():
+        def relinearize_on_path():
             self._path, self._q = path, None
             self._refresh_sde_params()
             self.set_linearized_prior()
             self._path, self._q = path, None
-            return -float(self.variational_expectation().sum())
 
+        if finite_difference:
+            def neg_ve():
+                relinearize_on_path()
+                return -float(self.variational_expectation().sum())
+            grads = []
+            for n in sde.trainable_variables:
+                v0 = sde.get(n)
+                h = rel_step * max(abs(v0), 1.0)
+                sde.assign(n, v0 + h)
+                up = neg_ve()
+                sde.assign(n, v0 - h)
+                dn = neg_ve()
+                sde.assign(n, v0)
+                grads.append((up - dn) / (2.0 * h))
+            neg_ve()
+            return grads
+        # the q the reference differentiates: prior re-linearised on the path at the current parameters, plus the sites
+        relinearize_on_path()
+        T, d, B = self.T, self.state_dim, self.B
+        qn = self._refresh(want_sub=True, want_marginals=True)
+        mu, cov, csub = pl.unpack(VEC, qn["mu"]), pl.unpack(SYM, qn["Sig"]), pl.unpack(FULL, qn["Sub"], T - 1)
+        tq = self.full_sites()
+        diag, sub = pl.unpack(SYM, tq.diag), pl.unpack(FULL, tq.sub, T - 1)
+        mu_o, cov_o = self._obs_marginals()
+        g1, g2 = self.likelihood.ve_gradients_expectation(mu_o, cov_o, self._obs_flat())
+        g_lin = torch.zeros((B * T, d), dtype=torch.float64, device=self.device).index_add_(0, self.obs_node_ids, g1.reshape(-1, d))
+        g_diag = torch.zeros((B * T, d, d), dtype=torch.float64, device=self.device).index_add_(0, self.obs_node_ids, g2.reshape(-1, d, d))
+        u = tape.fisher_vector_product(pl, diag, sub, mu, cov, csub, g_lin.view(B, T, d), g_diag.view(B, T, d, d), torch.zeros_like(sub))
         grads = []
         for n in sde.trainable_variables:
             v0 = sde.get(n)
-            h = rel_step * max(abs(v0), 1.0)
+            h = 1e-3 * max(abs(v0), 1.0)          # exact for the quadratic dependence of theta_p on the Euler-map coefficients
             sde.assign(n, v0 + h)
-            up = neg_ve()
+            up = self._prior_naturals_on(path)
             sde.assign(n, v0 - h)
-            dn = neg_ve()
+            dn = self._prior_naturals_on(path)
             sde.assign(n, v0)
-            grads.append((up - dn) / (2.0 * h))
-        neg_ve()
+            grads.append(-float(sum(((a - b) * w).sum() for a, b, w in zip(up, dn, u))) / (2.0 * h))
+        self._path, self._q = path, None
         return grads
 
     def update_girsanov_sites(self, lr: float):
