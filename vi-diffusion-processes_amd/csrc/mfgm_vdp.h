@@ -29,6 +29,9 @@ MFGM_DEV double vdp_bcast(double x, int src) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// value of x in lane (own - o) of the wavefront (own value where there is no such lane)
+MFGM_DEV double vdp_up(double x, int o) { return __shfl_up(x, (unsigned)o, 64); }
+
 MFGM_DEV double vdp_stab(double x, double c) {
     x = (x != x) ? 1e-8 : x;
     return fmin(fmax(x, -c), c);
@@ -398,14 +401,16 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
 
 // value at the first node of segment p+1 = map_p(value at the first node of segment p), from q(x0) = N(q0_mu[b], q0_cov[b]):
 // one wavefront per chain, as k_vdp_lagrange_scan_wave (lane j composes K = ceil(P / 64) consecutive maps, readlane chain, replay).
+constexpr int kScanBlock = 256;       // lanes per chain in the segment-map scans: four wavefronts, K = ceil(P / 256) maps per lane
 template <int D>
-__global__ __launch_bounds__(64) void k_vdp_marginals_scan(LevelDesc lv, const double* __restrict__ q0_mu,
-                                                          const double* __restrict__ q0_cov, double* __restrict__ seg) {
+__global__ __launch_bounds__(kScanBlock) void k_vdp_marginals_scan(LevelDesc lv, const double* __restrict__ q0_mu,
+                                                                  const double* __restrict__ q0_cov, double* __restrict__ seg) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
-    const int b = blockIdx.x, j = threadIdx.x;
+    __shared__ double wtot[kScanBlock / 64][MAP];  // the composed map of each wavefront's 64 lanes
+    const int b = blockIdx.x, jl = threadIdx.x, j = jl & 63, wv = jl >> 6;
     const int P = lv.P;
-    const int K = (P + 63) / 64;
-    const int lo = j * K;                          // this lane's segments: lo, lo+1, ..., min(lo+K, P) - 1
+    const int K = (P + kScanBlock - 1) / kScanBlock;
+    const int lo = jl * K;                         // this lane's segments: lo, lo+1, ..., min(lo+K, P) - 1
     double* bnd = seg + MAP;
     auto load_map = [&](int p, double (&Ph)[EF], double (&Qa)[ET], double (&ma)[D]) {
         const size_t lane = (size_t)b * P + p;
@@ -444,24 +449,65 @@ __global__ __launch_bounds__(64) void k_vdp_marginals_scan(LevelDesc lv, const d
             for (int e = 0; e < EF; ++e) Phi[e] = t[e];
         }
     }
-    double rm[D], rS[ET], mym[D], myS[ET];
+    // Inclusive scan of the lanes' composed maps in log2(64) rounds (Kogge-Stone): after round o a lane holds the composition of up to 2 o
+    // consecutive lanes' maps ending with its own.  (A serial chain of 64 applications through v_readlane broadcasts took 67 of the
+    // kernel's 160 us at d = 6: every one of them a d x d congruence behind 126 broadcasts.)  later o earlier:
+    // (Phi, Q, m) o (Pp, Qp, mp) = (Phi Pp, Phi Qp Phi^T + Q, Phi mp + m).
+    for (int o = 1; o < 64; o <<= 1) {
+        double Pp[EF], Qp[ET], mp[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { rm[i] = q0_mu[(size_t)b * D + i]; mym[i] = 0.0; }
+        for (int e = 0; e < EF; ++e) Pp[e] = vdp_up(Phi[e], o);
 #pragma unroll
-    for (int e = 0; e < ET; ++e) { rS[e] = q0_cov[(size_t)b * ET + e]; myS[e] = 0.0; }
-    for (int jj = 0; jj < 64; ++jj) {
+        for (int e = 0; e < ET; ++e) Qp[e] = vdp_up(Qc[e], o);
 #pragma unroll
-        for (int i = 0; i < D; ++i) mym[i] = (jj == j) ? rm[i] : mym[i];
+        for (int i = 0; i < D; ++i) mp[i] = vdp_up(mc[i], o);
+        if (j >= o) {
+            double t[EF];
+            apply(Phi, Qc, mc, mp, Qp);
+            gemm<D>(Phi, Pp, t);
 #pragma unroll
-        for (int e = 0; e < ET; ++e) myS[e] = (jj == j) ? rS[e] : myS[e];
-        double Pb[EF], Qb[ET], mb[D];
+            for (int e = 0; e < EF; ++e) Phi[e] = t[e];
 #pragma unroll
-        for (int e = 0; e < EF; ++e) Pb[e] = vdp_bcast(Phi[e], jj);
+            for (int e = 0; e < ET; ++e) Qc[e] = Qp[e];
 #pragma unroll
-        for (int e = 0; e < ET; ++e) Qb[e] = vdp_bcast(Qc[e], jj);
+            for (int i = 0; i < D; ++i) mc[i] = mp[i];
+        }
+    }
+    // the value that enters lane j's segments: q(x0) through the composed maps of the wavefronts before this one (at most three
+    // applications, maps handed over through LDS), then through the composition of the lanes before it in its own wavefront
+    if (j == 63) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) mb[i] = vdp_bcast(mc[i], jj);
-        apply(Pb, Qb, mb, rm, rS);
+        for (int e = 0; e < EF; ++e) wtot[wv][e] = Phi[e];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) wtot[wv][EF + e] = Qc[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) wtot[wv][EF + ET + i] = mc[i];
+    }
+    __syncthreads();
+    double mym[D], myS[ET];
+#pragma unroll
+    for (int i = 0; i < D; ++i) mym[i] = q0_mu[(size_t)b * D + i];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) myS[e] = q0_cov[(size_t)b * ET + e];
+    for (int w = 0; w < wv; ++w) {
+        double Pw[EF], Qw[ET], mw[D];
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Pw[e] = wtot[w][e];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) Qw[e] = wtot[w][EF + e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) mw[i] = wtot[w][EF + ET + i];
+        apply(Pw, Qw, mw, mym, myS);
+    }
+    {
+        double Pe[EF], Qe[ET], me[D];
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Pe[e] = vdp_up(Phi[e], 1);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) Qe[e] = vdp_up(Qc[e], 1);
+#pragma unroll
+        for (int i = 0; i < D; ++i) me[i] = vdp_up(mc[i], 1);
+        if (j > 0) apply(Pe, Qe, me, mym, myS);
     }
     for (int k = 0; k < K; ++k) {
         const int p = lo + k;
@@ -699,12 +745,13 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_products(LevelDesc lv, VdpP
 //   PART 0: psi (value X, maps X -> X M + C);  PART 1: lambda (value v, maps v -> M v + C)
 
 template <int D, int PART>
-__global__ __launch_bounds__(64) void k_vdp_lagrange_scan_wave(LevelDesc lv, double* __restrict__ seg) {
+__global__ __launch_bounds__(kScanBlock) void k_vdp_lagrange_scan_wave(LevelDesc lv, double* __restrict__ seg) {
     constexpr int EF = D * D, SEG = 3 * EF + D, STR = SEG + EF + D, NV = PART == 0 ? EF : D;
-    const int b = blockIdx.x, j = threadIdx.x;
+    __shared__ double wtot[kScanBlock / 64][EF + NV];   // the composed map of each wavefront's 64 lanes
+    const int b = blockIdx.x, jl = threadIdx.x, j = jl & 63, wv = jl >> 6;
     const int P = lv.P;
-    const int K = (P + 63) / 64;
-    const int hi = P - j * K;                      // this lane's segments: hi-1, hi-2, ..., max(hi-K, 0)
+    const int K = (P + kScanBlock - 1) / kScanBlock;
+    const int hi = P - jl * K;                     // this lane's segments: hi-1, hi-2, ..., max(hi-K, 0)
     const double* Mg = seg + (PART == 0 ? 0 : 2 * EF);
     const double* Cg = seg + (PART == 0 ? EF : 3 * EF);
     double* bnd = seg + SEG + (PART == 0 ? 0 : EF);
@@ -742,23 +789,55 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_scan_wave(LevelDesc lv, dou
             for (int e = 0; e < EF; ++e) M[e] = t[e];
         }
     }
-    // value at the last node of the chain: psi_{N-1} = 1e-10 I, lambda_{N-1} = 0; chained through the lanes' maps
-    double run[NV], mine[NV];
+    // Inclusive scan of the lanes' composed maps (lane 0 holds the END of the chain) in log2(64) rounds, as k_vdp_marginals_scan:
+    //   PART 0, X -> X M + C:  later o earlier = (Mp M, Cp M + C);      PART 1, v -> M v + C:  later o earlier = (M Mp, M Cp + C).
+    for (int o = 1; o < 64; o <<= 1) {
+        double Mp[EF], Cp[NV];
 #pragma unroll
-    for (int e = 0; e < NV; ++e) { run[e] = 0.0; mine[e] = 0.0; }
+        for (int e = 0; e < EF; ++e) Mp[e] = vdp_up(M[e], o);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) Cp[e] = vdp_up(C[e], o);
+        if (j >= o) {
+            double t[EF];
+            apply(Cp, M, C);                       // Cp M + C  /  M Cp + C
+            if constexpr (PART == 0) gemm<D>(Mp, M, t); else gemm<D>(M, Mp, t);
+#pragma unroll
+            for (int e = 0; e < EF; ++e) M[e] = t[e];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) C[e] = Cp[e];
+        }
+    }
+    // value at the last node of the chain: psi_{N-1} = 1e-10 I, lambda_{N-1} = 0; what enters lane j's segments is the composition of the
+    // lanes before it applied to that value
+    if (j == 63) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) wtot[wv][e] = M[e];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) wtot[wv][EF + e] = C[e];
+    }
+    __syncthreads();
+    double mine[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) mine[e] = 0.0;
     if constexpr (PART == 0) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) run[i * D + i] = 1e-10;
+        for (int i = 0; i < D; ++i) mine[i * D + i] = 1e-10;
     }
-    for (int jj = 0; jj < 64; ++jj) {
+    for (int w = 0; w < wv; ++w) {                 // through the wavefronts before this one (they hold the later segments)
+        double Mw[EF], Cw[NV];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) mine[e] = (jj == j) ? run[e] : mine[e];
-        double Mb[EF], Cb[NV];
+        for (int e = 0; e < EF; ++e) Mw[e] = wtot[w][e];
 #pragma unroll
-        for (int e = 0; e < EF; ++e) Mb[e] = vdp_bcast(M[e], jj);
+        for (int e = 0; e < NV; ++e) Cw[e] = wtot[w][EF + e];
+        apply(mine, Mw, Cw);
+    }
+    {
+        double Me[EF], Ce[NV];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) Cb[e] = vdp_bcast(C[e], jj);
-        apply(run, Mb, Cb);
+        for (int e = 0; e < EF; ++e) Me[e] = vdp_up(M[e], 1);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) Ce[e] = vdp_up(C[e], 1);
+        if (j > 0) apply(mine, Me, Ce);
     }
     // replay: boundary value of every segment of this lane
     for (int k = 0; k < K; ++k) {
