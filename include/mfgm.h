@@ -298,6 +298,13 @@ typedef struct mfgm_kf_sites {
  * Pd (SYM) / Ps (FULL): packed prior precision blocks; D, r, L, y: packed scratch (SYM, VEC, TRI, VEC). */
 int mfgm_kf_sites_loglik(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, double* D, double* r,
                          double* L, double* y, double* t1, double* ldR, double* logdet, double* quad, void* ws, int* info, void* stream);
+/* mfgm_kf_sites_loglik with the scalar assembly inside (kalman_filter.py:229-255): ll[b] = cst + term1 + term2 + term3 with
+ * term3 = -sumlogchol[b] - log|L| + 1/2 ldR (sumlogchol [B]: sum log diag chol of the prior's P0, Q_k; cst: the caller's
+ * -1/2 o T log 2 pi), total = sum_b ll[b]; NaN when a pivot block was not positive definite (info).  terms [4, B] (may be NULL) receives
+ * (t1, ldR, log|L|, |y|^2).  The four per-chain sums take two launches instead of five. */
+int mfgm_kf_sites_elbo(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, double* D, double* r,
+                       double* L, double* y, const double* sumlogchol, double cst, double* terms, double* ll, double* total, void* ws,
+                       int* info, void* stream);
 /* posterior marginals (Sig SYM, x VEC packed) of  precision = prior precision + H^T R^{-1} H,  rhs = plin + H^T nat1  (plin = packed
  * K^{-1} mu_prior or NULL), and their projections Fmu = H x, Fvar = diag(H Sig H^T), natural [B, T, o]. */
 int mfgm_kf_sites_predict(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, const double* plin,

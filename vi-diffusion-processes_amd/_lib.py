@@ -79,6 +79,7 @@ EXPORTS = {
     "mfgm_mvn_ve_compact": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_kf_sites_loglik": (ctypes.c_int, [ctypes.c_void_p] * 15),
     "mfgm_kf_sites_predict": (ctypes.c_int, [ctypes.c_void_p] * 16),
+    "mfgm_kf_sites_elbo": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_double] + [ctypes.c_void_p] * 6),
     "mfgm_kf_sites_predict_factored": (ctypes.c_int, [ctypes.c_void_p] * 11),
     "mfgm_sparse_theta": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 9),
     "mfgm_sparse_predict": (ctypes.c_int, [ctypes.c_void_p] * 7),

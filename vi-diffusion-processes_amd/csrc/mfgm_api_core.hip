@@ -72,7 +72,7 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
     auto take = [&](size_t nd) { size_t o = off; off += (nd + 63) / 64 * 64; return o; };
     // per-segment partial sums (narrow: also the d-vector hand-over of the fused Girsanov sweep); the wide local kernels keep one
     // partial per node
-    P.off_part[0] = take(P.wide ? 2 * std::max<size_t>(P.lv[0].Lpad, (size_t)B * (T + 1)) : (size_t)std::max(2, d) * P.lv[0].Lpad);
+    P.off_part[0] = take(P.wide ? 2 * std::max<size_t>(P.lv[0].Lpad, (size_t)B * (T + 1)) : (size_t)std::max(4, d) * P.lv[0].Lpad);
     P.off_part2 = take(std::max((size_t)2 * B * 128, (size_t)B * (d * d + d)));    // also: the saved boundary correction of a sharded chain
     for (int i = 1; i < P.nlevels; ++i) {
         const LevelDesc& lv = P.lv[i];

@@ -103,7 +103,8 @@ int launch_coarse_backward(const Plan& P, int lf, bool has_rhs, double* ws, hipS
 template <int D>
 int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info,
-                hipStream_t st, int only_stage = -1, int only_level = -1) {
+                hipStream_t st, int only_stage = -1, int only_level = -1, bool partials_only = false) {
+    // partials_only: the per-lane log|L| / |y|^2 partials are left in ws + off_part[0] for the caller to sum (kf_elbo_impl)
     const bool has_rhs = (rg != nullptr);
     const int K = P.nlevels - 1;  // top level index (single segment per chain)
     auto make = [&](int l) {
@@ -114,7 +115,7 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
         if (l == 0) {
             a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
             a.Lg = Lg; a.Gg = Gg; a.yg = yg;
-            a.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
+            a.part = (logdet || quad || partials_only) ? ws + P.off_part[0] : nullptr;
         } else {
             bind_level_inputs(P, l, ws, a);
         }
@@ -393,6 +394,72 @@ int kf_assemble_impl(const Plan& P, const KfArgs& k, const double* Pd, const dou
     }
     return 0;
 }
+// The four per-chain sums of the Kalman log-likelihood with sites and its assembly (kalman_filter.py:229-255) in two launches instead
+// of five: part = [log|L|, |y|^2, t1, ldR] x [Lpad] per-lane partials; stage 1: kElboSplit blocks per chain sum a slice of each
+// array (fixed order: deterministic), stage 2: one block adds those and forms
+//   ll_b = cst - 1/2 t1 + 1/2 |y|^2 - sumlogchol_b - log|L| + 1/2 ldR      (NaN when a pivot block was not positive definite).
+constexpr int kElboSplit = 64;
+static __global__ __launch_bounds__(256) void k_kf_elbo_stage1(const double* __restrict__ part, int P, int Lpad, double* __restrict__ scratch) {
+    __shared__ double sh[4][4];
+    const int g = blockIdx.x, b = blockIdx.y, B = gridDim.y;
+    const int slice = (P + kElboSplit - 1) / kElboSplit, lo = g * slice, hi = min(P, lo + slice);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += part[(size_t)q * Lpad + (size_t)b * P + p];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = s[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) scratch[((size_t)threadIdx.x * B + b) * kElboSplit + g] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+static __global__ __launch_bounds__(64) void k_kf_elbo_stage2(const double* __restrict__ scratch, int B, double cst, const double* __restrict__ sumlogchol,
+                                                             const int* __restrict__ info, double* __restrict__ terms, double* __restrict__ ll,
+                                                             double* __restrict__ total) {
+    // one wavefront; lane g holds the stage-1 partial g of each term, chains one after the other (B is small on this path)
+    const bool bad = info && *info != 0;
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[q] = scratch[((size_t)q * B + b) * kElboSplit + threadIdx.x];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+            s[q] = __shfl(s[q], 0, 64);
+        }
+        double v = cst - 0.5 * s[2] + 0.5 * s[1] - sumlogchol[b] - s[0] + 0.5 * s[3];
+        if (bad) v = __builtin_nan("");
+        if (threadIdx.x == 0) {
+            if (terms) { terms[b] = s[2]; terms[B + b] = s[3]; terms[2 * B + b] = s[0]; terms[3 * B + b] = s[1]; }   // (t1, ldR, log|L|, |y|^2)
+            if (ll) ll[b] = v;
+        }
+        tot += v;
+    }
+    if (threadIdx.x == 0 && total) *total = tot;
+}
+
+template <int D, int O>
+int kf_elbo_impl(const Plan& P, const KfArgs& k, const double* Pd, const double* Ps, double* Dg, double* rg, double* L, double* y,
+                 const double* sumlogchol, double cst, double* terms, double* ll, double* total, double* ws, int* info, hipStream_t st) {
+    double* part = ws + P.off_part[0];
+    hipLaunchKernelGGL((k_kf_assemble<D, O>), dim3(P.lv[0].Lpad / 64), dim3(64), 0, st, P.lv[0], P.T, k, Pd, (const double*)nullptr, Dg, rg,
+                       part + 2 * (size_t)P.lv[0].Lpad);
+    MFGM_CHECK_LAUNCH();
+    int rc = factor_impl<D>(P, Dg, Ps, rg, 1.0, 1.0, 1.0, L, nullptr, y, nullptr, nullptr, ws, info, st, -1, -1, true);
+    if (rc) return rc;
+    double* scratch = ws + P.off_part2;
+    hipLaunchKernelGGL(k_kf_elbo_stage1, dim3(kElboSplit, P.B), dim3(256), 0, st, (const double*)part, P.lv[0].P, P.lv[0].Lpad, scratch);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_kf_elbo_stage2, dim3(1), dim3(64), 0, st, (const double*)scratch, P.B, cst, sumlogchol, (const int*)info, terms, ll, total);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int D, int O>
 int kf_loglik_impl(const Plan& P, const KfArgs& k, const double* Pd, const double* Ps, double* Dg, double* rg, double* L, double* y,
                    double* t1, double* ldR, double* logdet, double* quad, double* ws, int* info, hipStream_t st) {
@@ -533,6 +600,18 @@ int mfgm_kf_sites_loglik(const mfgm_plan* plan, const mfgm_kf_sites* sites, cons
     if (P.T > 1 && !Ps) return 1;
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_DO(P.d, sites->o, (kf_loglik_impl<DD, OO>(P, k, Pd, Ps, D, r, L, y, t1, ldR, logdet, quad, (double*)ws, info, st)));
+}
+
+int mfgm_kf_sites_elbo(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, double* D, double* r,
+                       double* L, double* y, const double* sumlogchol, double cst, double* terms, double* ll, double* total, void* ws,
+                       int* info, void* stream) {
+    KfArgs k;
+    if (!kf_args(plan, sites, 0, k) || !Pd || !D || !r || !L || !y || !sumlogchol || (!ll && !total) || !ws || !info) return 1;
+    const Plan& P = plan->p;
+    if (P.T > 1 && !Ps) return 1;
+    if ((size_t)4 * P.B * kElboSplit > std::max((size_t)2 * P.B * 128, (size_t)P.B * (P.d * P.d + P.d))) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_DO(P.d, sites->o, (kf_elbo_impl<DD, OO>(P, k, Pd, Ps, D, r, L, y, sumlogchol, cst, terms, ll, total, (double*)ws, info, st)));
 }
 
 int mfgm_kf_sites_predict(const mfgm_plan* plan, const mfgm_kf_sites* sites, const double* Pd, const double* Ps, const double* plin,

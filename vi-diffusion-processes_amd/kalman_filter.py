@@ -219,22 +219,19 @@ class KalmanFilterWithSites(BaseKalmanFilter):
         sv, keep, cache = call
         pr = ssm._precision_packed()
         b = _kf_scratch(cache, pl, ("D", "r", "L", "y"))
-        out = torch.empty((4, ssm.B), dtype=torch.float64, device=pl.device)
+        total = torch.empty(1, dtype=torch.float64, device=pl.device)
         pl.epoch += 1
-        _lib.check(pl.lib.mfgm_kf_sites_loglik(pl.h, ctypes.byref(sv), _ptr(pr["diag"]), _ptr(pr["sub"]), _ptr(b["D"]), _ptr(b["r"]),
-                                               _ptr(b["L"]), _ptr(b["y"]), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
-                                               _ptr(pl.ws), _ptr(pl.info), _stream()), "mfgm_kf_sites_loglik")
+        cst = -0.5 * math.log(2 * math.pi) * sv.o * ssm.T
+        # cst + term1 + term2 + term3 (kalman_filter.py:229-255) assembled by the library call itself; NaN when a pivot block was not
+        # positive definite (no host synchronisation in the loop: plan.check_info() raises for it when asked, VIDP_EAGER_CHECK=1 asks
+        # every time)
+        _lib.check(pl.lib.mfgm_kf_sites_elbo(pl.h, ctypes.byref(sv), _ptr(pr["diag"]), _ptr(pr["sub"]), _ptr(b["D"]), _ptr(b["r"]),
+                                             _ptr(b["L"]), _ptr(b["y"]), _ptr(pr["sumlogchol"]), cst, None, None, _ptr(total), _ptr(pl.ws),
+                                             _ptr(pl.info), _stream()), "mfgm_kf_sites_elbo")
         # the factorisation now in (L, y) and the workspace belongs to these sites: with a zero-mean prior the prediction at the data
         # solves the same system with the same right-hand side (_predict_f_fused reuses it).  The site tensors are kept alive here,
         # so that `is` identifies them.
         cache["factor_of"] = (keep[0], keep[0]._version, keep[1], keep[1]._version, pl.epoch) if cache["zero_mean"] else None
-        cst = -0.5 * math.log(2 * math.pi) * sv.o * ssm.T
-        # cst + term1 + term2 + term3 (kalman_filter.py:229-255) in one launch; NaN when a pivot block was not positive definite (no host
-        # synchronisation in the loop: plan.check_info() raises for it when asked, VIDP_EAGER_CHECK=1 asks every time)
-        w = (ctypes.c_double * 4)(-0.5, 0.5, -1.0, 0.5)
-        total = torch.empty(1, dtype=torch.float64, device=pl.device)
-        _lib.check(pl.lib.mfgm_combine_terms(4, ssm.B, _ptr(out), w, cst, _ptr(pr["sumlogchol"]), -1.0, _ptr(pl.info), None, _ptr(total),
-                                             _stream()), "mfgm_combine_terms")
         if os.environ.get("VIDP_EAGER_CHECK", "0") == "1":
             pl.check_info()
         return total[0]
