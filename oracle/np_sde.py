@@ -162,6 +162,41 @@ class SqrtDiffusionSDE(SDE):
         return 0.5 * np.sign(x) * np.sqrt(self.theta / np.abs(x))
 
 
+class VanderPolSDE(SDE):
+    """sde.py:432-482: f = tau (a (x1 - x1^3 / 3 - x2), x1 / a); gradient_drift is the full Jacobian (batch_jacobian, sde.py:484-498)."""
+
+    def __init__(self, a=1.0, tau=1.0, q=np.eye(2)):
+        super().__init__(q)
+        self.a, self.tau = float(a), float(tau)
+
+    def drift(self, x, t=None):
+        x1, x2 = x[..., 0], x[..., 1]
+        return self.tau * np.stack([self.a * (x1 - x1 ** 3 / 3.0 - x2), x1 / self.a], axis=-1)
+
+    def jacobian_drift(self, x, t=None):
+        x1 = x[..., 0]
+        one, zero = np.ones_like(x1), np.zeros_like(x1)
+        return self.tau * np.stack([np.stack([self.a * (1.0 - x1 * x1), -self.a * one], axis=-1), np.stack([one / self.a, zero], axis=-1)], axis=-2)
+
+
+class MLPDriftSDE(SDE):
+    """sde.py:359-429: the one-dimensional 1 -> 3 -> 1 ReLU network drift, weights (W1 [1,3], b1 [3], W2 [3,1], b2 [1]) given."""
+
+    def __init__(self, weights, q=np.ones((1, 1))):
+        super().__init__(q)
+        self.weights = [np.asarray(w, dtype=np.float64) for w in weights]
+
+    def drift(self, x, t=None):
+        W1, b1, W2, b2 = self.weights
+        h = np.maximum(x.reshape(-1, 1) @ W1 + b1, 0.0)
+        return (h @ W2 + b2).reshape(x.shape)
+
+    def jacobian_drift(self, x, t=None):
+        W1, b1, W2, b2 = self.weights
+        act = ((x.reshape(-1, 1) @ W1 + b1) > 0).astype(np.float64)
+        return ((act * W1) @ W2).reshape(x.shape + (1,))
+
+
 def linear_drift_to_ssm(A, b, q, transition_times, initial_mean, initial_chol_covariance):
     """LinearDrift.to_ssm (drift.py:66-117): A_k = A dt + I, b_k = b dt, Q_k = q dt.  A [N,D,D], b [N,D], q [N,D,D]."""
     dts = (transition_times[1:] - transition_times[:-1])
@@ -178,6 +213,13 @@ def linearize_sde(sde, transition_times, path_mu, path_cov, init_mu, init_cov, c
     closed_form: the two expectations from the cubic's Gaussian moments instead of the 10^D-point quadrature.
     """
     N, D = path_mu.shape
+    if hasattr(sde, "jacobian_drift"):
+        # drifts that couple the dimensions: E[f'] is the full Jacobian [N, D, D] (sde.py:500-518 with batch_jacobian, :484-498)
+        E_f = sde.expected_drift(path_mu[None], path_cov[None])[0]
+        A = mvnquad(lambda x: sde.jacobian_drift(x), path_mu, path_cov, 10, D, (D, D))
+        b = E_f - (A @ path_mu[..., None])[..., 0]
+        cq = sde.diffusion(path_mu, None)
+        return linear_drift_to_ssm(A, b, cq @ cq, transition_times, init_mu, np.linalg.cholesky(init_cov))
     if closed_form:
         E_f, Adiag = expected_drift_closed_form(sde, path_mu, path_cov)
     else:

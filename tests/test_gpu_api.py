@@ -1661,3 +1661,53 @@ def test_cvi_classic_elbo_site_gradient_vanishes_at_optimum(amd, rng, kname):
         # (the Matern-3/2 component loses digits to cancellation in Q = Pinf - A Pinf A^T, as in KA7 above: the difference quotient of the
         #  ordinary path carries that noise divided by the step)
         np.testing.assert_allclose(got, fd, rtol=1e-6 if kname == "m12" else 1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("kind", ["vanderpol", "mlp"])
+def test_cvi_sites_sde_quadrature_drifts(amd, rng, kind):
+    """The drifts that couple the state dimensions / have no polynomial form (markovflow/sde/sde.py:359-518: VanderPolOscillatorSDE, MLPDrift)
+    through CVISitesSDEQuadrature -- the reference's Gauss-Hermite formulation with autograd for its GradientTape, sweeps in HIP --
+    against the oracle's restatement (quadrature KL, central differences for the tape): linearised prior, KL, its gradient with
+    respect to the expectation parameters, and the ELBO over damped data / Girsanov updates and a re-linearisation."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDEQuadrature
+    T, dt = 16, 0.05
+    grid = np.arange(T) * dt
+    if kind == "vanderpol":
+        d = 2
+        o_sde, g_sde = np_sde.VanderPolSDE(1.3, 0.9, 0.5 * np.eye(2)), gsde.VanderPolOscillatorSDE(1.3, 0.9, torch.from_numpy(0.5 * np.eye(2)))
+    else:
+        d = 1
+        w = (rng.normal(size=(1, 3)), 0.1 * rng.normal(size=3), rng.normal(size=(3, 1)), np.zeros(1))
+        o_sde, g_sde = np_sde.MLPDriftSDE(w), gsde.MLPDrift(weights=[torch.from_numpy(np.asarray(x)) for x in w])
+    idx = np.array([3, 7, 12])
+    y = rng.normal(size=(1, len(idx), d))
+    cholR = 0.4 * np.eye(d)
+    init = (np.zeros(d), 0.8 * np.eye(d))
+    g = CVISitesSDEQuadrature(g_sde, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)), prior_initial_state=init)
+    o = np_models.CVISitesSDE(o_sde, grid, idx, y[0], np_models.MultivariateGaussianLik(cholR), *init)
+    assert_close(host(g.dist_p.state_transitions)[0], o.dist_p.A, rtol=1e-9)
+    assert_close(host(g.dist_p.state_offsets)[0], o.dist_p.b, rtol=1e-9)
+    for m in (g, o):
+        m.update_data_sites(0.5)
+    np.testing.assert_allclose(float(g.KL_q_p()[0]), o.KL_q_p(), rtol=1e-8)
+    _, (g1, gd, gs) = g.grad_kl_wrt_exp_param()
+    o1, od, os_ = o.grad_kl_wrt_exp_param()
+    pl = g.plan
+    # (the oracle's gradient is a central difference with step 1e-6: 1e-5 is its own accuracy)
+    assert_close(host(pl.unpack(amd.VEC, g1))[0], o1, rtol=2e-5, scale_atol=2e-6)
+    assert_close(host(pl.unpack(amd.SYM, gd))[0], od, rtol=2e-5, scale_atol=2e-6)
+    assert_close(host(pl.unpack(amd.FULL, gs, T - 1))[0], os_, rtol=2e-5, scale_atol=2e-6)
+    for it in range(2):
+        for m in (g, o):
+            m.update_girsanov_sites(0.2)
+            m.update_data_sites(0.4)
+        np.testing.assert_allclose(float(g.classic_elbo()), o.classic_elbo(), rtol=1e-5)
+        if it == 0:
+            g.relinearize()
+            o.relinearize()
+            np.testing.assert_allclose(float(g.classic_elbo()), o.classic_elbo(), rtol=1e-5)
+    g.plan.check_info()

@@ -104,3 +104,25 @@ def test_non_polynomial_drifts_against_adaptive_quadrature(rng):
         # tolerance = accuracy of the reference's own 10-point rule on these integrands
         np.testing.assert_allclose(sde.expected_drift(mm, vv)[0, 0, 0], Ef, rtol=5e-6)
         np.testing.assert_allclose(sde.expected_gradient_drift(mm, vv)[0, 0, 0], Eg, rtol=5e-5)
+
+
+def test_oracle_vanderpol_linearisation_matches_closed_form(rng):
+    """The coupled-drift route of the oracle (full expected Jacobian by the 10-point rule, reference sde.py:484-518) against the closed
+    form the Van der Pol drift admits: E f1 = tau a (m1 - (m1^3 + 3 m1 S11) / 3 - m2), E f2 = tau m1 / a,
+    E df/dx = tau [[a (1 - m1^2 - S11), -a], [1 / a, 0]] -- the rule is exact for this cubic."""
+    from oracle import np_sde
+    a, tau = 1.3, 0.9
+    sde = np_sde.VanderPolSDE(a, tau, 0.5 * np.eye(2))
+    N = 7
+    m = rng.normal(size=(N, 2))
+    L = np.tril(rng.normal(size=(N, 2, 2))) + 1.5 * np.eye(2)
+    S = L @ np.swapaxes(L, -1, -2)
+    Ef = sde.expected_drift(m[None], S[None])[0]
+    J = np_sde.mvnquad(lambda x: sde.jacobian_drift(x), m, S, 10, 2, (2, 2))
+    m1, m2, s11 = m[:, 0], m[:, 1], S[:, 0, 0]
+    np.testing.assert_allclose(Ef[:, 0], tau * a * (m1 - (m1 ** 3 + 3 * m1 * s11) / 3 - m2), rtol=1e-10)
+    np.testing.assert_allclose(Ef[:, 1], tau * m1 / a, rtol=1e-10)
+    np.testing.assert_allclose(J[:, 0, 0], tau * a * (1 - m1 ** 2 - s11), rtol=1e-10)
+    np.testing.assert_allclose(J[:, 0, 1], -tau * a, rtol=1e-10)
+    np.testing.assert_allclose(J[:, 1, 0], tau / a, rtol=1e-10)
+    np.testing.assert_allclose(J[:, 1, 1], 0.0, atol=1e-12)

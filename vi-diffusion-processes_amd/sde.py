@@ -211,3 +211,107 @@ class SqrtDiffusionSDE(_ThetaSDE):
 
     def gradient_drift(self, x, t=None):
         return 0.5 * torch.sign(x) * torch.sqrt(self.theta / torch.abs(x))
+
+
+# ---- drifts that couple the state dimensions or are not given in closed form (sde.py:359-518) ----------------------------------------------
+def _hermgauss_grid(H, D, device):
+    """Tensor-product Gauss-Hermite nodes [H^D, D] and weights [H^D] of GPflow's mvnquad (weights include pi^{-D/2})."""
+    import itertools
+    gx, gw = np.polynomial.hermite.hermgauss(H)
+    x = np.array(list(itertools.product(*(gx,) * D)))
+    w = np.prod(np.array(list(itertools.product(*(gw,) * D))), 1) * np.pi ** (-0.5 * D)
+    return torch.from_numpy(x).to(device), torch.from_numpy(w).to(device)
+
+
+def mvnquad(func, means, chols, H, Dout=()):
+    """E_{N(m, L L^T)} func(x) by the H^D-point tensor Gauss-Hermite rule (gpflow.quadrature.mvnquad as the reference calls it,
+    sde.py:92-131, sde_utils.py:262-359) for means [..., D] and Cholesky factors [..., D, D]; func maps [H^D, ..., D] -> [H^D, ..., *Dout].
+    Differentiable in (means, chols): the nodes are m + sqrt(2) L z."""
+    D = means.shape[-1]
+    z, w = _hermgauss_grid(H, D, means.device)
+    X = means[None] + math.sqrt(2.0) * torch.einsum("...ij,hj->h...i", chols, z)
+    fX = func(X)
+    return (fX * w.reshape((-1,) + (1,) * (fX.dim() - 1))).sum(0)
+
+
+class QuadratureSDE(SDE):
+    """An SDE whose drift is a torch function of the whole state: E_q f and E_q df/dx by the reference's 10-point-per-dimension
+    Gauss-Hermite rules (sde.py:92-131; `expected_gradient_drift` returns the full Jacobian [.., D, D], sde.py:484-518 for the coupled
+    drifts).  Served by variational_cvi_sde.CVISitesSDEQuadrature: small models (the tensor grid has 10^D / 20^D points per step), the
+    posterior refresh itself stays in the HIP sweeps."""
+
+    kind = -1       # not a drift family of the HIP kernels
+
+    def jacobian_drift(self, x, t=None):
+        """d f_i / d x_j at x [..., D] -> [..., D, D]; default: reverse-mode through `drift`, one pass per output dimension."""
+        with torch.enable_grad():
+            xx = x.detach().requires_grad_(True)
+            f = self.drift(xx, t)
+            rows = [torch.autograd.grad(f[..., i].sum(), xx, retain_graph=True)[0] for i in range(self.state_dim)]
+        return torch.stack(rows, dim=-2)
+
+    gradient_drift = jacobian_drift
+
+    def expected_drift(self, q_mean, q_chol):
+        return mvnquad(lambda x: self.drift(x), q_mean, q_chol, 10, (self.state_dim,))
+
+    def expected_gradient_drift(self, q_mean, q_chol):
+        return mvnquad(lambda x: self.jacobian_drift(x), q_mean, q_chol, 10, (self.state_dim, self.state_dim))
+
+    def cubic(self, dt):
+        raise NotImplementedError("not a per-dimension cubic drift: use CVISitesSDEQuadrature")
+
+    def params(self, *a, **k):
+        raise NotImplementedError("not a per-dimension cubic drift: use CVISitesSDEQuadrature")
+
+
+class VanderPolOscillatorSDE(QuadratureSDE):
+    """Van der Pol oscillator, state (x1, x2): f = tau (a (x1 - x1^3 / 3 - x2), x1 / a) (sde.py:432-482)."""
+
+    _param_names = ("a", "tau")
+
+    def __init__(self, a=1.0, tau=1.0, q=None, trainable=False):
+        super().__init__(torch.eye(2, dtype=torch.float64) if q is None else q)
+        if self.state_dim != 2:
+            raise ValueError("the Van der Pol oscillator has two state dimensions")
+        self.a, self.tau = float(a), float(tau)
+        self._trainable = {"a": bool(trainable), "tau": bool(trainable)}
+
+    def drift(self, x, t=None):
+        x1, x2 = x[..., 0], x[..., 1]
+        return self.tau * torch.stack([self.a * (x1 - x1 ** 3 / 3.0 - x2), x1 / self.a], dim=-1)
+
+    def jacobian_drift(self, x, t=None):
+        x1 = x[..., 0]
+        one, zero = torch.ones_like(x1), torch.zeros_like(x1)
+        return self.tau * torch.stack([torch.stack([self.a * (1.0 - x1 * x1), -self.a * one], dim=-1),
+                                       torch.stack([one / self.a, zero], dim=-1)], dim=-2)
+
+    gradient_drift = jacobian_drift
+
+
+class MLPDrift(QuadratureSDE):
+    """One-dimensional drift given by a 1 -> 3 -> 1 ReLU network (sde.py:359-429: two Dense layers, standard-normal initial weights, zero
+    biases).  `weights` = (W1 [1, 3], b1 [3], W2 [3, 1], b2 [1]); default: drawn with torch's generator `seed`."""
+
+    def __init__(self, q=None, weights=None, seed=0):
+        super().__init__(torch.ones((1, 1), dtype=torch.float64) if q is None else q)
+        if self.state_dim != 1:
+            raise ValueError("MLPDrift is the reference's one-dimensional network drift")
+        if weights is None:
+            g = torch.Generator().manual_seed(int(seed))
+            weights = (torch.randn((1, 3), generator=g, dtype=torch.float64), torch.zeros(3, dtype=torch.float64),
+                       torch.randn((3, 1), generator=g, dtype=torch.float64), torch.zeros(1, dtype=torch.float64))
+        self.weights = tuple(torch.as_tensor(w, dtype=torch.float64) for w in weights)
+
+    def drift(self, x, t=None):
+        W1, b1, W2, b2 = (w.to(x.device) for w in self.weights)
+        h = torch.relu(x.reshape(-1, 1) @ W1 + b1)
+        return (h @ W2 + b2).reshape(x.shape)
+
+    def jacobian_drift(self, x, t=None):
+        W1, b1, W2, b2 = (w.to(x.device) for w in self.weights)
+        act = ((x.reshape(-1, 1) @ W1 + b1) > 0).to(x.dtype)
+        return ((act * W1) @ W2).reshape(x.shape + (1,))
+
+    gradient_drift = jacobian_drift

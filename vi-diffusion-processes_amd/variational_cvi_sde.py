@@ -774,6 +774,139 @@ class CVISitesSDE(CVISitesSSM):
         self._started = True
 
 
+class CVISitesSDEQuadrature(CVISitesSSM):
+    """
+    CVI-DP (variational_cvi_sde.py:368-518) for drifts the closed-form kernels do not cover: drifts that couple the state dimensions
+    (`sde.VanderPolOscillatorSDE`) or have no polynomial form (`sde.MLPDrift`).  Everything that is LOCAL in time follows the reference's
+    own formulation -- the linearisation by 10-point-per-dimension Gauss-Hermite rules (sde_utils.py:119-179), KL[q || p_SDE] along the
+    Gaussian path by the 20-point rule (sde_utils.py:262-359) and its gradient with respect to the expectation parameters through
+    expectations_to_ssm_params (sde_utils.py:473-547; torch autograd stands in for the GradientTape) -- as batched torch operations on
+    natural-layout tensors; everything SEQUENTIAL in time (the posterior refresh: factorisation, selected inverse, solves) runs in the
+    HIP sweeps on the dense posterior naturals, as for every other model.  A small-model route: the tensor grids have 10^d / 20^d
+    points per time step (the reference's own experiment is T = 501, d = 2).
+    """
+
+    def __init__(self, prior_sde, time_grid, input_data, likelihood, prior_initial_state=None, initial_posterior_path=None,
+                 stabilize_ssm=True, clip_state_transitions=(-1.0, 1.0), plan=None):
+        self.prior_sde = prior_sde
+        d = input_data[1].shape[-1]
+        if prior_initial_state is None:
+            q = prior_sde.q.cpu().numpy()
+            prior_initial_state = (torch.zeros(d, dtype=torch.float64).numpy(), q * (torch.ones((d, d), dtype=torch.float64).numpy()))
+        self.stabilize_ssm, self.clip_state_transitions = stabilize_ssm, clip_state_transitions
+        super().__init__(None, time_grid, input_data, likelihood, prior_initial_state=prior_initial_state,
+                         initial_posterior_path=initial_posterior_path, plan=plan)
+        self.dist_p_linearized = None
+        self.set_linearized_prior()
+
+    # -- linearisation ------------------------------------------------------------------------------------------------------------
+    def _path_natural(self):
+        """(mu [B, T, d], Sigma [B, T, d, d]) of the current posterior; before the first refresh: the initial path."""
+        pl, d = self.plan, self.state_dim
+        if self._q is not None:
+            q = self._refresh(want_marginals=True)
+            return pl.unpack(VEC, q["mu"]), pl.unpack(SYM, q["Sig"])
+        if self._path is not None:
+            return pl.unpack(VEC, self._path[0]), pl.unpack(SYM, self._path[1])
+        mu = torch.zeros((self.B, self.T, d), dtype=torch.float64, device=self.device)
+        return mu, torch.eye(d, dtype=torch.float64, device=self.device).expand(self.B, self.T, d, d).contiguous()
+
+    def set_linearized_prior(self, move_theta_q=True):
+        """A_k = I + dt E_q[df/dx], b_k = dt (E_q f - E_q[df/dx] m), Q_k = dt q on the current path (sde_utils.py:119-179;
+        LinearDrift.to_ssm, drift.py:66-117), installed as dist_p; stabilised: transitions and offsets clipped
+        (variational_cvi_sde.py:420-432)."""
+        from . import linalg
+        sde, d, dt = self.prior_sde, self.state_dim, self.dt
+        mu, cov = self._path_natural()
+        # transition k is linearised on the marginal at k + 1, as the reference hands `fx_mus[1:]` to linearize_sde (:412)
+        m, chol = mu[:, 1:], linalg.cholesky(cov[:, 1:].contiguous())
+        with torch.no_grad():
+            Ef = sde.expected_drift(m, chol)
+            J = sde.expected_gradient_drift(m, chol)
+        eye = torch.eye(d, dtype=torch.float64, device=self.device)
+        A = eye + dt * J
+        b = dt * (Ef - (J @ m[..., None])[..., 0])
+        cholQ = linalg.cholesky((dt * sde.q).to(self.device)).expand(self.B, self.T - 1, d, d).contiguous()
+        mu0 = torch.as_tensor(self.prior_initial_state[0], dtype=torch.float64, device=self.device).expand(self.B, d).contiguous()
+        cholP0 = linalg.cholesky(torch.as_tensor(self.prior_initial_state[1], dtype=torch.float64, device=self.device))
+        cholP0 = cholP0.expand(self.B, d, d).contiguous()
+        self.dist_p_linearized = StateSpaceModel(mu0, cholP0, A.contiguous(), b.contiguous(), cholQ, plan=self.plan)
+        if self.stabilize_ssm:
+            lo, hi = self.clip_state_transitions
+            self._set_prior(StateSpaceModel(mu0, cholP0, A.clamp(lo, hi).contiguous(), b.clamp(lo, hi).contiguous(), cholQ, plan=self.plan),
+                            move_theta_q=move_theta_q)
+        else:
+            self._set_prior(self.dist_p_linearized, move_theta_q=move_theta_q)
+
+    def relinearize(self):
+        """cvi_dp_trainer.py:127-134 (see CVISitesSDE.relinearize): theta_q stays, the implicit Girsanov sites absorb the change."""
+        q_valid = self._q
+        self.full_sites()
+        self.set_linearized_prior(move_theta_q=False)
+        self._q = q_valid
+
+    # -- KL[q || p_SDE] and its gradient --------------------------------------------------------------------------------------------
+    def _kl_from_expectations(self, e1, ed, es):
+        """The scalar SDE_SSM_KL_with_grads_wrt_exp_params differentiates (sde_utils.py:496-543), per chain [B], as a torch graph of the
+        expectation parameters (e1 [B,T,d], ed [B,T,d,d], es [B,T-1,d,d])."""
+        from . import linalg, tape
+        from .sde import mvnquad
+        sde, d, dt = self.prior_sde, self.state_dim, self.dt
+        A, b, cP0, cQ, mu0 = tape.expectations_to_ssm_params(e1, ed, es)
+        cov = ed - e1[..., :, None] * e1[..., None, :]
+        Qq = cQ @ cQ.transpose(-1, -2)
+        Qp = (dt * sde.q).to(self.device)
+        Qp_inv = linalg.spd_inverse(Qp)
+        ld = lambda c: 2.0 * torch.log(torch.diagonal(c, dim1=-2, dim2=-1)).sum(-1)
+        const = -(ld(cQ) - linalg.logdet_spd(Qp)) - d + (Qp_inv * Qq).sum(dim=(-1, -2))                # [B, T-1]
+        m, chol = e1[:, :-1], tape.cholesky(cov[:, :-1])
+
+        def sq(x):                                                                                      # x [H^d, B, T-1, d]
+            diff = x + dt * sde.drift(x) - ((A @ x[..., None])[..., 0] + b)
+            return ((diff @ Qp_inv) * diff).sum(-1)
+        path = 0.5 * (mvnquad(sq, m, chol, 20) + const).sum(-1)
+        # KL[q(x0) || p(x0)]
+        p_mu = torch.as_tensor(self.prior_initial_state[0], dtype=torch.float64, device=self.device)
+        P0 = torch.as_tensor(self.prior_initial_state[1], dtype=torch.float64, device=self.device)
+        P0inv = linalg.spd_inverse(P0)
+        S0 = cP0 @ cP0.transpose(-1, -2)
+        dm = p_mu - mu0
+        kl0 = 0.5 * ((P0inv * S0).sum(dim=(-1, -2)) + ((dm @ P0inv) * dm).sum(-1) - d + linalg.logdet_spd(P0) - ld(cP0))
+        return path + kl0
+
+    def _expectations_natural(self):
+        pl, T = self.plan, self.T
+        q = self._refresh(want_sub=True, want_marginals=True)
+        mu, cov, sub = pl.unpack(VEC, q["mu"]), pl.unpack(SYM, q["Sig"]), pl.unpack(FULL, q["Sub"], T - 1)
+        return mu, cov + mu[..., :, None] * mu[..., None, :], sub + mu[:, 1:, :, None] * mu[:, :-1, None, :]
+
+    def KL_q_p(self):
+        with torch.no_grad():
+            return self._kl_from_expectations(*self._expectations_natural())
+
+    def grad_kl_wrt_exp_param(self):
+        """(KL [B], (d/d eta_lin, d/d eta_diag, d/d eta_sub) packed) (variational_cvi_sde.py:488-493)."""
+        pl = self.plan
+        eta = [e.detach().requires_grad_(True) for e in self._expectations_natural()]
+        kl = self._kl_from_expectations(*eta)
+        g1, gd, gs = torch.autograd.grad(kl.sum(), eta)
+        gd = 0.5 * (gd + gd.transpose(-1, -2))
+        return kl.detach(), (pl.pack(VEC, g1), pl.pack(SYM, gd), pl.pack(FULL, gs.contiguous()))
+
+    def update_girsanov_sites(self, lr: float):
+        """g <- g + lr (scatter(data sites) - dKL/d eta) (variational_cvi_sde.py:279-299); theta_q = theta_prior + g + data moves by
+        the same increment."""
+        pl = self.plan
+        _, (g1, gd, gs) = self.grad_kl_wrt_exp_param()
+        tq = self.full_sites()
+        for qq, gg in ((tq.lin, g1), (tq.diag, gd), (tq.sub, gs)):
+            pl.lincomb(qq, 1.0, qq, -float(lr), gg)
+        pl.scatter_nodes_pair(tq.lin, tq.diag, self.obs_node_ids, self.data_nat1, self.data_nat2, scale=lr)
+        self._q = None
+        self._obs_fresh = False
+        self._started = True
+
+
 def tranform_girsanov_sites(plan, girsanov_sites, current_prior_nat, new_prior_nat):
     """
     g <- g + theta(current prior) - theta(new prior), in place (sde_utils.py:550-568; the reference's spelling).
