@@ -224,6 +224,77 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
     if (bad) flag_not_pd(a.info, a.lv.level, lane);
 }
 
+// ---- the P-form of the level-0 factor --------------------------------------------------------------------------------------------------
+// The cq sweeps keep, per node, P_t = F_t^{-1} = L_t^{-T} L_t^{-1} (packed lower triangle, in the array the dense route calls L) and
+// z_t = L_t^{-T} y_t (in the array it calls y) instead of the Cholesky factor and the forward-substituted right-hand side: the two
+// backward sweeps of a step -- latency-bound at one wavefront per SIMD -- used to rebuild exactly these from L_t (6 reciprocals, a
+// triangular inverse, X^T X and a transposed substitution per node, ~200 of their 1 450 / 1 800 instructions), while the forward sweep
+// is bandwidth-bound with issue slots to spare; the arithmetic that produces P and z is the same, it moved.  With
+// S = diag(theta_sub) + sOff (1 1^T - I) (csrc header above) the products with S are a row scaling plus a rank-one term:
+//   forward   C = (aS S) P (aS S)^T,  c = (aS S) z                                   (was: G = aS S L^{-T} by substitution, G G^T, G y)
+//   backward  H = aS S P,  Sigma_{t+1,t} = -Sigma_{t+1} H,  Sigma_t = P - Sigma_{t+1,t}^T H,  x_t = z_t - P (aS S x_{t+1}).
+template <int D>
+MFGM_DEV void cq_carry(const double (&Pm)[MFGM_NTRI(D)], const double (&z)[D], const double (&sd)[D], double aS, double sOff,
+                       double (&C)[MFGM_NTRI(D)], double (&c)[D]) {
+    if (D == 1) sOff = 0.0;                 // a 1 x 1 block has no off-diagonal entry: whatever the state carries there is not a value
+    const double cs = aS * sOff;
+    double e[D], u[D], sig = 0.0, sz = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        e[i] = aS * (sd[i] - sOff);
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += Pm[six(k, i)];
+        u[i] = t;
+        sig += t;
+        sz += z[i];
+    }
+    const double c2 = cs * cs * sig;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double wi = cs * e[i] * u[i];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) C[tix(i, j)] = __builtin_fma(e[i] * e[j], Pm[tix(i, j)], wi + __builtin_fma(cs * e[j], u[j], c2));
+        c[i] = __builtin_fma(e[i], z[i], cs * sz);
+    }
+}
+// one step of the backward sweeps: Sigma_{t+1} (Sn), x_{t+1} (xn) -> Sigma_t (Sig), Sigma_{t+1,t} (Ssub), x_t (x holds z_t on entry)
+template <int D>
+MFGM_DEV void backward_p_step(const double (&Pm)[MFGM_NTRI(D)], const double (&sd)[D], double sOff, double aS, const double (&Sn)[MFGM_NTRI(D)],
+                              const double (&xn)[D], double (&Sig)[MFGM_NTRI(D)], double (&Ssub)[D * D], double (&x)[D]) {
+    if (D == 1) sOff = 0.0;
+    const double cs = aS * sOff;
+    double e[D], u[D], H[D * D], tg[D], sx = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        e[i] = aS * (sd[i] - sOff);
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += Pm[six(k, i)];
+        u[i] = cs * t;
+        sx += xn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) H[i * D + j] = __builtin_fma(e[i], Pm[six(i, j)], u[j]);
+        tg[i] = __builtin_fma(e[i], xn[i], cs * sx);
+    }
+    gemm_sym_full<D>(Sn, H, Ssub);
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) Ssub[k] = -Ssub[k];
+#pragma unroll
+    for (int k = 0; k < MFGM_NTRI(D); ++k) Sig[k] = Pm[k];
+    gemm_tn_sym_acc<D>(Ssub, H, -1.0, Sig);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double t = x[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) t = __builtin_fma(-Pm[six(i, k)], tg[k], t);
+        x[i] = t;
+    }
+}
+
 // ---- forward -------------------------------------------------------------------------------------------------------------------
 // forward_body<D, true, false, true> on the cq state (L_{t+1,t} is never stored).  A node's record is requested one step ahead; its
 // slot two steps ahead, so that the gather of the site's linear part rides with the record.
@@ -311,7 +382,7 @@ static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q)
     }
     for (int s = 0; s < R; ++s) {
         if (s < len) {
-            double F[ET], G[EF], h[D];
+            double F[ET], h[D];
             const double cnt = (sA >= 0) ? 1.0 : 0.0;
             const bool has_next = (p * R + s + 1 < n);
 #pragma unroll
@@ -321,10 +392,9 @@ static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q)
                     const double dn = __builtin_fma(cnt, ssym[tix(i, j)], (i == j) ? rn[D + i] : q.dOff);
                     F[tix(i, j)] = __builtin_fma(a.aD, dn, -C[tix(i, j)]);
                 }
+            double sdn[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) G[i * D + j] = has_next ? a.aS * ((i == j) ? rn[2 * D + i] : q.sOff) : 0.0;
+            for (int i = 0; i < D; ++i) sdn[i] = has_next ? rn[2 * D + i] : 0.0;      // (the chain's last node has no transition: its slot is not read)
 #pragma unroll
             for (int e = 0; e < D; ++e) h[e] = __builtin_fma(a.aR, rn[e] + sln[e], -c[e]);
             if (s + 1 < len) {
@@ -341,16 +411,26 @@ static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q)
             double invd[D];
             chol_inplace<D>(F, invd, bad);
             trsv_lower<D>(F, invd, h);
-            trsm_right_lower_t<D>(F, invd, G);
-            st_node<ET>(a.Lg, R, s, me, F);
-            st_node<D>(a.yg, R, s, me, h);
-            syrk_set<D>(G, C);
-            gemv<D>(G, h, c);
 #pragma unroll
             for (int j = 0; j < D; ++j) la.mul(F[tix(j, j)]);
             la.renorm();
 #pragma unroll
             for (int j = 0; j < D; ++j) quad = __builtin_fma(h[j], h[j], quad);
+            // P-form of the factor (cq_pform below): P = F^{-1} = L^{-T} L^{-1} and z = L^{-T} y go to the factor arrays
+            double X[ET], Pm[ET], z[D];
+            tri_inverse<D>(F, invd, X);
+            tri_t_tri<D>(X, Pm);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = i; k < D; ++k) t = __builtin_fma(X[tix(k, i)], h[k], t);
+                z[i] = t;
+            }
+            st_node<ET>(a.Lg, R, s, me, Pm);
+            st_node<D>(a.yg, R, s, me, z);
+            // carried to the next node: C = (aS S) P (aS S)^T, c = (aS S) z with S = diag(theta_sub) + sOff (1 1^T - I)
+            cq_carry<D>(Pm, z, sdn, has_next ? a.aS : 0.0, q.sOff, C, c);
         }
     }
     if (a.part) {
@@ -366,23 +446,23 @@ template <int D>
 MFGM_DEV void backward_s_left_cq(const SweepArgs& a, const CqArgs& q, int R, LaneRef left, const double (&Sn)[MFGM_NTRI(D)],
                                  double (&Gd)[D], double (&SnH)[D * D]) {
     constexpr int ET = MFGM_NTRI(D);
-    double Lt[ET], invd[D], X[ET], H[D * D], Pm[ET], G[D * D];
-    ld_node<ET>(a.Lg, R, R - 1, left, Lt);
+    double H[D * D], Pm[ET], e[D], u[D];
+    ld_node<ET>(a.Lg, R, R - 1, left, Pm);                   // P-form: the array holds P = F^{-1}
     ld_part<3 * D, 2 * D, D>(q.dyn, R, R - 1, left, Gd);
-    cq_sub<D>(Gd, q.sOff, G);
+    const double so = (D == 1) ? 0.0 : q.sOff;
+    const double cs = a.aS * so;
 #pragma unroll
-    for (int j = 0; j < D; ++j) invd[j] = rcp_nr(Lt[tix(j, j)]);
-    tri_inverse<D>(Lt, invd, X);
-    tri_t_tri<D>(X, Pm);
+    for (int i = 0; i < D; ++i) {
+        e[i] = a.aS * (Gd[i] - so);
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += Pm[six(k, i)];
+        u[i] = cs * t;
+    }
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], Pm[six(k, j)], t);
-            H[i * D + j] = a.aS * t;
-        }
+        for (int j = 0; j < D; ++j) H[i * D + j] = __builtin_fma(e[i], Pm[six(i, j)], u[j]);
     gemm_sym_full<D>(Sn, H, SnH);
 }
 
@@ -484,12 +564,11 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov_cq(SweepArgs a,
     }
     for (int s = R - 2; s >= 0; --s) {
         if (s < len - 1) {
-            double Lt[ET], G[EF], x[D], Gd[D], adc[D], l1c[D];
+            double Lt[ET], x[D], Gd[D], adc[D], l1c[D];
 #pragma unroll
             for (int e = 0; e < ET; ++e) Lt[e] = Ln[e];
 #pragma unroll
             for (int e = 0; e < D; ++e) { Gd[e] = Gdn[e]; x[e] = yn[e]; adc[e] = adn[e]; l1c[e] = l1n[e]; }
-            cq_sub<D>(Gd, q.sOff, G);
             if (s > 0) {
                 ld_node<ET>(a.Lg, R, s - 1, me, Ln);
                 ld_part<E3, 2 * D, D>(q.dyn, R, s - 1, me, Gdn);
@@ -497,9 +576,8 @@ static __global__ __launch_bounds__(64) void k_backward_girsanov_cq(SweepArgs a,
                 ld_part<E3, 0, D>(q.dyn, R, s, me, l1n);
                 ld_node<D>(a.yg, R, s - 1, me, yn);
             }
-            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET], tg[D];
-            backward_s_head<D>(Lt, G, a.aS, xn, invd, X, Sig, H, tg);
-            backward_s_tail<D>(Lt, invd, X, a.aS, Sn, H, tg, Sig, Ssub, x);
+            double Ssub[EF], Sig[ET];
+            backward_p_step<D>(Lt, Gd, q.sOff, a.aS, Sn, xn, Sig, Ssub, x);
             double v[D], c[D], lin[D], dg[D], sb[D], wd[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) { v[i] = Sig[tix(i, i)]; c[i] = Ssub[i * D + i]; }
@@ -623,22 +701,20 @@ static __global__ __launch_bounds__(64) void k_backward_kl_cq(SweepArgs a, SdePa
     }
     for (int s = R - 2; s >= 0; --s) {
         if (s < len - 1) {
-            double Lt[ET], G[EF], x[D], Gd[D];
+            double Lt[ET], x[D], Gd[D];
 #pragma unroll
             for (int e = 0; e < ET; ++e) Lt[e] = Ln[e];
 #pragma unroll
             for (int e = 0; e < D; ++e) { Gd[e] = Gdn[e]; x[e] = yn[e]; }
             const int sc = sn;
-            cq_sub<D>(Gd, q.sOff, G);
             if (s > 0) {
                 ld_node<ET>(a.Lg, R, s - 1, me, Ln);
                 ld_part<E3, 2 * D, D>(q.dyn, R, s - 1, me, Gdn);
                 ld_node<D>(a.yg, R, s - 1, me, yn);
                 if (obs) sn = cq_slot(q.slot, R, s - 1, me);
             }
-            double invd[D], X[ET], H[EF], Ssub[EF], Sig[ET], tg[D];
-            backward_s_head<D>(Lt, G, a.aS, xn, invd, X, Sig, H, tg);
-            backward_s_tail<D>(Lt, invd, X, a.aS, Sn, H, tg, Sig, Ssub, x);
+            double Ssub[EF], Sig[ET];
+            backward_p_step<D>(Lt, Gd, q.sOff, a.aS, Sn, xn, Sig, Ssub, x);
             if (keep) {
                 st_node<D>(a.mug, R, s, me, x);
                 st_node<ET>(a.Sigg, R, s, me, Sig);
