@@ -502,14 +502,18 @@ def bench_sparse(h, data_rank):
         form = f.get("form", 0)
         fused = m._fused_theta()       # the passes read the prior naturals + the sites instead of materialised posterior naturals
         null = None
+        packed = fused and getattr(m, "_packed", False)      # the sites' resident form: quadrant-packed (include/mfgm.h)
         if fused:
             pn = m._prior_natural()
-            lin, diag, sub, s1, s2 = pn["lin"], pn["diag"], pn["sub"], m.nat1, m.nat2
+            lin, diag, sub, s1, s2 = pn["lin"], pn["diag"], pn["sub"], m.nat1, (m._nat2q if packed else m.nat2)
         else:
             (lin, diag, sub), s1, s2 = m._theta(), None, None
 
         def stage(which):
-            if which < 2:
+            if which < 2 and packed:
+                rc = lib.mfgm_wide_stage_q(pl.h, which, _ptr(diag), _ptr(sub), _ptr(lin), -2.0, -1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]),
+                                           _ptr(f["y"]), _ptr(s1), _ptr(s2), _ptr(pl.ws), _ptr(pl.info), _stream())
+            elif which < 2:
                 rc = lib.mfgm_wide_stage(pl.h, form, which, _ptr(diag), _ptr(sub), _ptr(lin), -2.0, -1.0, 1.0, _ptr(f["L"]), _ptr(f["G"]),
                                          _ptr(f["y"]), null, null, null, _ptr(s1), _ptr(s2), _ptr(pl.ws), _ptr(pl.info), _stream())
             else:
@@ -519,7 +523,9 @@ def bench_sparse(h, data_rank):
 
         pre = "kmi" if form == 1 else "km"
         EF = d * d
-        rd = (2 * EF + d) + (3 * EF + 2 * d) if fused else (2 * EF + d)      # fused: prior naturals + three site quadrants + site vectors
+        ETq = d * (d + 1) // 2
+        # fused: prior naturals + the site quadrants a node reads (packed: two triangles + one full block) + site vectors
+        rd = ((2 * EF + d) + ((2 * ETq + EF) if packed else 3 * EF) + 2 * d) if fused else (2 * EF + d)
         rows = [h.roofline(f"mfgm::{pre}_{name}", what, h.timed(lambda w=w: stage(w)), 8 * dbl * M, 1, out["ms_per_step"])
                 for name, w, dbl, what in (
                     ("forward<1, true, false, true>", 1, rd + (2 * EF + d),

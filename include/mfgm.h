@@ -358,6 +358,22 @@ int mfgm_sparse_factor(const mfgm_plan* plan, const double* nat1, const double* 
 int mfgm_sparse_factor_phase(const mfgm_plan* plan, int phase, const double* nat1, const double* nat2, const double* plin,
                              const double* pdiag, const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws,
                              int* info, void* stream);
+/* The QUADRANT-PACKED site tensor nat2q [M + 1, QS], QS = d (d + 1) + d^2: per site the upper-left block of the symmetric [2d, 2d]
+ * matrix as a packed lower triangle (row-major, ET = d (d + 1) / 2 entries), the lower-left block in full (d x d, rows = second state
+ * of the pair), the lower-right block as a packed lower triangle; the upper-right block is the transpose of the lower-left one and is
+ * not stored.  The resident form of SparseCVIGaussianProcess's sites on the wide path (the reference's `sites.nat2`,
+ * sparse_variational_cvi.py:96-110, is materialised from it on demand): 528 instead of 1 024 doubles per site at d = 16 for the
+ * site update and for the two factor passes that read the sites.
+ *   mfgm_sparse_factor_q       mfgm_sparse_factor (phase -1) / mfgm_sparse_factor_phase (phase 0, 1) on nat2q
+ *   mfgm_sparse_site_update_q  mfgm_sparse_site_update on nat2q
+ *   mfgm_wide_stage_q          one level-0 pass alone (which = 0 reduce, 1 forward; inverse form), for profiling */
+int mfgm_sparse_factor_q(const mfgm_plan* plan, int phase, const double* nat1, const double* nat2q, const double* plin, const double* pdiag,
+                         const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                         void* stream);
+int mfgm_sparse_site_update_q(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2q,
+                              void* stream);
+int mfgm_wide_stage_q(const mfgm_plan* plan, int which, const double* D, const double* S, const double* r, double aD, double aS, double aR,
+                      double* L, double* G, double* y, const double* site1, const double* site2q, void* ws, int* info, void* stream);
 /* After mfgm_packed_selinv_form on a shared chain: the marginal (Sig [T, d, d], x [T, d] or NULL) of the separator on the left of the
  * owned node range, node_lo - 1, copied from the replicated exchange level -- the pair marginal of the first owned interval needs it
  * (conditionals.py:380-421 with the left conditioning state owned by the neighbour).  No-op on the first process. */

@@ -108,6 +108,9 @@ EXPORTS = {
                         + [ctypes.c_void_p] * 11),
     "mfgm_sparse_predict_kl": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 5),
     "mfgm_sparse_factor": (ctypes.c_int, [ctypes.c_void_p] * 14),
+    "mfgm_sparse_factor_q": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 13),
+    "mfgm_sparse_site_update_q": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_double] + [ctypes.c_void_p] * 3),
+    "mfgm_wide_stage_q": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 8),
     "mfgm_sparse_factor_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 13),
     "mfgm_plan_shard_left_marginal": (ctypes.c_int, [ctypes.c_void_p] * 5),
     "mfgm_batched_cholesky": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4),

@@ -92,6 +92,22 @@ int mfgm_cond_predict(int M, int d, int N, const int* idx, const double* P, cons
     return 0;
 }
 
+int mfgm_sparse_site_update_q(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2q,
+                              void* stream) {
+    if (!sparse_ok(data) || !nat1 || !nat2q || (data->N > 0 && (!g1 || !g2))) return 1;
+    const int d = data->d, QS = d * (d + 1) + d * d;
+    const size_t shmem = sizeof(double) * kSitesChunk * (2 * d + 2);
+    const SparseArgs sa = sparse_args(data);
+    const dim3 grid((sa.m_hi - sa.m_lo + kSitesQG - 1) / kSitesQG);
+    const int ne = (QS + 255) / 256;
+#define SITESQ(NE_) hipLaunchKernelGGL((k_sparse_sites_q<NE_>), grid, dim3(256), shmem, (hipStream_t)stream, sa, g1, g2, lr, nat1, nat2q)
+    if (ne <= 1) SITESQ(1); else if (ne <= 2) SITESQ(2); else if (ne <= 3) SITESQ(3); else if (ne <= 4) SITESQ(4);
+    else if (ne <= 8) SITESQ(8); else return 1;
+#undef SITESQ
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 int mfgm_sparse_site_update(const mfgm_sparse_data* data, const double* g1, const double* g2, double lr, double* nat1, double* nat2,
                             void* stream) {
     if (!sparse_ok(data) || !nat1 || !nat2 || (data->N > 0 && (!g1 || !g2))) return 1;

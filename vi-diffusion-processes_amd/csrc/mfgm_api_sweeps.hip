@@ -739,6 +739,25 @@ int mfgm_sparse_factor_phase(const mfgm_plan* plan, int phase, const double* nat
                        nat2);
 }
 
+int mfgm_sparse_factor_q(const mfgm_plan* plan, int phase, const double* nat1, const double* nat2q, const double* plin, const double* pdiag,
+                         const double* psub, double* L, double* G, double* y, double* logdet, double* quad, void* ws, int* info,
+                         void* stream) {
+    if (!plan || !nat1 || !nat2q || !pdiag || !psub || !L || !G || !y || !info || !ws || phase < -1 || phase > 1) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide || P.B != 1 || (phase < 0) != (P.shard_level < 1)) return 1;
+    return wide_factor(P, pdiag, psub, plin, -2.0, -1.0, 1.0, L, G, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, phase, 1, nat1,
+                       nat2q, 1);
+}
+
+int mfgm_wide_stage_q(const mfgm_plan* plan, int which, const double* D, const double* S, const double* r, double aD, double aS, double aR,
+                      double* L, double* G, double* y, const double* site1, const double* site2q, void* ws, int* info, void* stream) {
+    if (!plan || !L || !G || !y || !info || !ws || !D || !S || !site1 || !site2q || which < 0 || which > 1) return 1;
+    const Plan& P = plan->p;
+    if (!P.wide) return 1;
+    return wide_stage(P, 1, which, D, S, r, aD, aS, aR, L, G, y, nullptr, nullptr, nullptr, (double*)ws, info, (hipStream_t)stream, site1,
+                      site2q, 1);
+}
+
 int mfgm_plan_shard_left_marginal(const mfgm_plan* plan, double* Sig, double* x, const void* ws, void* stream) {
     if (!plan || !Sig || !ws) return 1;
     const Plan& P = plan->p;

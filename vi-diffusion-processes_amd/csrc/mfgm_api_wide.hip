@@ -118,7 +118,7 @@ static __global__ void k_carry_restore(int d, int n, int q, double* __restrict__
 // the exchange level's inputs over the processes);  phase 1: everything after.
 int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st,
-                int phase, int form, const double* site1, const double* site2) {
+                int phase, int form, const double* site1, const double* site2, int site_packed) {
     if (form != 0 && form != 1) return 1;
     if ((site1 != nullptr) != (site2 != nullptr) || (site2 && (form != 1 || P.B != 1))) return 1;
     const bool has_rhs = (rg != nullptr) || (site1 != nullptr);
@@ -135,7 +135,7 @@ int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double*
             a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
             a.Lg = Lg; a.Gg = Gg; a.yg = yg;
             a.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
-            a.site1 = site1; a.site2 = site2;
+            a.site1 = site1; a.site2 = site2; a.site_packed = site_packed;
         }
         wide_bind(P, l, ws, a);
         return a;
@@ -214,7 +214,7 @@ int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double*
 // one level-0 kernel alone (which 0 reduce, 1 forward, 2 backward) with the coarser levels already in ws
 int wide_stage(const Plan& P, int form, int which, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                double* Lg, double* Gg, double* yg, double* Sig, double* Sub, double* x, double* ws, int* info, hipStream_t st,
-               const double* site1, const double* site2) {
+               const double* site1, const double* site2, int site_packed) {
     if ((form != 0 && form != 1) || which < 0 || which > 2) return 1;
     if ((site1 != nullptr) != (site2 != nullptr) || (site2 && (form != 1 || P.B != 1))) return 1;
     const int K = P.nlevels - 1;
@@ -225,7 +225,7 @@ int wide_stage(const Plan& P, int form, int which, const double* Dg, const doubl
     a.Dg = Dg; a.Sg = Sg; a.rg = rg; a.aD = aD; a.aS = aS; a.aR = aR;
     a.Lg = Lg; a.Gg = Gg; a.yg = yg;
     if (which == 2) { a.Sigg = Sig; a.Subg = Sub; a.mug = x; }
-    a.site1 = site1; a.site2 = site2;
+    a.site1 = site1; a.site2 = site2; a.site_packed = site_packed;
     wide_bind(P, 0, ws, a);
     if (which < 2) return wide_dispatch(P.d, which, a, rg != nullptr || site1 != nullptr, false, K > 0, false, st, form);
     return wide_dispatch(P.d, 2, a, yg != nullptr, false, K > 0, Sub != nullptr, st, form);

@@ -51,12 +51,12 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // mfgm_api_wide.hip
 int wide_factor(const Plan& P, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                 double* Lg, double* Gg, double* yg, double* logdet, double* quad, double* ws, int* info, hipStream_t st,
-                int phase = -1, int form = 0, const double* site1 = nullptr, const double* site2 = nullptr);
+                int phase = -1, int form = 0, const double* site1 = nullptr, const double* site2 = nullptr, int site_packed = 0);
 int wide_selinv(const Plan& P, const double* Lg, const double* Gg, const double* yg, double* Sig, double* Sub, double* x,
                 double* ws, hipStream_t st, int form = 0);
 int wide_stage(const Plan& P, int form, int which, const double* Dg, const double* Sg, const double* rg, double aD, double aS, double aR,
                double* Lg, double* Gg, double* yg, double* Sig, double* Sub, double* x, double* ws, int* info, hipStream_t st,
-               const double* site1 = nullptr, const double* site2 = nullptr);
+               const double* site1 = nullptr, const double* site2 = nullptr, int site_packed = 0);
 int wide_ssm_to_naturals(const Plan& P, const double* A, const double* off, const double* chol, double cD, double cS, double* lin,
                          double* diag, double* sub, double* sumlogchol, double* ws, hipStream_t st);
 int wide_kl_terms(const Plan& P, const double* Sig, const double* Sub, const double* mu, const double* Pd, const double* Ps,

@@ -309,6 +309,29 @@ MFGM_DEV RawMat<NT> ld_raw(const double* __restrict__ base, int ld, int row0, in
             }
     return m;
 }
+// quadrant `quad` (0: upper left = first state of the pair, 1: lower left = second x first, 2: lower right = second state) of site m,
+// from either layout of the site tensor (WideArgs::site_packed)
+template <int NT, bool TRANSPOSED>
+MFGM_DEV RawMat<NT> ld_site_raw(const WideArgs& a, int m, int quad, const LaneId& L) {
+    const int d = a.d;
+    if (!a.site_packed) return ld_raw<NT, TRANSPOSED>(a.site2 + (size_t)m * (4 * d * d), 2 * d, quad == 0 ? 0 : d, quad == 2 ? d : 0, d, L);
+    const int ET = d * (d + 1) / 2, EF = d * d;
+    const double* base = a.site2 + (size_t)m * (2 * ET + EF) + (quad == 0 ? 0 : (quad == 1 ? ET : ET + EF));
+    RawMat<NT> o;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * I + L.g + 4 * i, c = 16 * J + L.c;
+                const bool ok = r < d && c < d;
+                const int hi = r > c ? r : c, lo = r > c ? c : r;
+                const int off = (quad == 1) ? (TRANSPOSED ? c * d + r : r * d + c) : hi * (hi + 1) / 2 + lo;
+                o.x[I][J][i] = base[ok ? off : 0];
+            }
+    return o;
+}
 // acc + scale * raw (zero outside d x d; PAD_EYE: plus an identity on the padded diagonal)
 template <int NT, bool PAD_EYE>
 MFGM_DEV Mat<NT> fix_mat(const RawMat<NT>& raw, int d, const LaneId& L, double scale, const Mat<NT>& acc) {
@@ -353,12 +376,12 @@ MFGM_DEV void ld_node_raw(const WideArgs& a, int b, int t, bool want_S, const La
     o.D = ld_raw<NT, false>(wblk(a.Dg, b, n, t, EF), d, 0, 0, d, L);
     if (HAS_CORR) o.Dc = ld_raw<NT, false>(wblk(a.Dcorr, b, n, t, EF), d, 0, 0, d, L);
     if (SITES) {
-        o.Shi = ld_raw<NT, false>(a.site2 + (size_t)(t + 1) * d2 * d2, d2, 0, 0, d, L);
-        o.Slo = ld_raw<NT, false>(a.site2 + (size_t)t * d2 * d2, d2, d, d, d, L);
+        o.Shi = ld_site_raw<NT, false>(a, t + 1, 0, L);
+        o.Slo = ld_site_raw<NT, false>(a, t, 2, L);
     }
     if (want_S) {
         o.S = ld_raw<NT, TRANSPOSED_S>(wblk(a.Sg, b, n, t, EF), d, 0, 0, d, L);
-        if (SITES) o.Ss = ld_raw<NT, TRANSPOSED_S>(a.site2 + (size_t)(t + 1) * d2 * d2, d2, d, 0, d, L);
+        if (SITES) o.Ss = ld_site_raw<NT, TRANSPOSED_S>(a, t + 1, 1, L);
     }
     if (HAS_RHS) {
         if (a.rg) o.r = ld_col_raw<NT>(wblk(a.rg, b, n, t, d), d, L);
@@ -397,15 +420,12 @@ MFGM_DEV ColVec<NT> node_h(const WideArgs& a, const RawNode<NT>& o, const LaneId
 // of its pair, site t as the second
 template <int NT>
 MFGM_DEV Mat<NT> site_diag(const WideArgs& a, int t, const LaneId& L) {
-    const int d = a.d, d2 = 2 * d;
-    const double* hi = a.site2 + (size_t)(t + 1) * d2 * d2;
-    const double* lo = a.site2 + (size_t)t * d2 * d2;
-    return mat_add<NT>(ld_sub<NT, false>(hi, d2, 0, 0, d, L, a.aD), ld_sub<NT, false>(lo, d2, d, d, d, L, a.aD));
+    const Mat<NT> hi = fix_mat<NT, false>(ld_site_raw<NT, false>(a, t + 1, 0, L), a.d, L, a.aD, mat_zero<NT>());
+    return fix_mat<NT, false>(ld_site_raw<NT, false>(a, t, 2, L), a.d, L, a.aD, hi);
 }
 template <int NT, bool TRANSPOSED>
 MFGM_DEV Mat<NT> site_sub(const WideArgs& a, int t, const LaneId& L) {
-    const int d = a.d, d2 = 2 * d;
-    return ld_sub<NT, TRANSPOSED>(a.site2 + (size_t)(t + 1) * d2 * d2, d2, d, 0, d, L, 2.0 * a.aS);
+    return fix_mat<NT, false>(ld_site_raw<NT, TRANSPOSED>(a, t + 1, 1, L), a.d, L, 2.0 * a.aS, mat_zero<NT>());
 }
 template <int NT>
 MFGM_DEV ColVec<NT> site_lin(const WideArgs& a, int t, const LaneId& L) {
@@ -454,7 +474,7 @@ static __global__ __launch_bounds__(64) void kmi_reduce(WideArgs a) {
         RawNode<NT> nx;
         ld_node_raw<NT, HAS_RHS, HAS_CORR, SITES, true>(a, b, t + 1, false, L, nx);
         nx.S = ld_raw<NT, true>(wblk(a.Sg, b, n, t, EF), d, 0, 0, d, L);
-        if (SITES) nx.Ss = ld_raw<NT, true>(a.site2 + (size_t)(t + 1) * (4 * EF), 2 * d, d, 0, d, L);
+        if (SITES) nx.Ss = ld_site_raw<NT, true>(a, t + 1, 1, L);
         sweep_inv<NT>(F, L, la, bad, ldsE);                          // (the determinant is not an output of this pass)
         __builtin_amdgcn_sched_barrier(0);
         const Mat<NT> St = node_S<NT, SITES>(a, nx, L);

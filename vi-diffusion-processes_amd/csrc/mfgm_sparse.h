@@ -374,4 +374,87 @@ static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const
         if (tid < d2 && m0 + gi < a.m_hi) nat1[(size_t)(m0 + gi) * d2 + tid] = __builtin_fma(lr, acc1[gi], (1.0 - lr) * old1[gi]);
 }
 
+// The same update on the QUADRANT-PACKED site tensor nat2q [M + 1, QS], QS = 2 ET + EF (WideArgs::site_packed, mfgm_wide.h: upper-left
+// block as a packed lower triangle, lower-left block in full, lower-right block as a packed lower triangle; the upper-right block of
+// the symmetric [2d, 2d] site is the transpose of the lower-left one and is not stored): 528 instead of 1 024 doubles per site at
+// d = 16, for this read-modify-write and for the two factor passes that read the sites.  A workgroup of 256 threads takes kSitesQG
+// consecutive intervals; thread tid owns the packed entries tid, tid + 256, ... of each.
+constexpr int kSitesQG = 4;
+template <int NE>           // packed entries per thread and site: ceil(QS / 256)
+static __global__ __launch_bounds__(256) void k_sparse_sites_q(SparseArgs a, const double* __restrict__ g1, const double* __restrict__ g2,
+                                                              double lr, double* __restrict__ nat1, double* __restrict__ nat2q) {
+    extern __shared__ double sh[];     // kSitesChunk x (w [2d], g1, g2)
+    const int d = a.d, d2 = 2 * d, ET = d * (d + 1) / 2, EF = d * d, QS = 2 * ET + EF;
+    const int tid = threadIdx.x, m0 = a.m_lo + blockIdx.x * kSitesQG;
+    int rr[NE], cc[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = tid + k * 256;
+        int r = 0, c = 0;
+        if (e < QS) {
+            if (e >= ET && e < ET + EF) {
+                r = d + (e - ET) / d;
+                c = (e - ET) % d;
+            } else {
+                const int t = (e < ET) ? e : e - ET - EF;
+                int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                while (i * (i + 1) / 2 > t) --i;
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                const int j = t - i * (i + 1) / 2;
+                r = (e < ET) ? i : d + i;
+                c = (e < ET) ? j : d + j;
+            }
+        }
+        rr[k] = r;
+        cc[k] = c;
+    }
+    double old[kSitesQG][NE], acc[kSitesQG][NE], old1[kSitesQG], acc1[kSitesQG];
+#pragma unroll
+    for (int gi = 0; gi < kSitesQG; ++gi) {
+        const bool own = (m0 + gi < a.m_hi);
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + k * 256;
+            old[gi][k] = (own && e < QS) ? nat2q[(size_t)(m0 + gi) * QS + e] : 0.0;
+            acc[gi][k] = 0.0;
+        }
+        old1[gi] = (own && tid < d2) ? nat1[(size_t)(m0 + gi) * d2 + tid] : 0.0;
+        acc1[gi] = 0.0;
+    }
+    const int st = d2 + 2;
+#pragma unroll
+    for (int gi = 0; gi < kSitesQG; ++gi) {
+        const int m = min(m0 + gi, a.m_hi - 1) - a.m_lo;
+        const int i0 = a.seg[m], i1 = (m0 + gi < a.m_hi) ? a.seg[m + 1] : i0;
+        for (int c0 = i0; c0 < i1; c0 += kSitesChunk) {
+            const int np = min(kSitesChunk, i1 - c0);
+            __syncthreads();
+            for (int e = tid; e < np * d2; e += 256) {
+                const int pt = e / d2, j = e - pt * d2;
+                sh[pt * st + j] = a.w[(size_t)(c0 + pt) * d2 + j];
+            }
+            if (tid < np) { sh[tid * st + d2] = g1[c0 + tid]; sh[tid * st + d2 + 1] = g2[c0 + tid]; }
+            __syncthreads();
+            for (int pt = 0; pt < np; ++pt) {
+                const double* w = sh + pt * st;
+                const double gg = w[d2 + 1];
+#pragma unroll
+                for (int k = 0; k < NE; ++k) acc[gi][k] = __builtin_fma(gg * w[rr[k]], w[cc[k]], acc[gi][k]);
+                if (tid < d2) acc1[gi] = __builtin_fma(w[d2], w[tid], acc1[gi]);
+            }
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < kSitesQG; ++gi) {
+        if (m0 + gi < a.m_hi) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int e = tid + k * 256;
+                if (e < QS) nat2q[(size_t)(m0 + gi) * QS + e] = __builtin_fma(lr, acc[gi][k], (1.0 - lr) * old[gi][k]);
+            }
+            if (tid < d2) nat1[(size_t)(m0 + gi) * d2 + tid] = __builtin_fma(lr, acc1[gi], (1.0 - lr) * old1[gi]);
+        }
+    }
+}
+
 }  // namespace mfgm

@@ -34,6 +34,10 @@ struct WideArgs {
     // the posterior naturals are formed on load by overlap-adding the sites site1 [n + 1, 2d], site2 [n + 1, 2d, 2d] on pairs of
     // consecutive states (sparse_variational_cvi.py:160-172; what k_sparse_theta would write out)
     const double* site1; const double* site2;
+    // site2 layout: 0 = the reference's [n + 1, 2d, 2d]; 1 = quadrant-packed [n + 1, 2 ET + EF] (ET = d (d + 1) / 2, EF = d^2): the upper
+    // left block (first state of the pair) as a packed lower triangle, the lower left block (second x first state) in full, the lower
+    // right block as a packed lower triangle -- the upper right block is the transpose of the lower left one and is never read
+    int site_packed;
 };
 
 // row i of a d x d block (zero padded), column i of a block

@@ -152,7 +152,7 @@ class ChainShard:
         """Selected inverse on the owned nodes (no communication: the levels from the exchange level up are replicated)."""
         return self.plan.selinv(L, G, y, want_sub=want_sub, form=form)
 
-    def sparse_factor(self, nat1, nat2, plin, pdiag, psub, out=None):
+    def sparse_factor(self, nat1, nat2, plin, pdiag, psub, out=None, packed=False):
         """Inverse-form factorisation of the sparse-CVI posterior of the shared chain straight from the sites (mfgm_sparse_factor_phase;
         sparse_variational_cvi.py:140-174): phase 0 on the owned segments, ONE all-reduce of the exchange region, phase 1.  The sites
         node_lo .. node_hi must be current (site node_hi is the right neighbour's: SparseCVIGaussianProcess passes it on after every
@@ -169,9 +169,10 @@ class ChainShard:
         logdet = torch.empty(pl.B, dtype=torch.float64, device=pl.device)
         args = (_ptr(nat1), _ptr(nat2), _ptr(plin), _ptr(pdiag), _ptr(psub), _ptr(L), _ptr(G), _ptr(y), _ptr(logdet), None, _ptr(pl.ws),
                 _ptr(pl.info), _stream())
-        check(pl.lib.mfgm_sparse_factor_phase(pl.h, 0, *args), "mfgm_sparse_factor_phase(0)")
+        fn = pl.lib.mfgm_sparse_factor_q if packed else pl.lib.mfgm_sparse_factor_phase      # (nat2: the quadrant-packed site tensor)
+        check(fn(pl.h, 0, *args), "sparse factor, phase 0")
         self._allreduce(self.exchange)
-        check(pl.lib.mfgm_sparse_factor_phase(pl.h, 1, *args), "mfgm_sparse_factor_phase(1)")
+        check(fn(pl.h, 1, *args), "sparse factor, phase 1")
         return dict(L=L, G=G, y=y, logdet=logdet, quad=None, form=1)
 
     def left_marginal(self, Sig, x=None):

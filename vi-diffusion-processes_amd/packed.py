@@ -98,17 +98,23 @@ class Plan:
                                                     _ptr(self.info), _stream()), "mfgm_packed_factor_form")
         return dict(L=L, G=G, y=y, logdet=logdet, quad=quad, form=form)
 
-    def sparse_factor(self, nat1, nat2, plin, pdiag, psub, want_logdet=True, out=None):
+    def sparse_factor(self, nat1, nat2, plin, pdiag, psub, want_logdet=True, out=None, packed=False):
         """Inverse-form factorisation of the sparse-CVI posterior straight from the sites (mfgm_sparse_factor; plans with d > 8, one
-        chain): the posterior naturals  prior + overlap-added sites  are formed by the level-0 passes while loading."""
+        chain): the posterior naturals  prior + overlap-added sites  are formed by the level-0 passes while loading.
+        packed: nat2 is the quadrant-packed tensor [M + 1, d (d + 1) + d^2] (mfgm_sparse_factor_q)."""
         out = {} if out is None else out
         L = out.get("L") if out.get("L") is not None else self.empty(TRI)
         G = out.get("G") if out.get("G") is not None else self.empty(FULL)
         y = out.get("y") if out.get("y") is not None else self.empty(VEC)
         self.epoch += 1
         logdet = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_logdet else None
-        _lib.check(self.lib.mfgm_sparse_factor(self.h, _ptr(nat1), _ptr(nat2), _ptr(plin), _ptr(pdiag), _ptr(psub), _ptr(L), _ptr(G), _ptr(y),
-                                               _ptr(logdet), None, _ptr(self.ws), _ptr(self.info), _stream()), "mfgm_sparse_factor")
+        if packed:
+            _lib.check(self.lib.mfgm_sparse_factor_q(self.h, -1, _ptr(nat1), _ptr(nat2), _ptr(plin), _ptr(pdiag), _ptr(psub), _ptr(L), _ptr(G),
+                                                     _ptr(y), _ptr(logdet), None, _ptr(self.ws), _ptr(self.info), _stream()),
+                       "mfgm_sparse_factor_q")
+        else:
+            _lib.check(self.lib.mfgm_sparse_factor(self.h, _ptr(nat1), _ptr(nat2), _ptr(plin), _ptr(pdiag), _ptr(psub), _ptr(L), _ptr(G),
+                                                   _ptr(y), _ptr(logdet), None, _ptr(self.ws), _ptr(self.info), _stream()), "mfgm_sparse_factor")
         return dict(L=L, G=G, y=y, logdet=logdet, quad=None, form=1)
 
     def selinv(self, L, G, y=None, want_sub=True, out=None, form=0):

@@ -32,8 +32,17 @@ class SparseCVIGaussianProcess:
         M, sd = inducing_points.shape[-1], kernel.state_dim
         dev, dt = inducing_points.device, torch.float64
         self._version = 0          # bumped by every site update: keys the cached posterior marginals
+        # Wide path (state dimension > 8): the RESIDENT form of nat2 is the quadrant-packed tensor _nat2q [M + 1, d (d + 1) + d^2]
+        # (include/mfgm.h: the lower triangle of each symmetric [2d, 2d] site, 528 instead of 1 024 doubles at d = 16) that the site
+        # update and the factor passes work on; `nat2` materialises the reference's [M + 1, 2d, 2d] tensor on demand and takes
+        # assignments / in-place edits back (VIDP_PACKED_SITES=0: the dense tensor stays the resident one)
+        self._packed = sd > 8 and inducing_points.dim() == 1 and os.environ.get("VIDP_PACKED_SITES", "1") != "0"
+        self._nat2q, self._nat2, self._nat2_seen = None, None, None
         self.nat1 = torch.zeros((M + 1, 2 * sd), dtype=dt, device=dev)
-        self.nat2 = torch.zeros((M + 1, 2 * sd, 2 * sd), dtype=dt, device=dev)
+        if self._packed:
+            self._nat2q = torch.zeros((M + 1, sd * (sd + 1) + sd * sd), dtype=dt, device=dev)
+        else:
+            self.nat2 = torch.zeros((M + 1, 2 * sd, 2 * sd), dtype=dt, device=dev)
         self._dist_p = None
         self._shard = None
         if shard is not None:
@@ -61,17 +70,49 @@ class SparseCVIGaussianProcess:
         self._nat1 = value
         self._version += 1
 
+    def _pack_index(self):
+        """Flat indices into a [2d, 2d] site of the entries the packed form keeps, in its order: upper-left lower triangle, lower-left
+        block, lower-right lower triangle."""
+        idx = getattr(self, "_pidx", None)
+        if idx is None:
+            d = self._kernel.state_dim
+            d2 = 2 * d
+            i, j = torch.tril_indices(d, d)
+            r, c = torch.meshgrid(torch.arange(d), torch.arange(d), indexing="ij")
+            idx = torch.cat([i * d2 + j, ((d + r) * d2 + c).reshape(-1), (d + i) * d2 + d + j]).to(self._nat1.device)
+            self._pidx = idx
+        return idx
+
+    def _sync_sites(self):
+        """Packed mode: take back a dense `nat2` that was edited in place since it was handed out."""
+        if self._packed and self._nat2 is not None and self._nat2._version != self._nat2_seen:
+            self.nat2 = self._nat2
+
     @property
     def nat2(self):
+        if self._packed:
+            self._sync_sites()
+            if self._nat2 is None:
+                d2 = self._nat1.shape[-1]
+                flat = torch.zeros((self._nat2q.shape[0], d2 * d2), dtype=torch.float64, device=self._nat2q.device)
+                flat[:, self._pack_index()] = self._nat2q
+                low = flat.view(-1, d2, d2)
+                self._nat2 = low + low.transpose(-1, -2) - torch.diag_embed(torch.diagonal(low, dim1=-2, dim2=-1))
+                self._nat2_seen = self._nat2._version
         return self._nat2
 
     @nat2.setter
     def nat2(self, value):
         self._nat2 = value
         self._version += 1
+        if self._packed:
+            self._nat2_seen = value._version
+            self._nat2q = value.reshape(value.shape[0], -1)[:, self._pack_index()].contiguous()
 
     def _key(self):
-        return (self._version, id(self._nat1), self._nat1._version, id(self._nat2), self._nat2._version)
+        self._sync_sites()
+        n2 = self._nat2q if self._packed else self._nat2
+        return (self._version, id(self._nat1), self._nat1._version, id(n2), n2._version)
 
     @property
     def kernel(self):
@@ -180,7 +221,7 @@ class SparseCVIGaussianProcess:
     def _fused_theta(self):
         import os
         return (self._inverse_form() and os.environ.get("VIDP_FUSED_THETA", "1") != "0" and self.nat1.is_contiguous()
-                and self.nat2.is_contiguous())
+                and (self._packed or self.nat2.is_contiguous()))
 
     def _theta(self):
         """Posterior naturals of the current sites, packed (lin, diag, sub): one pass over the sites (mfgm_sparse_theta)."""
@@ -214,11 +255,13 @@ class SparseCVIGaussianProcess:
             # one chain shared between processes: the same passes on the owned segments, one exchange (distributed.ChainShard)
             sh, pn = self._shard, self._prior_natural()
             pl = sh.plan
-            f = sh.sparse_factor(self._nat1, self._nat2, pn["lin"], pn["diag"], pn["sub"], out=bufs["f"])
+            f = sh.sparse_factor(self._nat1, self._nat2q if self._packed else self._nat2, pn["lin"], pn["diag"], pn["sub"], out=bufs["f"],
+                                 packed=self._packed)
         elif self._fused_theta():
             # the level-0 passes of the factorisation form  prior + overlap-added sites  while loading: no posterior naturals in memory
             pn = self._prior_natural()
-            f = pl.sparse_factor(self.nat1, self.nat2, pn["lin"], pn["diag"], pn["sub"], want_logdet=True, out=bufs["f"])
+            f = pl.sparse_factor(self._nat1, self._nat2q if self._packed else self._nat2, pn["lin"], pn["diag"], pn["sub"], want_logdet=True,
+                                 out=bufs["f"], packed=self._packed)
         else:
             lin, diag, sub = self._theta()
             f = pl.factor(diag, sub, lin, aD=-2.0, aS=-1.0, aR=1.0, want_logdet=True, out=bufs["f"], moments_only=self._inverse_form())
@@ -279,8 +322,14 @@ class SparseCVIGaussianProcess:
         _, grads = self.local_objective_and_gradients(fx_mus, fx_covs, observations[data["own"]])
         g1, g2 = grads[0].reshape(-1).contiguous(), grads[1].reshape(-1).contiguous()
         pl = self.dist_p.plan
-        _lib.check(pl.lib.mfgm_sparse_site_update(ctypes.byref(data["struct"]), _ptr(g1), _ptr(g2), float(self.learning_rate), _ptr(self._nat1),
-                                                  _ptr(self._nat2), _stream()), "mfgm_sparse_site_update")
+        self._sync_sites()
+        if self._packed:
+            _lib.check(pl.lib.mfgm_sparse_site_update_q(ctypes.byref(data["struct"]), _ptr(g1), _ptr(g2), float(self.learning_rate),
+                                                        _ptr(self._nat1), _ptr(self._nat2q), _stream()), "mfgm_sparse_site_update_q")
+            self._nat2 = None            # a dense copy handed out earlier is stale now
+        else:
+            _lib.check(pl.lib.mfgm_sparse_site_update(ctypes.byref(data["struct"]), _ptr(g1), _ptr(g2), float(self.learning_rate),
+                                                      _ptr(self._nat1), _ptr(self._nat2), _stream()), "mfgm_sparse_site_update")
         self._version += 1
         if self._shard is not None:
             self._pass_edge_site()
@@ -290,21 +339,27 @@ class SparseCVIGaussianProcess:
         updated -- every process publishes its first owned site, one all-gather of [2d + 4d^2] doubles per process."""
         sh = self._shard
         lo, hi = sh.node_lo, sh.node_hi
-        mine = torch.cat([self._nat1[lo], self._nat2[lo].reshape(-1)])
+        n2 = self._nat2q if self._packed else self._nat2
+        mine = torch.cat([self._nat1[lo], n2[lo].reshape(-1)])
         every = sh.allgather(mine)
         if sh.rank + 1 < sh.world:
             d2 = self._nat1.shape[-1]
             self._nat1[hi].copy_(every[sh.rank + 1, :d2])
-            self._nat2[hi].copy_(every[sh.rank + 1, d2:].view(d2, d2))
+            n2[hi].copy_(every[sh.rank + 1, d2:].view(n2[hi].shape))
+            if self._packed:
+                self._nat2 = None
             self._version += 1
 
     def _gather_sites(self):
         """A shared chain: the sites of every process on every process (dist_q / posterior of the whole chain; not on the training path)."""
         sh = self._shard
-        for t in (self._nat1, self._nat2):
+        self._sync_sites()
+        for t in (self._nat1, self._nat2q if self._packed else self._nat2):
             own = torch.zeros_like(t)
             own[self._m_lo:self._m_hi] = t[self._m_lo:self._m_hi]
             t.copy_(sh.allreduce(own))
+        if self._packed:
+            self._nat2 = None
         self._version += 1
 
     def _update_sites_generic(self, input_data):
