@@ -96,9 +96,10 @@ int mfgm_sparse_site_update_q(const mfgm_sparse_data* data, const double* g1, co
                               void* stream) {
     if (!sparse_ok(data) || !nat1 || !nat2q || (data->N > 0 && (!g1 || !g2))) return 1;
     const int d = data->d, QS = d * (d + 1) + d * d;
-    const size_t shmem = sizeof(double) * kSitesChunk * (2 * d + 2);
+    const size_t shmem = sizeof(double) * kSitesQChunk * (2 * d + 2);
     const SparseArgs sa = sparse_args(data);
-    const dim3 grid((sa.m_hi - sa.m_lo + kSitesQG - 1) / kSitesQG);
+    const int per_wg = kSitesQG * kSitesQRounds;
+    const dim3 grid((sa.m_hi - sa.m_lo + per_wg - 1) / per_wg);
     const int ne = (QS + 255) / 256;
 #define SITESQ(NE_) hipLaunchKernelGGL((k_sparse_sites_q<NE_>), grid, dim3(256), shmem, (hipStream_t)stream, sa, g1, g2, lr, nat1, nat2q)
     if (ne <= 1) SITESQ(1); else if (ne <= 2) SITESQ(2); else if (ne <= 3) SITESQ(3); else if (ne <= 4) SITESQ(4);

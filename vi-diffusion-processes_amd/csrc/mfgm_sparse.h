@@ -379,13 +379,15 @@ static __global__ __launch_bounds__(256) void k_sparse_sites(SparseArgs a, const
 // the symmetric [2d, 2d] site is the transpose of the lower-left one and is not stored): 528 instead of 1 024 doubles per site at
 // d = 16, for this read-modify-write and for the two factor passes that read the sites.  A workgroup of 256 threads takes kSitesQG
 // consecutive intervals; thread tid owns the packed entries tid, tid + 256, ... of each.
-constexpr int kSitesQG = 4;
+constexpr int kSitesQG = 4;          // sites whose old values a workgroup has in flight together
+constexpr int kSitesQRounds = 8;     // rounds of kSitesQG sites per workgroup: the index decode and the launch are paid once per 32 sites
+constexpr int kSitesQChunk = 32;     // data points staged through LDS at a time
 template <int NE>           // packed entries per thread and site: ceil(QS / 256)
 static __global__ __launch_bounds__(256) void k_sparse_sites_q(SparseArgs a, const double* __restrict__ g1, const double* __restrict__ g2,
                                                               double lr, double* __restrict__ nat1, double* __restrict__ nat2q) {
     extern __shared__ double sh[];     // kSitesChunk x (w [2d], g1, g2)
     const int d = a.d, d2 = 2 * d, ET = d * (d + 1) / 2, EF = d * d, QS = 2 * ET + EF;
-    const int tid = threadIdx.x, m0 = a.m_lo + blockIdx.x * kSitesQG;
+    const int tid = threadIdx.x;
     int rr[NE], cc[NE];
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
@@ -408,26 +410,42 @@ static __global__ __launch_bounds__(256) void k_sparse_sites_q(SparseArgs a, con
         rr[k] = r;
         cc[k] = c;
     }
-    double old[kSitesQG][NE], acc[kSitesQG][NE], old1[kSitesQG], acc1[kSitesQG];
-#pragma unroll
-    for (int gi = 0; gi < kSitesQG; ++gi) {
-        const bool own = (m0 + gi < a.m_hi);
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const int e = tid + k * 256;
-            old[gi][k] = (own && e < QS) ? nat2q[(size_t)(m0 + gi) * QS + e] : 0.0;
-            acc[gi][k] = 0.0;
-        }
-        old1[gi] = (own && tid < d2) ? nat1[(size_t)(m0 + gi) * d2 + tid] : 0.0;
-        acc1[gi] = 0.0;
-    }
     const int st = d2 + 2;
+    double old[kSitesQG][NE], nxt[kSitesQG][NE], old1[kSitesQG], nxt1[kSitesQG];
+    auto load = [&](int m0, double (&o)[kSitesQG][NE], double (&o1)[kSitesQG]) {
 #pragma unroll
-    for (int gi = 0; gi < kSitesQG; ++gi) {
-        const int m = min(m0 + gi, a.m_hi - 1) - a.m_lo;
-        const int i0 = a.seg[m], i1 = (m0 + gi < a.m_hi) ? a.seg[m + 1] : i0;
-        for (int c0 = i0; c0 < i1; c0 += kSitesChunk) {
-            const int np = min(kSitesChunk, i1 - c0);
+        for (int gi = 0; gi < kSitesQG; ++gi) {
+            const bool own = (m0 + gi < a.m_hi);
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int e = tid + k * 256;
+                o[gi][k] = (own && e < QS) ? nat2q[(size_t)(m0 + gi) * QS + e] : 0.0;
+            }
+            o1[gi] = (own && tid < d2) ? nat1[(size_t)(m0 + gi) * d2 + tid] : 0.0;
+        }
+    };
+    const int mbase = a.m_lo + blockIdx.x * (kSitesQG * kSitesQRounds);
+    load(mbase, old, old1);
+    for (int rd = 0; rd < kSitesQRounds; ++rd) {
+        const int m0 = mbase + rd * kSitesQG;
+        if (m0 >= a.m_hi) break;
+        // the next round's old values are requested before this round's data points are walked
+        if (rd + 1 < kSitesQRounds) load(m0 + kSitesQG, nxt, nxt1);
+        double acc[kSitesQG][NE], acc1[kSitesQG];
+#pragma unroll
+        for (int gi = 0; gi < kSitesQG; ++gi) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) acc[gi][k] = 0.0;
+            acc1[gi] = 0.0;
+        }
+        // the data points of the round's sites are one contiguous range (the intervals are consecutive): staged through LDS together,
+        // kSitesQChunk at a time -- one pair of barriers per round instead of one per site (with a load -> LDS -> barrier chain per
+        // site the kernel ran at the latency of 32 dependent round trips per workgroup, 2.7 TB/s)
+        int segv[kSitesQG + 1];
+#pragma unroll
+        for (int gi = 0; gi <= kSitesQG; ++gi) segv[gi] = a.seg[min(m0 + gi, a.m_hi) - a.m_lo];
+        for (int c0 = segv[0]; c0 < segv[kSitesQG]; c0 += kSitesQChunk) {
+            const int np = min(kSitesQChunk, segv[kSitesQG] - c0);
             __syncthreads();
             for (int e = tid; e < np * d2; e += 256) {
                 const int pt = e / d2, j = e - pt * d2;
@@ -435,24 +453,31 @@ static __global__ __launch_bounds__(256) void k_sparse_sites_q(SparseArgs a, con
             }
             if (tid < np) { sh[tid * st + d2] = g1[c0 + tid]; sh[tid * st + d2 + 1] = g2[c0 + tid]; }
             __syncthreads();
-            for (int pt = 0; pt < np; ++pt) {
-                const double* w = sh + pt * st;
-                const double gg = w[d2 + 1];
 #pragma unroll
-                for (int k = 0; k < NE; ++k) acc[gi][k] = __builtin_fma(gg * w[rr[k]], w[cc[k]], acc[gi][k]);
-                if (tid < d2) acc1[gi] = __builtin_fma(w[d2], w[tid], acc1[gi]);
+            for (int gi = 0; gi < kSitesQG; ++gi) {
+                const int p0 = max(segv[gi], c0) - c0, p1 = min(segv[gi + 1], c0 + np) - c0;
+                for (int pt = p0; pt < p1; ++pt) {
+                    const double* w = sh + pt * st;
+                    const double gg = w[d2 + 1];
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) acc[gi][k] = __builtin_fma(gg * w[rr[k]], w[cc[k]], acc[gi][k]);
+                    if (tid < d2) acc1[gi] = __builtin_fma(w[d2], w[tid], acc1[gi]);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int gi = 0; gi < kSitesQG; ++gi) {
-        if (m0 + gi < a.m_hi) {
+        for (int gi = 0; gi < kSitesQG; ++gi) {
+            if (m0 + gi < a.m_hi) {
 #pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const int e = tid + k * 256;
-                if (e < QS) nat2q[(size_t)(m0 + gi) * QS + e] = __builtin_fma(lr, acc[gi][k], (1.0 - lr) * old[gi][k]);
+                for (int k = 0; k < NE; ++k) {
+                    const int e = tid + k * 256;
+                    if (e < QS) nat2q[(size_t)(m0 + gi) * QS + e] = __builtin_fma(lr, acc[gi][k], (1.0 - lr) * old[gi][k]);
+                }
+                if (tid < d2) nat1[(size_t)(m0 + gi) * d2 + tid] = __builtin_fma(lr, acc1[gi], (1.0 - lr) * old1[gi]);
             }
-            if (tid < d2) nat1[(size_t)(m0 + gi) * d2 + tid] = __builtin_fma(lr, acc1[gi], (1.0 - lr) * old1[gi]);
+#pragma unroll
+            for (int k = 0; k < NE; ++k) old[gi][k] = nxt[gi][k];
+            old1[gi] = nxt1[gi];
         }
     }
 }
