@@ -229,10 +229,10 @@ def vdp_step_rate(B, T, d, dt, noise, idx, ys, device, steps=10):
 
 def pmc_traffic(kernel_name, B, T, d, build):
     """(HBM bytes per launch of `kernel_name`, source note) from the committed rocprofv3 PMC passes of this bench
-    (profiles/r02_pmc/pmc_traffic.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, read side doubled as the gfx950 guide
+    (profiles/r03_pmc/pmc_traffic.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, read side doubled as the gfx950 guide
     prescribes).  The figure is archival, not measured by this run: it is used only when the file was collected on THIS build of the
     library (mfgm_version()) and this workload size; otherwise (None, why)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc", "pmc_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -243,7 +243,7 @@ def pmc_traffic(kernel_name, B, T, d, build):
     if prof.get("library_build") != build:
         return None, f"the committed PMC profile was collected on library build {prof.get('library_build')!r}, this is {build!r}"
     try:
-        return float(prof["kernels"][kernel_name]["hbm_bytes_per_launch"]), f"profiles/r02_pmc/pmc_traffic.json (build {build})"
+        return float(prof["kernels"][kernel_name]["hbm_bytes_per_launch"]), f"profiles/r03_pmc/pmc_traffic.json (build {build})"
     except KeyError:
         return None, "kernel not in the committed PMC profile"
 

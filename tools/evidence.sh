@@ -1,6 +1,8 @@
 #!/bin/bash
-# End-of-round evidence pass on the GPU box (run through gpurun from the repo root): full GPU test suite, the default bench line, the
-# other configurations, rocprofv3 kernel statistics and the two PMC passes behind roofline.traffic.  Everything lands under gpurun_out/ev/.
+# End-of-round evidence pass on the GPU box (run through gpurun from the repo root): full GPU test suite, the default bench line (every
+# BASELINE configuration in it), rocprofv3 kernel statistics of the headline / c2 / c3 / c5 benches, the FETCH_SIZE / WRITE_SIZE passes
+# behind roofline.traffic (headline, c3, c5) and the MFMA-utilisation pass of the config-5 sweeps.  Everything lands under
+# gpurun_out/ev/; copy what is to be judged into profiles/ (names per round).
 set -o pipefail
 R=/root/repo
 O=$R/gpurun_out/ev
@@ -8,27 +10,39 @@ mkdir -p $O
 cd $R
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $O/pytest_rc.txt
 python -c "import vidp_amd; print(vidp_amd._lib.load().mfgm_version().decode())" 2>/dev/null > $O/version.txt
+V="$(cat $O/version.txt)"
 cd /tmp && export TMPDIR=/tmp
-# PMC passes first (their summary must be in profiles/ when the bench line is printed)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vdp > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vdp > $O/pmc_write.log 2>&1
-F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
-mkdir -p $R/profiles/r02_pmc
-python3 $R/tools/pmc_summarize.py "$F" "$W" 64 100000 6 "$(cat $O/version.txt)" > $R/profiles/r02_pmc/pmc_traffic.json
-cp "$F" $O/fetch_counter_collection.csv; cp "$W" $O/write_counter_collection.csv; cp $R/profiles/r02_pmc/pmc_traffic.json $O/pmc_traffic.json
-# kernel statistics of the headline bench and the line it prints
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-vdp > $O/bench_profiled.json 2> $O/bench_profiled.err
-cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+pmc() {  # name, counters, bench arguments...
+    local name=$1 ctr=$2; shift 2
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$name -- python3 $R/bench.py "$@" > $O/pmc_$name.log 2>&1
+    cp "$(find $O/pmc_$name -name '*counter_collection.csv' | head -1)" $O/${name}_counter_collection.csv
+    rm -rf $O/pmc_$name
+}
+H="--steps 2 --warmup 1 --no-cpu-baseline --no-vdp --no-other-configs"
+pmc h_fetch FETCH_SIZE $H
+pmc h_write WRITE_SIZE $H
+python3 $R/tools/pmc_summarize.py $O/h_fetch_counter_collection.csv $O/h_write_counter_collection.csv 64 100000 6 "$V" > $O/pmc_traffic.json
+mkdir -p $R/profiles/r03_pmc && cp $O/pmc_traffic.json $R/profiles/r03_pmc/pmc_traffic.json   # bench.py reads roofline.traffic from it
+for c in c3 c5; do
+    pmc ${c}_fetch FETCH_SIZE --config $c --steps 2 --warmup 1 --no-cpu-baseline
+    pmc ${c}_write WRITE_SIZE --config $c --steps 2 --warmup 1 --no-cpu-baseline
+done
+python3 $R/tools/pmc_counters.py "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --config c3 --steps 2 --warmup 1 --no-cpu-baseline" 3200000 "$V" $O/c3_fetch_counter_collection.csv $O/c3_write_counter_collection.csv > $O/pmc_traffic_c3.json
+python3 $R/tools/pmc_counters.py "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline" 200000 "$V" $O/c5_fetch_counter_collection.csv $O/c5_write_counter_collection.csv > $O/pmc_traffic_c5.json
+pmc c5_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --config c5 --steps 2 --warmup 1 --no-cpu-baseline
+python3 $R/tools/pmc_counters.py "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline" 200000 "$V" $O/c5_mfma_counter_collection.csv > $O/pmc_mfma_c5.json
+pmc h_sq "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $H
+python3 $R/tools/pmc_counters.py "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py $H" 6400000 "$V" $O/h_sq_counter_collection.csv > $O/pmc_sq_headline.json
+# kernel statistics (and the line each profiled run prints)
+stats() {  # name, bench arguments...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$name -- python3 $R/bench.py "$@" > $O/bench_${name}_profiled.json 2> /dev/null
+    cp "$(find $O/st_$name -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_$name.csv
+    rm -rf $O/st_$name
+}
+stats headline --steps 20 --warmup 3 --no-cpu-baseline --no-vdp --no-other-configs
+for c in c2 c3 c5; do stats $c --config $c --steps 20 --warmup 3 --no-cpu-baseline; done
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-for c in c1 c2 c3 c5; do python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$?"; done
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c5_profiled.json 2> /dev/null
-cp $(find $O/stats_c5 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c5.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 $R/bench.py --config c3 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c3_profiled.json 2> /dev/null
-cp $(find $O/stats_c3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c3.csv
-cd $R
-{ for M in 0 1; do echo "== moments_only=$M (d=16)"; PROBE_MOMENTS_ONLY=$M python tools/perf_probe_wide.py 1 200000 16; echo "== moments_only=$M (d=30)"; PROBE_MOMENTS_ONLY=$M python tools/perf_probe_wide.py 1 20000 30; done; } 2>&1 | grep -v amdgpu.ids > $O/mfma_forms.txt
 python -m pytest tests/test_gpu_accuracy.py -m gpu -s -q 2>&1 | grep -v amdgpu.ids > $O/accuracy_tables.txt
-rm -rf $O/pmc_fetch $O/pmc_write $O/stats $O/stats_c5 $O/stats_c3
-tail -3 $O/pytest_gpu.log; cat $O/bench.json | cut -c1-400
+tail -3 $O/pytest_gpu.log; cut -c1-400 $O/bench.json
