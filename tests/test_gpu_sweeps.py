@@ -296,3 +296,31 @@ def test_not_pd_report_names_the_first_failing_chain_and_nodes(amd, rng, d, mome
     plan.factor(plan.pack(amd.SYM, _dev(diag2)), plan.pack(amd.FULL, _dev(sub2)), moments_only=moments_only)
     assert plan.lib.mfgm_plan_check_info(plan.h, _ptr(plan.info), out, _stream()) == 0
     plan.check_info()
+
+
+@pytest.mark.parametrize("B,T,d,R0,Rup", [(3, 700, 6, 7, 4), (2, 333, 8, 5, 3), (5, 260, 1, 4, 4), (2, 500, 3, 6, 2), (1, 900, 7, 9, 4),
+                                           (4, 150, 2, 3, 4), (3, 410, 4, 5, 4), (2, 290, 5, 4, 5)])
+def test_coarse_row_bodies_agree_with_lane_bodies(amd, rng, monkeypatch, B, T, d, R0, Rup):
+    """Levels whose chains have at most 16 segments run, inside the fused coarse kernels, on 16 lanes per segment (mfgm_rows.h); with
+    MFGM_COARSE_ROWS=0 they run on the lane-per-segment bodies the larger levels use.  Same arrays in, same arrays out: every output of
+    the factorisation and of the selected inverse must agree to rounding (and both with the oracle, by the tests above)."""
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    r = rng.normal(size=(B, T, d))
+    plan = amd.Plan(B, T, d, R0=R0, Rup=Rup)
+    assert plan.nlevels >= 3
+    Dp, Sp, rp = plan.pack(amd.SYM, _dev(diag)), plan.pack(amd.FULL, _dev(sub)), plan.pack(amd.VEC, _dev(r))
+    outs = []
+    for rows in ("16", "0"):
+        monkeypatch.setenv("MFGM_COARSE_ROWS", rows)
+        f = plan.factor(Dp, Sp, rp, want_logdet=True, want_quad=True)
+        plan.check_info()
+        s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True)
+        outs.append([plan.unpack(amd.TRI, f["L"]), plan.unpack(amd.FULL, f["G"], T - 1), plan.unpack(amd.VEC, f["y"]), f["logdet"].clone(),
+                     f["quad"].clone(), plan.unpack(amd.SYM, s["Sig"]), plan.unpack(amd.FULL, s["Sub"], T - 1), plan.unpack(amd.VEC, s["x"])])
+    differs = False
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-9, atol=1e-11)
+        differs |= bool((a != b).any())
+    assert differs or d == 1, "the two routes produced bit-identical arrays: the row bodies did not run"   # 1 x 1 blocks: same operations
+    Ld, Ls = np_btd.cholesky(diag, sub)
+    assert_close(outs[0][0].cpu().numpy(), Ld)

@@ -1,6 +1,7 @@
 // Multi-level drivers of the lane-per-segment sweeps (d <= 8): reduce / forward / backward over the partition levels.
 #include "mfgm_internal.h"
 #include "mfgm_sweeps.h"
+#include "mfgm_rows.h"
 #include "mfgm_girsanov.h"
 #include "mfgm_cq.h"
 #include "mfgm_kf.h"
@@ -92,10 +93,20 @@ int coarse_fuse_from(const Plan& P) {
     return P.nlevels;
 }
 
+// Levels whose chains have at most this many segments run on the 16-lanes-per-segment row bodies (mfgm_rows.h) inside the fused
+// kernels; MFGM_COARSE_ROWS=0 keeps every level on the lane-per-segment bodies (the cross-check of tests/test_gpu_sweeps.py), a value
+// in 1 .. kRowsMaxP lowers the threshold.
+int coarse_rows_p() {
+    // read per launch (a getenv, next to a kernel launch): the cross-check test flips it inside one process
+    const char* e = getenv("MFGM_COARSE_ROWS");
+    if (!e) return kRowsMaxP;
+    return std::max(0, std::min(atoi(e), kRowsMaxP));
+}
+
 template <int D>
 int launch_coarse_backward(const Plan& P, int lf, bool has_rhs, double* ws, hipStream_t st) {
-    if (has_rhs) hipLaunchKernelGGL((k_coarse_backward<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws);
-    else hipLaunchKernelGGL((k_coarse_backward<D, false>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws);
+    if (has_rhs) hipLaunchKernelGGL((k_coarse_backward<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, coarse_rows_p());
+    else hipLaunchKernelGGL((k_coarse_backward<D, false>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, coarse_rows_p());
     MFGM_CHECK_LAUNCH();
     return 0;
 }
@@ -131,8 +142,8 @@ int factor_impl(const Plan& P, const double* Dg, const double* Sg, const double*
         if (rc) return rc;
     }
     if (lf <= K) {
-        if (has_rhs) hipLaunchKernelGGL((k_coarse_factor<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info);
-        else hipLaunchKernelGGL((k_coarse_factor<D, false>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info);
+        if (has_rhs) hipLaunchKernelGGL((k_coarse_factor<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info, coarse_rows_p());
+        else hipLaunchKernelGGL((k_coarse_factor<D, false>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info, coarse_rows_p());
         MFGM_CHECK_LAUNCH();
     }
     for (int l = std::min(K, lf - 1); l >= 0; --l) {
@@ -282,7 +293,7 @@ int cq_factor_impl(const Plan& P, const CqArgs& q, double* Lg, double* yg, doubl
             if (rc) return rc;
         }
         if (lf <= K) {
-            hipLaunchKernelGGL((k_coarse_factor<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info);
+            hipLaunchKernelGGL((k_coarse_factor<D, true>), dim3(P.B), dim3(kCoarseBlock), 0, st, P, lf, ws, info, coarse_rows_p());
             MFGM_CHECK_LAUNCH();
         }
         for (int l = std::min(K, lf - 1); l >= 1; --l) {

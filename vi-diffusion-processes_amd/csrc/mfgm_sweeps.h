@@ -588,60 +588,6 @@ MFGM_HD SweepArgs coarse_level_args(const Plan& P, int l, double* ws, int* info)
     return a;
 }
 
-constexpr int kCoarseBlock = 256;     // one wavefront per SIMD: the level bodies need the whole register file
-
-// reduce l0 .. top-1, then forward top .. l0 (l0 >= 1); grid = B workgroups
-template <int D, bool HAS_RHS>
-static __global__ __launch_bounds__(kCoarseBlock) void k_coarse_factor(Plan P, int l0, double* ws, int* info) {
-    const int K = P.nlevels - 1, b = blockIdx.x;
-    for (int l = l0; l < K; ++l) {
-        const SweepArgs a = coarse_level_args(P, l, ws, info);
-        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
-            const int lane = b * a.lv.P + p;
-            reduce_body<D, HAS_RHS, true>(a, lane, LaneRef::of(lane));
-        }
-        __syncthreads();
-    }
-    {
-        const SweepArgs a = coarse_level_args(P, K, ws, info);
-        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
-            const int lane = b * a.lv.P + p;
-            forward_body<D, HAS_RHS, true, false>(a, lane, LaneRef::of(lane));
-        }
-        __syncthreads();
-    }
-    for (int l = K - 1; l >= l0; --l) {
-        const SweepArgs a = coarse_level_args(P, l, ws, info);
-        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
-            const int lane = b * a.lv.P + p;
-            forward_body<D, HAS_RHS, true, true>(a, lane, LaneRef::of(lane));
-        }
-        __syncthreads();
-    }
-}
-
-// backward top .. l0
-template <int D, bool HAS_RHS>
-static __global__ __launch_bounds__(kCoarseBlock) void k_coarse_backward(Plan P, int l0, double* ws) {
-    const int K = P.nlevels - 1, b = blockIdx.x;
-    {
-        const SweepArgs a = coarse_level_args(P, K, ws, nullptr);
-        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
-            const int lane = b * a.lv.P + p;
-            backward_body<D, HAS_RHS, false, false, false, false, true>(a, lane, LaneRef::of(lane));
-        }
-        __syncthreads();
-    }
-    for (int l = K - 1; l >= l0; --l) {
-        const SweepArgs a = coarse_level_args(P, l, ws, nullptr);
-        for (int p = threadIdx.x; p < a.lv.P; p += kCoarseBlock) {
-            const int lane = b * a.lv.P + p;
-            backward_body<D, HAS_RHS, true, false, false, false, true>(a, lane, LaneRef::of(lane));
-        }
-        __syncthreads();
-    }
-}
-
 // ---- per-chain sum of the per-lane partials ---------------------------------------------------------
 // part: [2*Lpad]; out_logdet[b] = sum_p part[b*P+p]; out_quad[b] likewise.  One wave per chain.
 static __global__ __launch_bounds__(256) void k_sum_partials(const double* part, int P, int Lpad, double* out_logdet,
