@@ -674,3 +674,34 @@ def test_sparse_cvi_assigned_sites_move_the_caches(amd, rng, monkeypatch):
     c.nat1, c.nat2 = b.nat1.clone(), b.nat2.clone()
     np.testing.assert_allclose(eb, float(c.classic_elbo((dev(t), dev(y)))), rtol=1e-8)
     assert abs(eb - ea) > 1e-3 * abs(ea)
+
+
+def test_sparse_cvi_form_follows_prior_conditioning(amd, rng, monkeypatch):
+    """The inverse-form sweeps (the fast route for d > 8) lose ~200 x more digits than the Cholesky form.  The model picks the form from
+    the conditioning of the prior's precision blocks: config 5's grid (dz = 0.1, cond 3.7e10) keeps the inverse form, a three times
+    finer grid (cond 1.1e13, where the inverse form's ELBO is off by up to 0.8 relative in tests/test_gpu_accuracy.py) falls back to the
+    Cholesky form with a warning -- and then agrees with a model forced to the Cholesky form bit for bit."""
+    import warnings
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
+    monkeypatch.delenv("VIDP_SPARSE_INVERSE_FORM", raising=False)
+    M = 80
+    for dz, inverse in ((0.1, True), (0.03, False)):
+        z = np.linspace(0, dz * M, M)
+        t = np.sort(rng.uniform(0, dz * M, size=2 * M))
+        y = (np.sin(3 * t) + 0.1 * rng.normal(size=t.size)).reshape(-1, 1)
+        data = (dev(t), dev(y))
+        g = SparseCVIGaussianProcess(_config5_kernel(K), dev(z), Gaussian(0.01), learning_rate=0.5)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert g._inverse_form() is inverse
+            g.update_sites(data)
+            e = float(g.classic_elbo(data))
+        assert (len([x for x in w if issubclass(x.category, RuntimeWarning) and "Cholesky-form" in str(x.message)]) == 1) is (not inverse)
+        if not inverse:
+            monkeypatch.setenv("VIDP_SPARSE_INVERSE_FORM", "0")
+            h = SparseCVIGaussianProcess(_config5_kernel(K), dev(z), Gaussian(0.01), learning_rate=0.5)
+            h.update_sites(data)
+            assert float(h.classic_elbo(data)) == e
+            monkeypatch.delenv("VIDP_SPARSE_INVERSE_FORM")

@@ -210,13 +210,43 @@ class SparseCVIGaussianProcess:
             self._pn = dict(nat=nat, lin=lin.contiguous(), diag=diag.contiguous(), sub=sub.contiguous(), zeros=pl.zeros(VEC))
         return self._pn
 
+    # the inverse form is used while the prior's precision blocks are conditioned better than this (tests/test_gpu_accuracy.py: at
+    # 3.7e10, config 5's grid, both forms hold 1e-10 on the ELBO; at 1.1e13 the inverse form is 10-1000 x worse than the Cholesky form)
+    INVERSE_FORM_MAX_COND = 1e11
+
     def _inverse_form(self):
         """The marginals come from the inverse-form sweeps (Plan.factor(moments_only=True), d > 8).  They lose ~10 eps cond(F_t) where
         the Cholesky form loses ~0.05 eps cond: on config 5's kernel and grid (rho = dz / lengthscale >= 0.05) the ELBO agrees with the
         oracle to 1e-10 in either form; on grids so fine that the prior precision is numerically singular (rho ~ 0.005, cond 1e15)
-        neither form nor the NumPy oracle is meaningful in fp64.  VIDP_SPARSE_INVERSE_FORM=0 selects the Cholesky form."""
-        import os
-        return self.dist_p.plan.wide and os.environ.get("VIDP_SPARSE_INVERSE_FORM", "1") != "0"
+        neither form nor the NumPy oracle is meaningful in fp64.  So the form follows the conditioning of the prior's precision blocks
+        (a sample of them, once per prior): above INVERSE_FORM_MAX_COND the Cholesky form is used, with a warning.
+        VIDP_SPARSE_INVERSE_FORM=0 / 1 forces the Cholesky / inverse form."""
+        if not self.dist_p.plan.wide:
+            return False
+        forced = os.environ.get("VIDP_SPARSE_INVERSE_FORM")
+        if forced is not None:
+            return forced != "0"
+        pn = self._prior_natural()
+        if "inverse_ok" not in pn:
+            cond = self._prior_block_condition(pn["diag"])
+            pn["inverse_ok"] = cond <= self.INVERSE_FORM_MAX_COND
+            if not pn["inverse_ok"]:
+                import warnings
+                warnings.warn(f"SparseCVIGaussianProcess: the prior's precision blocks have condition number ~{cond:.1e} on this grid; "
+                              "using the Cholesky-form sweeps (slower, ~200x more accurate) instead of the inverse form", RuntimeWarning)
+        return pn["inverse_ok"]
+
+    @staticmethod
+    def _prior_block_condition(diag, samples=128):
+        """Largest 2-norm condition number over a sample of the prior's diagonal precision blocks ([T, d, d], lower triangle valid): evenly
+        spaced nodes plus both ends (on a uniform grid every interior block is the same).  Host side, once per prior."""
+        T = diag.shape[0]
+        idx = torch.unique(torch.cat([torch.linspace(0, T - 1, min(samples, T)).round().long(), torch.tensor([0, max(T - 2, 0), T - 1])]))
+        blk = diag[idx.to(diag.device)].detach().cpu()
+        low = torch.tril(blk)
+        blk = low + torch.tril(blk, -1).transpose(-1, -2)
+        ev = torch.linalg.eigvalsh(blk).abs()
+        return float((ev.max(-1).values / ev.min(-1).values.clamp_min(1e-300)).max())
 
     def _fused_theta(self):
         import os
