@@ -77,10 +77,10 @@ def allgather_(t):
 class ChainShard:
     """
     One long chain over several GPUs (SURVEY 8e second row, config 5): the time axis is cut at segment boundaries of a COARSE level
-    X of the partition (the highest level that still has at least `world` nodes per chain); rank k owns a contiguous range of that
+    X of the partition (the highest level that still has at least 4 x `world` nodes per chain, else `world`); rank k owns a contiguous range of that
     level's nodes and, below it, the segments they stand for.  Every rank eliminates the interior of its range by itself (the
     reduces of the levels 0 .. X-1 on its own segments); the one exchange per factorisation is the sum of the level-X inputs --
-    n_X x (3 d^2 + 2 d) doubles per chain, every entry written by one rank (8 x 800 doubles = 51 KB at config 5) -- after which the
+    n_X x (3 d^2 + 2 d) doubles per chain, every entry written by one rank (32 x 800 doubles = 205 KB at config 5 on 8 ranks) -- after which the
     levels >= X are solved redundantly on every rank and the sweeps back down touch only the owned segments.  Besides that exchange
     only the scalar log-determinant / quadratic-form sums cross ranks.
     Wide plans (8 < d <= 32) only.  Arrays are addressed with global node indices: a rank needs the inputs of its own nodes
@@ -103,7 +103,11 @@ class ChainShard:
         cand = [l for l in range(1, plan.nlevels) if levels[l][0] >= self.world]
         if not cand:
             raise ValueError(f"no level of this plan has {world} nodes per chain to share between the ranks: use a smaller R0")
-        self.level = max(cand)
+        # balance: a level with about `world` nodes deals them out 2 : 1 in the worst case (3 ranks on 8 nodes own 3 / 3 / 2, and a node of a
+        # high level is thousands of level-0 nodes), so prefer the highest level with >= 4 nodes per rank -- the levels from X upwards, solved
+        # on every rank, and the exchange (n_X blocks) stay tiny either way
+        roomy = [l for l in cand if levels[l][0] >= 4 * self.world]
+        self.level = max(roomy) if roomy else max(cand)
         n_x = levels[self.level][0]
         lo, hi = shard_bounds(n_x, self.rank, self.world)
         _lib.check(plan.lib.mfgm_plan_set_shard_level(plan.h, self.level, lo, hi), "mfgm_plan_set_shard_level (wide plans with >= 2 levels only)")
