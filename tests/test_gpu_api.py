@@ -1188,6 +1188,77 @@ def test_full_size_fused_model_steps(amd):
     np.testing.assert_allclose(ea, eb, rtol=1e-9)
 
 
+def test_full_size_steps_against_the_c_port(amd):
+    """
+    Headline size (B = 64, T = 100k, d = 6) and config 3 (VDP, T = 50k) against the ORACLE: the plain-C port of the same steps
+    (oracle/csrc/btd_ref.c: ref_cvi_dp_step / ref_vdp_step, sequential block sweeps, no partition) run on the first 8 trajectories of
+    the same data.  Per-trajectory ELBOs after each of two steps must agree to 1e-9 (north-star bound 1e-5): the partitioned HIP
+    sweeps, the structured state and the fused site updates at the size the bench measures, checked against an independent CPU
+    restatement rather than against themselves.
+    """
+    import gc
+    import torch
+    import bench
+    from oracle import c_ref
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    B, d, dt, noise, Bs = 64, 6, 0.01, 0.1, 8
+    dev_ = torch.device("cuda", 0)
+    Lc = bench.obs_chol(d, noise)
+    Rinv, logdetR = np.linalg.inv(Lc @ Lc.T), 2 * np.sum(np.log(np.diag(Lc)))
+    lik = lambda: MultivariateGaussian(torch.from_numpy(Lc).to(dev_))
+    q = torch.eye(d, dtype=torch.float64)
+
+    # CVI-DP, headline size
+    T = 100000
+    idx, ys = bench.synth_double_well(B, T, d, dt, 50, noise, seed=11)
+    grid = np.arange(T) * dt
+    m = CVISitesSDE(gsde.DoubleWellSDE(q=q), grid, (grid[idx], torch.from_numpy(ys).to(dev_)), lik(),
+                    prior_initial_state=(np.zeros(d), np.eye(d)), plan=amd.Plan(B, T, d))
+    got = []
+    for _ in range(2):
+        m.update_data_sites(0.5)
+        m.update_girsanov_sites(0.1)
+        got.append(host(m.classic_elbo_per_trajectory())[:Bs])
+    m.plan.check_info()
+    del m
+    gc.collect(); torch.cuda.empty_cache()
+    alpha, beta = 1.0 + dt * 4.0, dt * 4.0
+    A = np.broadcast_to((alpha - 3.0 * beta) * np.eye(d), (T - 1, d, d))           # the prior linearised on N(0, I), as the model starts
+    chol = np.concatenate([np.eye(d)[None], np.broadcast_to(np.sqrt(dt) * np.eye(d), (T - 1, d, d))], axis=0)
+    lin, diag, sub = c_ref.ssm_to_naturals(A, np.zeros((T, d)), chol)
+    rep = lambda a: np.broadcast_to(a, (Bs,) + a.shape).copy()
+    st = c_ref.CviDpStepState(rep(lin), rep(diag), rep(sub), idx, ys[:Bs], Rinv, logdetR, alpha, beta, np.ones(d), dt, np.zeros(d), np.eye(d))
+    for k in range(2):
+        st.step(0.5, 0.1)
+        assert np.isfinite(st.elbo).all()
+        np.testing.assert_allclose(got[k], st.elbo, rtol=1e-9)
+    del st
+
+    # VDP, config 3 size
+    T = 50000
+    idx, ys = bench.synth_double_well(B, T, d, dt, 50, noise, seed=12)
+    grid = np.arange(T) * dt
+    m = VariationalMarkovGP((grid[idx], torch.from_numpy(ys).to(dev_)), gsde.DoubleWellSDE(q=q), grid, lik(),
+                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=amd.Plan(B, T, d))
+    m.plan.pack(amd.FULL, (4.0 * torch.eye(d, dtype=torch.float64, device=dev_)).expand(B, T, d, d).contiguous(), out=m.A)
+    mS = m._forward_packed()
+    got = []
+    for _ in range(2):
+        m.update_lagrange_and_param(mS, lr=0.01)
+        mS = m._forward_packed()
+        got.append(host(m.elbo_per_trajectory(mS))[:Bs])
+    m.plan.check_info()
+    sv = c_ref.VdpStepState(np.broadcast_to(4.0 * np.eye(d), (Bs, T - 1, d, d)), np.zeros((Bs, T - 1, d)), idx, ys[:Bs], Rinv, logdetR, 4.0, 4.0,
+                            np.ones(d), dt, np.zeros(d), np.eye(d), stabilize=True)
+    for k in range(2):
+        sv.step(0.01)
+        assert np.isfinite(sv.elbo).all()
+        np.testing.assert_allclose(got[k], sv.elbo, rtol=1e-9)
+
+
 @pytest.mark.parametrize("d,B,T,n_obs", [(1, 2, 40, 5), (3, 3, 77, 9), (6, 2, 131, 300)])
 def test_site_update_and_obs_ve_kernels(amd, rng, d, B, T, n_obs):
     """mfgm_site_update_pair and mfgm_mvn_obs_ve against the torch formulas they replace (blend + difference + scatter; gather +
