@@ -104,6 +104,11 @@ int mfgm_combine_terms(int n_terms, int n, const double* terms, const double* w,
 int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, const double* y, double c,
                  const double* z, void* stream);
 
+/* The damped site update of CVIGaussianProcess.update_sites, theta <- (1 - rho) theta + rho g assigned to BOTH site variables
+ * (variational_cvi.py:364-368, two tf.Variable.assign), in place and in one launch: nat1[i] += w (g1[i] - nat1[i]) for i < n1,
+ * nat2[i] += w (g2[i] - nat2[i]) for i < n2 (flat device arrays). */
+int mfgm_site_lerp(double* nat1, const double* g1, size_t n1, double* nat2, const double* g2, size_t n2, double w, void* stream);
+
 /* Sparse node lists (observation times on the grid): node_ids[i] = b*T + t (int64, device), values natural
  * [n, d] / [n, d, d].  mode 0: gather packed -> values; 1: scatter values -> packed (overwrite);
  * 2: packed += scale*values, and packed2 += scale*values when packed2 != NULL.  Replaces tf.scatter_nd / tf.gather_nd at

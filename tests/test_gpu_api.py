@@ -1188,6 +1188,32 @@ def test_full_size_fused_model_steps(amd):
     np.testing.assert_allclose(ea, eb, rtol=1e-9)
 
 
+def test_site_lerp_kernel(amd, rng):
+    """mfgm_site_lerp (variational_cvi.py:364-368: both site variables assigned (1 - rho) theta + rho g) against the torch formula, on
+    arrays of different lengths; and CVIGaussianProcess.update_sites, which calls it behind torch's back, must still move the version
+    counters the factor caches are keyed on."""
+    import torch
+    from vidp_amd import _lib
+    from vidp_amd.packed import _ptr, _stream
+    for n1, n2 in ((1, 1), (1000, 1000), (70001, 13), (5, 300000)):
+        x1, g1, x2, g2 = (dev(rng.normal(size=n)) for n in (n1, n1, n2, n2))
+        r1, r2 = torch.lerp(x1, g1, 0.3), torch.lerp(x2, g2, 0.3)
+        _lib.check(_lib.load().mfgm_site_lerp(_ptr(x1), _ptr(g1), n1, _ptr(x2), _ptr(g2), n2, 0.3, _stream()), "mfgm_site_lerp")
+        np.testing.assert_allclose(host(x1), host(r1), rtol=1e-15, atol=1e-16)
+        np.testing.assert_allclose(host(x2), host(r2), rtol=1e-15, atol=1e-16)
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.variational_cvi import CVIGaussianProcess
+    t = np.linspace(0, 10, 200) + rng.uniform(0, 0.02, size=200)
+    y = np.sin(t)[:, None] + 0.1 * rng.normal(size=(200, 1))
+    m = CVIGaussianProcess((dev(t), dev(y)), K.Matern52(1.0, 1.0), Gaussian(0.1), learning_rate=0.5)
+    v = (m.sites.nat1._version, m.sites.nat2._version)
+    e0 = float(m.classic_elbo())
+    m.update_sites()
+    assert m.sites.nat1._version > v[0] and m.sites.nat2._version > v[1]
+    assert abs(float(m.classic_elbo()) - e0) > 1e-6 * abs(e0)
+
+
 def test_full_size_steps_against_the_c_port(amd):
     """
     Headline size (B = 64, T = 100k, d = 6) and config 3 (VDP, T = 50k) against the ORACLE: the plain-C port of the same steps

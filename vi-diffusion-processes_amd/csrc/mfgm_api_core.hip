@@ -238,6 +238,27 @@ int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, con
 }
 
 namespace {
+// x <- x + w (g - x) on two arrays in one launch (blockIdx.y picks the array)
+__global__ __launch_bounds__(256) void k_site_lerp(double* __restrict__ x1, const double* __restrict__ g1, size_t n1, double* __restrict__ x2,
+                                                   const double* __restrict__ g2, size_t n2, double w) {
+    double* x = blockIdx.y ? x2 : x1;
+    const double* g = blockIdx.y ? g2 : g1;
+    const size_t n = blockIdx.y ? n2 : n1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = __builtin_fma(w, g[i] - x[i], x[i]);
+}
+}  // namespace
+
+int mfgm_site_lerp(double* nat1, const double* g1, size_t n1, double* nat2, const double* g2, size_t n2, double w, void* stream) {
+    if (!nat1 || !g1 || !nat2 || !g2) return 1;
+    if (n1 == 0 && n2 == 0) return 0;
+    const size_t n = std::max(n1, n2);
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_site_lerp, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, nat1, g1, n1, nat2, g2, n2, w);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
 struct CombineW { double w[8]; };
 // out[i] = c + ce extra[i] + sum_k w[k] terms[k][i]  (NaN when *info != 0: a pivot block was not positive definite), total = sum_i out[i]
 __global__ void k_combine_terms(int n_terms, int n, const double* __restrict__ terms, CombineW w, double c, const double* __restrict__ extra,
