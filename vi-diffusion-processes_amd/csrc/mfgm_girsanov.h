@@ -171,8 +171,7 @@ MFGM_DEV void up_moments(const SweepArgs& a, int b, int q, double (&m)[D], doubl
     const int uP = a.up.P, uR = a.up.R, ul = b * uP + q / uR, us = q % uR;
     const LaneRef uw = LaneRef::of(ul);
     ld_node<D, true>(a.umu, uR, us, uw, m);
-    const size_t node = (size_t)ul * uR + us;                      // node-major layout of the coarser level
-    const double* ps = a.uSig + ((node >> 6) * ET) * 64 + (node & 63);
+    const double* ps = a.uSig + coarse_off<ET>(ul, uR, us);
 #pragma unroll
     for (int i = 0; i < D; ++i) v[i] = ps[tix(i, i) * 64];
 }

@@ -10,9 +10,8 @@
 // contiguous bytes, a whole step of a wavefront is one contiguous run of E*512 bytes, and a wavefront streams
 // its R steps from one contiguous region -- every load and store of the sequential sweeps is fully
 // coalesced while each lane still walks its own piece of the time axis in order.  The separators of level l form the chain of level l+1
-// (n_{l+1} = P_l), until a level has a single segment per chain.  Levels >= 1 live in the plan workspace in the NODE-MAJOR layout
-// (mfgm_sweeps.h, ld_node<E, NM = true>): node = lane * R + s, element e at ((node / 64) * E + e) * 64 + node % 64 -- the
-// separators that 64 consecutive lanes of the level below hand up are one contiguous 512-byte run per element.  Same sizes.
+// (n_{l+1} = P_l), until a level has a single segment per chain.  Levels >= 1 live in the plan workspace in the same layout, with
+// their own lane count and R (mfgm_sweeps.h, coarse_off / ld_node<E, NM = true>).
 #pragma once
 #include <cstddef>
 #include <cstdint>

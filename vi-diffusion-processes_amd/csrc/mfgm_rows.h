@@ -46,14 +46,16 @@ MFGM_DEV double rb(double x, int j) {
     }
 }
 
-// ---- one row of a block of the node-major arrays (i < D; loads are branch-free, stores are the caller's to guard) -----------------
+// ---- one row of a block of the level arrays (i < D; loads are branch-free, stores are the caller's to guard) --------------------------
+// A node is named by (lane, R, s) of its level, as in ld_node<E, true>; At{lane - 1, R, R - 1} is the left separator of segment `lane`.
+struct At { int lane, R, s; };
 template <int E>
-MFGM_DEV const double* nm_node(const double* __restrict__ base, size_t node) { return base + ((node >> 6) * E) * 64 + (node & 63); }
+MFGM_DEV const double* nm_node(const double* __restrict__ base, At n) { return base + coarse_off<E>(n.lane, n.R, n.s); }
 template <int E>
-MFGM_DEV double* nm_node(double* __restrict__ base, size_t node) { return base + ((node >> 6) * E) * 64 + (node & 63); }
+MFGM_DEV double* nm_node(double* __restrict__ base, At n) { return base + coarse_off<E>(n.lane, n.R, n.s); }
 
 template <int D>
-MFGM_DEV void ld_sym_row(const double* __restrict__ base, size_t node, int i, double (&o)[D]) {
+MFGM_DEV void ld_sym_row(const double* __restrict__ base, At node, int i, double (&o)[D]) {
     const double* p = nm_node<MFGM_NTRI(D)>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -63,7 +65,7 @@ MFGM_DEV void ld_sym_row(const double* __restrict__ base, size_t node, int i, do
 }
 // row i of a lower-triangular block (zeros above the diagonal)
 template <int D>
-MFGM_DEV void ld_low_row(const double* __restrict__ base, size_t node, int i, double (&o)[D]) {
+MFGM_DEV void ld_low_row(const double* __restrict__ base, At node, int i, double (&o)[D]) {
     const double* p = nm_node<MFGM_NTRI(D)>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -73,7 +75,7 @@ MFGM_DEV void ld_low_row(const double* __restrict__ base, size_t node, int i, do
 }
 // row i of the TRANSPOSE of a lower-triangular block: o[k] = L[k][i] (zeros for k < i)
 template <int D>
-MFGM_DEV void ld_lowT_row(const double* __restrict__ base, size_t node, int i, double (&o)[D]) {
+MFGM_DEV void ld_lowT_row(const double* __restrict__ base, At node, int i, double (&o)[D]) {
     const double* p = nm_node<MFGM_NTRI(D)>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -82,35 +84,35 @@ MFGM_DEV void ld_lowT_row(const double* __restrict__ base, size_t node, int i, d
     }
 }
 template <int D>
-MFGM_DEV void ld_full_row(const double* __restrict__ base, size_t node, int i, double (&o)[D]) {
+MFGM_DEV void ld_full_row(const double* __restrict__ base, At node, int i, double (&o)[D]) {
     const double* p = nm_node<D * D>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k) o[k] = p[(i * D + k) * 64];
 }
 template <int D>
-MFGM_DEV void ld_full_col(const double* __restrict__ base, size_t node, int i, double (&o)[D]) {
+MFGM_DEV void ld_full_col(const double* __restrict__ base, At node, int i, double (&o)[D]) {
     const double* p = nm_node<D * D>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k) o[k] = p[(k * D + i) * 64];
 }
 template <int D>
-MFGM_DEV double ld_vec_elem(const double* __restrict__ base, size_t node, int i) { return nm_node<D>(base, node)[i * 64]; }
+MFGM_DEV double ld_vec_elem(const double* __restrict__ base, At node, int i) { return nm_node<D>(base, node)[i * 64]; }
 
 template <int D>
-MFGM_DEV void st_low_row(double* __restrict__ base, size_t node, int i, const double (&v)[D]) {
+MFGM_DEV void st_low_row(double* __restrict__ base, At node, int i, const double (&v)[D]) {
     double* p = nm_node<MFGM_NTRI(D)>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k)
         if (k <= i) p[(i * (i + 1) / 2 + k) * 64] = v[k];
 }
 template <int D>
-MFGM_DEV void st_full_row(double* __restrict__ base, size_t node, int i, const double (&v)[D]) {
+MFGM_DEV void st_full_row(double* __restrict__ base, At node, int i, const double (&v)[D]) {
     double* p = nm_node<D * D>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k) p[(i * D + k) * 64] = v[k];
 }
 template <int D>
-MFGM_DEV void st_full_col(double* __restrict__ base, size_t node, int i, const double (&v)[D]) {
+MFGM_DEV void st_full_col(double* __restrict__ base, At node, int i, const double (&v)[D]) {
     double* p = nm_node<D * D>(base, node);
 #pragma unroll
     for (int k = 0; k < D; ++k) p[(k * D + i) * 64] = v[k];
@@ -158,9 +160,9 @@ MFGM_DEV double rows_mv(const double (&A)[D], double v) {
 }
 
 // node of the coarser level that separator q of chain b is
-MFGM_DEV size_t up_node(const SweepArgs& a, int b, int q) {
+MFGM_DEV At up_node(const SweepArgs& a, int b, int q) {
     const int uP = a.up.P, uR = a.up.R;
-    return (size_t)(b * uP + q / uR) * uR + q % uR;
+    return At{b * uP + q / uR, uR, q % uR};
 }
 
 // ---- reduce (levels >= 1: the inputs are the reduced system of the level below, all scales 1, corrections present) ---------------
@@ -171,35 +173,35 @@ MFGM_DEV void rows_reduce(const SweepArgs& a, const int lane, const int r) {
     const int len = min(R, a.lv.n - p * R);
     const int i = min(r & 7, D - 1);
     const bool up = r >= 8, mine = (r & 7) < D;
-    const size_t node0 = (size_t)lane * R;
+    const At left{lane - 1, R, R - 1};          // the left separator is the last node of segment p-1
     int bad = 0;
 
     // lower half: F (row i of the pivot block), h;  upper half: X = Z (row i of W^T), Racc, rho
     double F[D], X[D], Racc[D], h = 0.0, rho = 0.0;
     {
         double c[D];
-        ld_sym_row<D>(a.Dg, node0, i, F);
-        ld_sym_row<D>(a.Dcorr, node0, i, c);
+        ld_sym_row<D>(a.Dg, At{lane, R, 0}, i, F);
+        ld_sym_row<D>(a.Dcorr, At{lane, R, 0}, i, c);
 #pragma unroll
         for (int k = 0; k < D; ++k) F[k] -= c[k];
     }
     if (p > 0) {
-        ld_full_col<D>(a.Sg, node0 - 1, i, X);       // the left separator is the last node of segment p-1
+        ld_full_col<D>(a.Sg, left, i, X);       // the left separator is the last node of segment p-1
     } else {
 #pragma unroll
         for (int k = 0; k < D; ++k) X[k] = 0.0;
     }
-    if (HAS_RHS) h = ld_vec_elem<D>(a.rg, node0, i) - ld_vec_elem<D>(a.rcorr, node0, i);
+    if (HAS_RHS) h = ld_vec_elem<D>(a.rg, At{lane, R, 0}, i) - ld_vec_elem<D>(a.rcorr, At{lane, R, 0}, i);
 #pragma unroll
     for (int k = 0; k < D; ++k) Racc[k] = 0.0;
 
     // the raw blocks of step s+1 are requested before step s is worked (a step is one memory round trip otherwise)
     double Gq[D], Fq[D], cq[D], hq = 0.0, hcq = 0.0;
     auto load_step = [&](int s) {
-        ld_full_row<D>(a.Sg, node0 + s, i, Gq);
-        ld_sym_row<D>(a.Dg, node0 + s + 1, i, Fq);
-        ld_sym_row<D>(a.Dcorr, node0 + s + 1, i, cq);
-        if (HAS_RHS) { hq = ld_vec_elem<D>(a.rg, node0 + s + 1, i); hcq = ld_vec_elem<D>(a.rcorr, node0 + s + 1, i); }
+        ld_full_row<D>(a.Sg, At{lane, R, s}, i, Gq);
+        ld_sym_row<D>(a.Dg, At{lane, R, s + 1}, i, Fq);
+        ld_sym_row<D>(a.Dcorr, At{lane, R, s + 1}, i, cq);
+        if (HAS_RHS) { hq = ld_vec_elem<D>(a.rg, At{lane, R, s + 1}, i); hcq = ld_vec_elem<D>(a.rcorr, At{lane, R, s + 1}, i); }
     };
     if (len > 1) load_step(0);
     for (int s = 0; s < len - 1; ++s) {
@@ -233,7 +235,7 @@ MFGM_DEV void rows_reduce(const SweepArgs& a, const int lane, const int r) {
         h = hn;
     }
     if (!up && mine) {
-        const size_t nq = up_node(a, b, p);
+        const At nq = up_node(a, b, p);
         st_low_row<D>(a.uDhat, nq, i, F);
         nm_node<D>(a.urhat, nq)[i * 64] = h;
         if (p == P - 1) {
@@ -246,7 +248,7 @@ MFGM_DEV void rows_reduce(const SweepArgs& a, const int lane, const int r) {
         }
     }
     if (up && mine && p > 0) {
-        const size_t nq = up_node(a, b, p - 1);
+        const At nq = up_node(a, b, p - 1);
         st_full_col<D>(a.uS, nq, i, X);               // couples separator p-1 -> p:  S~ = W = Z^T
         st_low_row<D>(a.uRsub, nq, i, Racc);
         nm_node<D>(a.urho, nq)[i * 64] = rho;
@@ -262,18 +264,18 @@ MFGM_DEV void rows_forward(const SweepArgs& a, const int lane, const int r) {
     const int len = min(R, n - p * R);
     const int i = min(r & 7, D - 1);
     const bool mine = r < D;
-    const size_t node0 = (size_t)lane * R;
+    const At left{lane - 1, R, R - 1};          // the left separator is the last node of segment p-1
     int bad = 0;
     double C[D], c = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) C[k] = 0.0;
     if (HAS_UP && p > 0) {
         // natural-order state at the separator on the left:  F_a = Ltil Ltil^T + R_p,  h_a = Ltil ytil + rho_p
-        const size_t nq = up_node(a, b, p - 1);
+        const At nq = up_node(a, b, p - 1);
         double Lt[D], Fa[D], Ga[D], invd[D];
         ld_low_row<D>(a.uL, nq, i, Lt);
         ld_sym_row<D>(a.uRsub, nq, i, Fa);
-        ld_full_row<D>(a.Sg, node0 - 1, i, Ga);
+        ld_full_row<D>(a.Sg, left, i, Ga);
         double ha = 0.0;
         if (HAS_RHS) {
             const double yt = ld_vec_elem<D>(a.uy, nq, i);
@@ -298,15 +300,15 @@ MFGM_DEV void rows_forward(const SweepArgs& a, const int lane, const int r) {
     }
     double Fq[D], cq[D], Gq[D], hq = 0.0, hcq = 0.0;
     auto load_step = [&](int s) {
-        ld_sym_row<D>(a.Dg, node0 + s, i, Fq);
-        ld_sym_row<D>(a.Dcorr, node0 + s, i, cq);
+        ld_sym_row<D>(a.Dg, At{lane, R, s}, i, Fq);
+        ld_sym_row<D>(a.Dcorr, At{lane, R, s}, i, cq);
         if (p * R + s + 1 < n) {
-            ld_full_row<D>(a.Sg, node0 + s, i, Gq);
+            ld_full_row<D>(a.Sg, At{lane, R, s}, i, Gq);
         } else {
 #pragma unroll
             for (int k = 0; k < D; ++k) Gq[k] = 0.0;
         }
-        if (HAS_RHS) { hq = ld_vec_elem<D>(a.rg, node0 + s, i); hcq = ld_vec_elem<D>(a.rcorr, node0 + s, i); }
+        if (HAS_RHS) { hq = ld_vec_elem<D>(a.rg, At{lane, R, s}, i); hcq = ld_vec_elem<D>(a.rcorr, At{lane, R, s}, i); }
     };
     load_step(0);
     for (int s = 0; s < len; ++s) {
@@ -318,9 +320,9 @@ MFGM_DEV void rows_forward(const SweepArgs& a, const int lane, const int r) {
         double y = 0.0;
         if (HAS_RHS) y = rows_fsolve<D>(F, invd, h, i);
         if (mine) {
-            st_low_row<D>(a.Lg, node0 + s, i, F);
-            st_full_row<D>(a.Gg, node0 + s, i, G);
-            if (HAS_RHS) nm_node<D>(a.yg, node0 + s)[i * 64] = y;
+            st_low_row<D>(a.Lg, At{lane, R, s}, i, F);
+            st_full_row<D>(a.Gg, At{lane, R, s}, i, G);
+            if (HAS_RHS) nm_node<D>(a.yg, At{lane, R, s})[i * 64] = y;
         }
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -364,17 +366,16 @@ MFGM_DEV void rows_backward(const SweepArgs& a, const int lane, const int r) {
     const int len = min(R, n - p * R), se = len - 1;
     const int i = min(r & 7, D - 1);
     const bool mine = r < D;
-    const size_t node0 = (size_t)lane * R;
 
     double Sn[D], xn = 0.0;
     if (HAS_UP) {
-        const size_t nq = up_node(a, b, p);
+        const At nq = up_node(a, b, p);
         ld_sym_row<D>(a.uSig, nq, i, Sn);
         if (HAS_RHS) xn = ld_vec_elem<D>(a.umu, nq, i);
     } else {
         double Xt[D], U[D];
-        ld_lowT_row<D>(a.Lg, node0 + se, i, U);
-        rows_inv_t<D>(U, nm_node<MFGM_NTRI(D)>(a.Lg, node0 + se)[(i * (i + 1) / 2 + i) * 64], i, Xt);
+        ld_lowT_row<D>(a.Lg, At{lane, R, se}, i, U);
+        rows_inv_t<D>(U, nm_node<MFGM_NTRI(D)>(a.Lg, At{lane, R, se})[(i * (i + 1) / 2 + i) * 64], i, Xt);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             double t = 0.0;
@@ -382,18 +383,18 @@ MFGM_DEV void rows_backward(const SweepArgs& a, const int lane, const int r) {
             for (int k = 0; k < D; ++k) t = __builtin_fma(Xt[k], rb(Xt[k], j), t);
             Sn[j] = t;
         }
-        if (HAS_RHS) xn = rows_mv<D>(Xt, ld_vec_elem<D>(a.yg, node0 + se, i));
+        if (HAS_RHS) xn = rows_mv<D>(Xt, ld_vec_elem<D>(a.yg, At{lane, R, se}, i));
     }
     if (mine) {
-        st_low_row<D>(a.Sigg, node0 + se, i, Sn);
-        if (HAS_RHS) nm_node<D>(a.mug, node0 + se)[i * 64] = xn;
+        st_low_row<D>(a.Sigg, At{lane, R, se}, i, Sn);
+        if (HAS_RHS) nm_node<D>(a.mug, At{lane, R, se})[i * 64] = xn;
     }
     double Uq[D], Gq[D], uq = 1.0, yq = 0.0;
     auto load_step = [&](int s) {
-        ld_lowT_row<D>(a.Lg, node0 + s, i, Uq);
-        uq = nm_node<MFGM_NTRI(D)>(a.Lg, node0 + s)[(i * (i + 1) / 2 + i) * 64];
-        ld_full_col<D>(a.Gg, node0 + s, i, Gq);
-        if (HAS_RHS) yq = ld_vec_elem<D>(a.yg, node0 + s, i);
+        ld_lowT_row<D>(a.Lg, At{lane, R, s}, i, Uq);
+        uq = nm_node<MFGM_NTRI(D)>(a.Lg, At{lane, R, s})[(i * (i + 1) / 2 + i) * 64];
+        ld_full_col<D>(a.Gg, At{lane, R, s}, i, Gq);
+        if (HAS_RHS) yq = ld_vec_elem<D>(a.yg, At{lane, R, s}, i);
     };
     if (len > 1) load_step(len - 2);
     for (int s = len - 2; s >= 0; --s) {
@@ -432,8 +433,8 @@ MFGM_DEV void rows_backward(const SweepArgs& a, const int lane, const int r) {
             xn = rows_mv<D>(Xt, v);
         }
         if (mine) {
-            st_low_row<D>(a.Sigg, node0 + s, i, Sig);
-            if (HAS_RHS) nm_node<D>(a.mug, node0 + s)[i * 64] = xn;
+            st_low_row<D>(a.Sigg, At{lane, R, s}, i, Sig);
+            if (HAS_RHS) nm_node<D>(a.mug, At{lane, R, s})[i * 64] = xn;
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) Sn[k] = Sig[k];

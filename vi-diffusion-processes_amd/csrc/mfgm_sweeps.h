@@ -22,16 +22,32 @@ struct LaneRef {
     int tile, l;
     MFGM_DEV static LaneRef of(int lane) { return LaneRef{lane >> 6, lane & 63}; }
 };
-// NM ("node-major") is the layout of the levels above the finest one: node = lane * R + s of the level, element e at
-//   ((node / 64) * E + e) * 64 + node % 64
-// so that the separators written by consecutive lanes of the level below (one node each) are contiguous, and a lane of this level
-// reads its R consecutive nodes from the same few cache lines.  (In the lane-interleaved layout of level 0 those hand-overs
-// touch one 64-byte sector per lane and element.)  Same array sizes as the lane-interleaved layout.
+// NM marks an array of a level above the finest one (plan workspace).  Those levels use the SAME lane-interleaved layout as level 0,
+// with the level's own lanes and R:  element e of (lane, step s) at (((lane / 64) * R + s) * E + e) * 64 + lane % 64  -- a wavefront of the
+// level reads 512 contiguous bytes per (step, element), and the 64 separators that consecutive lanes of the level below hand up land in
+// R runs of 64 / R lanes each (whole cache lines for R <= 8).  Rounds 2-3 kept these levels node-major (node = lane * R + s, element e at
+// ((node / 64) * E + e) * 64 + node % 64: the hand-over is one 512-byte run, but a wavefront of the level itself then reads R-strided
+// doubles, 32 cache lines per load instead of 8).  Per-phase cycle stamps of the fused coarse kernel showed where that goes: the level
+// with 256 segments per chain -- four wavefronts sharing one CU's texture-address unit -- took 27 000 cycles per block step against
+// 11 400 for the level with one wavefront.  Same box, headline: k_coarse_factor 0.143 -> 0.090 ms, k_coarse_backward 0.062 -> 0.047,
+// level-0 kernels unchanged, step 2.96 -> 2.83 ms.  MFGM_COARSE_NODE_MAJOR=1 at compile time brings the node-major layout back.
+// offset of element 0 of (lane, step s) of a level >= 1 array with E doubles per node (the elements follow at a stride of 64 doubles)
+#ifndef MFGM_COARSE_NODE_MAJOR
+#define MFGM_COARSE_NODE_MAJOR 0
+#endif
+template <int E>
+MFGM_DEV size_t coarse_off(int lane, int R, int s) {
+#if MFGM_COARSE_NODE_MAJOR
+    const size_t node = (size_t)lane * R + s;
+    return ((node >> 6) * E) * 64 + (node & 63);
+#else
+    return ((size_t)(lane >> 6) * R + s) * (size_t)(E * 64) + (lane & 63);
+#endif
+}
 template <int E, bool NM = false>
 MFGM_DEV void ld_node(const double* __restrict__ base, int R, int s, LaneRef w, double (&out)[E]) {
     if constexpr (NM) {
-        const size_t node = (size_t)(w.tile * 64 + w.l) * R + s;
-        const double* p = base + ((node >> 6) * E) * 64 + (node & 63);
+        const double* p = base + coarse_off<E>(w.tile * 64 + w.l, R, s);
 #pragma unroll
         for (int e = 0; e < E; ++e) out[e] = p[e * 64];
     } else {
@@ -43,8 +59,7 @@ MFGM_DEV void ld_node(const double* __restrict__ base, int R, int s, LaneRef w, 
 template <int E, bool NM = false>
 MFGM_DEV void st_node(double* __restrict__ base, int R, int s, LaneRef w, const double (&v)[E]) {
     if constexpr (NM) {
-        const size_t node = (size_t)(w.tile * 64 + w.l) * R + s;
-        double* p = base + ((node >> 6) * E) * 64 + (node & 63);
+        double* p = base + coarse_off<E>(w.tile * 64 + w.l, R, s);
 #pragma unroll
         for (int e = 0; e < E; ++e) p[e * 64] = v[e];
     } else {
@@ -56,8 +71,7 @@ MFGM_DEV void st_node(double* __restrict__ base, int R, int s, LaneRef w, const 
 template <int E, bool NM = false>
 MFGM_DEV void st_node_zero(double* __restrict__ base, int R, int s, LaneRef w) {
     if constexpr (NM) {
-        const size_t node = (size_t)(w.tile * 64 + w.l) * R + s;
-        double* p = base + ((node >> 6) * E) * 64 + (node & 63);
+        double* p = base + coarse_off<E>(w.tile * 64 + w.l, R, s);
 #pragma unroll
         for (int e = 0; e < E; ++e) p[e * 64] = 0.0;
     } else {
