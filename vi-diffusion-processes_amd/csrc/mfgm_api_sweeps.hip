@@ -45,7 +45,7 @@ int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub
     dim3 grid(a.lv.Lpad / 64), block(64);
     const bool mom = (a.momg != nullptr);
     if (coarse) {
-        // a level above the finest one: node-major arrays, marginals only
+        // a level above the finest one: workspace arrays (coarse_off), marginals only
         if (want_sub || mom || a.Gg == nullptr) return 1;
 #define BWC(R_, U_) hipLaunchKernelGGL((k_backward<D, R_, U_, false, false, false, true>), grid, block, 0, st, a)
         if (has_rhs) { if (has_up) BWC(true, true); else BWC(true, false); }

@@ -203,7 +203,7 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
             for (int i = 0; i < D; ++i) sdc[i] = rc[2 * D + i];
         }
     }
-    // separator of this segment is node q = p of the coarser level (node-major layout)
+    // separator of this segment is node q = p of the coarser level (level >= 1 layout: coarse_off)
     const int uP = a.up.P, uR = a.up.R;
     {
         const int qq = p, ul = b * uP + qq / uR, us = qq % uR;

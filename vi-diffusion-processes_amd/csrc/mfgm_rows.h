@@ -7,7 +7,7 @@
 // matrices reach it through `v_mov_b64_dpp row_newbcast:j` (a one-instruction broadcast of lane j's double to its row: no LDS, no
 // barrier, no readlane -- four segments share a wavefront and may diverge freely, DPP never leaves the row).  A step becomes ~400-600
 // instructions per lane.  The algorithms are those of the wavefront-per-segment kernels (mfgm_wide.h: kw_reduce / kw_forward /
-// kw_backward); the arrays are the narrow plans' node-major, triangle-packed level arrays (mfgm_sweeps.h, ld_node<E, true>), read and
+// kw_backward); the arrays are the narrow plans' triangle-packed level arrays (mfgm_sweeps.h, ld_node<E, true>), read and
 // written in place, so the level-0 kernels and the lane-per-segment bodies of the larger levels see exactly what they saw before.
 //
 // In the reduce body the two halves of a row do different work on the same broadcasts: lanes 0..7 carry the pivot block F and the

@@ -25,7 +25,7 @@ struct LaneRef {
 // NM marks an array of a level above the finest one (plan workspace).  Those levels use the SAME lane-interleaved layout as level 0,
 // with the level's own lanes and R:  element e of (lane, step s) at (((lane / 64) * R + s) * E + e) * 64 + lane % 64  -- a wavefront of the
 // level reads 512 contiguous bytes per (step, element), and the 64 separators that consecutive lanes of the level below hand up land in
-// R runs of 64 / R lanes each (whole cache lines for R <= 8).  Rounds 2-3 kept these levels node-major (node = lane * R + s, element e at
+// R runs of 64 / R lanes each (whole cache lines for R <= 8).  Round 2 and most of round 3 kept these levels node-major (node = lane * R + s, element e at
 // ((node / 64) * E + e) * 64 + node % 64: the hand-over is one 512-byte run, but a wavefront of the level itself then reads R-strided
 // doubles, 32 cache lines per load instead of 8).  Per-phase cycle stamps of the fused coarse kernel showed where that goes: the level
 // with 256 segments per chain -- four wavefronts sharing one CU's texture-address unit -- took 27 000 cycles per block step against
@@ -549,7 +549,7 @@ MFGM_DEV void backward_body(const SweepArgs& a, const int lane, const LaneRef me
     }
 }
 
-// CL: the level's own arrays are in the node-major layout (every level above the finest one)
+// CL: the level's own arrays are level >= 1 arrays of the plan workspace (addressed through coarse_off)
 template <int D, bool HAS_RHS, bool HAS_UP, bool WANT_SUB, bool WANT_MOM, bool USE_S = false, bool CL = false>
 static __global__ __launch_bounds__(64) void k_backward(SweepArgs a) {
     const int lane = blockIdx.x * 64 + threadIdx.x;
