@@ -390,9 +390,14 @@ def bench_cvigp(h, data_rank):
     m = CVIGaussianProcess((t, y), K.Matern52(lengthscale=0.2, variance=1.0), Gaussian(0.01), learning_rate=0.5)
     state = {"e": None}
 
+    firsts = []
+
     def step():
         m.update_sites()
-        state["e"] = h.vdist.allreduce_sum_(m.elbo())
+        e_loc = m.elbo()
+        if len(firsts) < 2:
+            firsts.append(e_loc.clone())                 # this rank's own chain, for the parity probe against the C port
+        state["e"] = h.vdist.allreduce_sum_(e_loc)
 
     elapsed = h.run(step)
     e = float(state["e"])
@@ -416,28 +421,30 @@ def bench_cvigp(h, data_rank):
                                      "level 0 forward sweep; one chain: the step is bound by dependent launches and short sweeps, not by HBM",
                                      h.timed(fwd), 8 * ((ET + d * d + d) + (ET + d)) * T, 2, out["ms_per_step"])
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_cvigp(t.cpu().numpy(), y.cpu().numpy(), T)
+            out["cpu_baseline"] = cpu_baseline_cvigp(t.cpu().numpy(), y.cpu().numpy(), T, [float(x) for x in firsts])
     return out
 
 
-def cpu_baseline_cvigp(t, y, T, sample=2000):
-    """The NumPy oracle of the same step (oracle/np_models.CVIGaussianProcess: dense per-step loops, one thread) on the first `sample`
-    points, scaled linearly to T (the algorithm is O(T))."""
-    from oracle import np_kernels, np_models
-    o = np_models.CVIGaussianProcess(t[:sample], y[:sample], np_kernels.Matern52(0.2, 1.0), np_models.GaussianLik(0.01), learning_rate=0.5)
-    o.update_sites()
-    o.elbo()
+def cpu_baseline_cvigp(t, y, T, gpu_elbos=None):
+    """The plain-C port (oracle/csrc/btd_ref.c: ref_cvigp_step, one thread -- the step is one chain) of the same update_sites + elbo
+    step at FULL size; the prior's precision blocks come from the NumPy oracle's kernel, once, as the GPU model builds its own once.
+    gpu_elbos: the ELBOs of the GPU run's first steps, compared with the port's."""
+    from oracle import c_ref, np_kernels
+    k = np_kernels.Matern52(0.2, 1.0)
+    st = c_ref.CviGpStepState(k.state_space_model(t), k.emission_matrix(t[:1])[0, 0], y, 0.01, 0.5)
+    first = [st.step() for _ in range(2)]
     n, t0 = 0, time.perf_counter()
     while True:
-        o.update_sites()
-        o.elbo()
+        st.step()
         n += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or n >= 10:
+        if el > 10.0 or n >= 40:
             break
-    per = el / n * (T / sample)
-    return {"value": 1.0 / per, "unit": "ELBO steps/s", "cores": 1, "threads_used": 1, "kind": "port",
-            "sample": f"{n} steps of the NumPy oracle on the first {sample} of the {T} points ({el / n:.3f} s each), scaled linearly to {T}"}
+    out = {"value": n / el, "unit": "ELBO steps/s", "cores": 1, "threads_used": 1, "kind": "port",
+           "sample": f"{n} full-size steps (T={T}) of the C port, one thread (one chain: nothing to spread over cores), {el / n:.4f} s each"}
+    if gpu_elbos is not None and len(gpu_elbos) >= 2:
+        out["first_steps_elbo_max_rel_diff_vs_gpu"] = float(max(abs(a - b) / abs(b) for a, b in zip(gpu_elbos[:2], first)))
+    return out
 
 
 def sum16_kernel(K):

@@ -47,6 +47,11 @@ def load():
         lib.ref_vdp_step.restype = ctypes.c_double
         lib.ref_vdp_step.argtypes = ([ctypes.c_int] * 4 + [_ip, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp,
                                      ctypes.c_double] + [_dp] * 8 + [ctypes.c_double, ctypes.c_int, _dp, _dp])
+        lib.ref_cvigp_step_work_doubles.restype = ctypes.c_size_t
+        lib.ref_cvigp_step_work_doubles.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.ref_cvigp_step.restype = ctypes.c_double
+        lib.ref_cvigp_step.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, _dp, _dp, ctypes.c_double, ctypes.c_double,
+                                       _dp, _dp, _dp]
         lib.ref_num_threads.restype = ctypes.c_int
         lib.ref_set_num_threads.argtypes = [ctypes.c_int]
         lib.ref_set_num_threads.restype = None
@@ -184,3 +189,25 @@ class VdpStepState:
                                 self.af, self.bf, _p(self.qdiag), self.dt, _p(self.q0_mu), _p(self.q0_chol), _p(self.p0_mu),
                                 _p(self.p0_cov), _p(self.A), _p(self.b), _p(self.m), _p(self.S), float(lr), self.stabilize,
                                 _p(self.work), _p(self.elbo))
+
+
+
+class CviGpStepState:
+    """Host arrays for ref_cvigp_step: CVI for GP regression with a state-space kernel (oracle/np_models.CVIGaussianProcess), one chain,
+    scalar Gaussian likelihood.  `ssm` is the oracle's prior StateSpaceModel on the data's time points (zero mean), `h` the emission row."""
+
+    def __init__(self, ssm, h, y, noise_variance, learning_rate):
+        pd, ps = ssm.precision()
+        self.pd, self.ps = c64(pd), c64(ps)
+        self.T, self.d = self.pd.shape[0], self.pd.shape[-1]
+        self.half_logdet_prior = 0.5 * float(ssm.log_det_precision())
+        self.h, self.y = c64(h).reshape(-1), c64(y).reshape(-1)
+        assert self.h.shape[0] == self.d and self.y.shape[0] == self.T
+        self.s2, self.lr = float(noise_variance), float(learning_rate)
+        self.nat1, self.nat2 = np.zeros(self.T), -1e-10 * np.ones(self.T)
+        self.work = np.zeros(load().ref_cvigp_step_work_doubles(self.T, self.d))
+
+    def step(self):
+        """update_sites(); elbo() -> the ELBO."""
+        return load().ref_cvigp_step(self.T, self.d, _p(self.pd), _p(self.ps), self.half_logdet_prior, _p(self.h), _p(self.y), self.s2,
+                                     self.lr, _p(self.nat1), _p(self.nat2), _p(self.work))

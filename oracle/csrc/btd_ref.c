@@ -759,6 +759,71 @@ double ref_vdp_step(int B, int T, int d, int n, const int* idx, const double* y,
 }
 
 /* number of OpenMP threads later calls may use (the baseline is timed with all host cores and with one) */
+/* ------------------------------------------------------------------------------------------------------------
+ * CVI for GP regression with a state-space kernel (CVIGaussianProcess, variational_cvi.py:225-421), one chain, scalar output
+ * f_t = h . s_t, zero-mean prior, scalar Gaussian likelihood of variance s2: one iteration of
+ *   update_sites(); elbo()
+ * as oracle/np_models.CVIGaussianProcess does them (predict_f from the posterior of the current sites -- factorisation, two
+ * substitutions, selected inverse --, the likelihood's gradients with respect to the expectation parameters, the damped site update;
+ * then KalmanFilterWithSites.log_likelihood, kalman_filter.py:184-255, with the new sites: a second factorisation).
+ * Pd [T,d,d], Ps [T-1,d,d]: prior precision blocks; half_logdet_prior = 1/2 log|K_prior^-1|; nat1, nat2 [T]: the sites, in place.
+ * work: ref_cvigp_step_work_doubles(T, d) doubles.  Returns the ELBO.
+ * ------------------------------------------------------------------------------------------------------------ */
+size_t ref_cvigp_step_work_doubles(int T, int d) { return (size_t)T * (5 * d * d + 3 * d); }
+
+double ref_cvigp_step(int T, int d, const double* Pd, const double* Ps, double half_logdet_prior, const double* h, const double* y,
+                      double s2, double lr, double* nat1, double* nat2, double* work) {
+    const int dd = d * d;
+    double* D = work;
+    double* Ld = D + (size_t)T * dd;
+    double* Ls = Ld + (size_t)T * dd;
+    double* Sd = Ls + (size_t)T * dd;
+    double* Ss = Sd + (size_t)T * dd;
+    double* lin = Ss + (size_t)T * dd;
+    double* yv = lin + (size_t)T * d;
+    double* mu = yv + (size_t)T * d;
+    /* update_sites: posterior of the current sites, marginals of f at the data */
+    for (int t = 0; t < T; ++t) {
+        const double rinv = -2.0 * nat2[t];
+        for (int r = 0; r < d; ++r) {
+            lin[(size_t)t * d + r] = h[r] * nat1[t];
+            for (int c = 0; c < d; ++c) D[(size_t)t * dd + IDX(r, c, d)] = Pd[(size_t)t * dd + IDX(r, c, d)] + rinv * h[r] * h[c];
+        }
+    }
+    ref_btd_cholesky(D, Ps, Ld, Ls, T, d);
+    ref_btd_solve(Ld, Ls, lin, yv, T, d, 0);
+    ref_btd_solve(Ld, Ls, yv, mu, T, d, 1);
+    ref_btd_inverse_blocks(Ld, Ls, Sd, Ss, T, d);
+    for (int t = 0; t < T; ++t) {
+        double fm = 0.0, fv = 0.0;
+        for (int r = 0; r < d; ++r) {
+            fm += h[r] * mu[(size_t)t * d + r];
+            for (int c = 0; c < d; ++c) fv += h[r] * Sd[(size_t)t * dd + IDX(r, c, d)] * h[c];
+        }
+        /* gradients of the variational expectations wrt (mu, var), then wrt the expectation parameters [mu, var + mu^2] */
+        const double dmu = (y[t] - fm) / s2, dvar = -0.5 / s2 + 0.0 * fv;
+        const double g1 = dmu - 2.0 * dvar * fm, g2 = dvar;
+        nat1[t] = (1.0 - lr) * nat1[t] + lr * g1;
+        nat2[t] = (1.0 - lr) * nat2[t] + lr * g2;
+    }
+    /* elbo: the log marginal likelihood of the model whose likelihood terms are the (new) Gaussian sites */
+    double term1 = 0.0, logdet_r = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double rinv = -2.0 * nat2[t], obs = -0.5 * nat1[t] / nat2[t];
+        term1 += rinv * obs * obs;
+        logdet_r += log(rinv);
+        for (int r = 0; r < d; ++r) {
+            lin[(size_t)t * d + r] = h[r] * rinv * obs;
+            for (int c = 0; c < d; ++c) D[(size_t)t * dd + IDX(r, c, d)] = Pd[(size_t)t * dd + IDX(r, c, d)] + rinv * h[r] * h[c];
+        }
+    }
+    ref_btd_cholesky(D, Ps, Ld, Ls, T, d);
+    ref_btd_solve(Ld, Ls, lin, yv, T, d, 0);
+    double term2 = 0.0;
+    for (size_t i = 0; i < (size_t)T * d; ++i) term2 += yv[i] * yv[i];
+    return -0.5 * log(2.0 * M_PI) * T - 0.5 * term1 + 0.5 * term2 + half_logdet_prior - ref_btd_logdet(Ld, T, d) + 0.5 * logdet_r;
+}
+
 void ref_set_num_threads(int n) {
     if (n > 0) omp_set_num_threads(n);
 }

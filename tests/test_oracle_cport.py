@@ -140,3 +140,25 @@ def test_c_vdp_step(rng, d, T, stabilize):
             np.testing.assert_allclose(st.b[b], m.b, rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(st.elbo, ref, rtol=1e-8)
         np.testing.assert_allclose(total, np.sum(ref), rtol=1e-8)
+
+
+@pytest.mark.parametrize("kname,T", [("m52", 60), ("m32", 41), ("m12", 25)])
+def test_c_cvigp_step(rng, kname, T):
+    """The C port of the CVI-GP step (ref_cvigp_step: update_sites + elbo on a state-space kernel -- bench.py's config-2 cpu_baseline)
+    against the NumPy oracle model (oracle/np_models.CVIGaussianProcess, itself pinned to the reference's KA7 known answers), over
+    damped steps: ELBO and both site arrays."""
+    from oracle import np_kernels
+    k = {"m52": np_kernels.Matern52(0.7, 1.3), "m32": np_kernels.Matern32(1.1, 0.8), "m12": np_kernels.Matern12(2.0, 2.25)}[kname]
+    t = np.linspace(0, 6, T) + rng.uniform(0, 0.03, size=T)
+    y = np.sin(2 * t)[:, None] + 0.2 * rng.normal(size=(T, 1))
+    noise, lr = 0.3, 0.6
+    o = np_models.CVIGaussianProcess(t, y, k, np_models.GaussianLik(noise), learning_rate=lr)
+    H = k.emission_matrix(t)
+    assert H.shape[-2] == 1 and np.allclose(H, H[0])
+    st = c_ref.CviGpStepState(k.state_space_model(t), H[0, 0], y, noise, lr)
+    for _ in range(4):
+        e = st.step()
+        o.update_sites()
+        np.testing.assert_allclose(e, o.elbo(), rtol=1e-10)
+        np.testing.assert_allclose(st.nat1, o.nat1[:, 0], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(st.nat2, o.nat2[:, 0, 0], rtol=1e-10)
