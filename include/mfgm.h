@@ -470,6 +470,15 @@ int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, cons
 int mfgm_packed_vdp_to_naturals(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
                                 const double* p0inv, const double* p0lin, double* lin, double* diag, double* sub, void* stream);
 
+/* X_t = Phi_t X_{t-1} Phi_t^T + Q_t for t = 0 .. T-1 with X_{-1} = 0, on every chain of the plan (d <= 8): Phi FULL, Q and X SYM packed
+ * arrays over all T nodes.  This is the recurrence behind the exact derivative of the marginals with respect to the natural parameters,
+ * dSigma = -Sigma dP Sigma restricted to the band -- what the reference's GradientTape returns through banded_matrices' registered
+ * gradients of cholesky_band / inverse_from_cholesky_band (ssm_natgrad.py:154-201 calls tape.gradient on naturals_to_ssm_params) --
+ * partitioned over the plan's segments like the VDP moment recursion (three passes, no factorisation).
+ * seg: scratch of mfgm_congruence_scan_workspace_doubles(plan) doubles. */
+size_t mfgm_congruence_scan_workspace_doubles(const mfgm_plan* plan);
+int mfgm_congruence_scan(const mfgm_plan* plan, const double* Phi, const double* Q, double* X, double* seg, void* stream);
+
 /* forward_pass as the moment recursion of the reference (vi_sde.py:171-204), partitioned over the segments of the plan: marginal
  * means mu (VEC) and covariances Sig (SYM) of the Euler chain of the drift (-A, b) started at q(x0) = N(q0_mu[b], q0_cov[b])
  * (q0_mu [B][d], q0_cov [B][d(d+1)/2] packed lower triangles).  No factorisation: 42 doubles read twice and 27 written per node.

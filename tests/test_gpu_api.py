@@ -1694,6 +1694,28 @@ def test_exact_band_of_sigma_dP_sigma(amd, rng, B, T, d):
         gd, gs = tape.band_of_sigma_dP_sigma(dev(np.stack(covs)), dev(np.stack(subs)), dev(dPd), dev(dPs))
         assert_close(host(gd), np.stack(Xd), rtol=1e-8)
         assert_close(host(gs), np.stack(Xs), rtol=1e-8)
+        # the same through the HIP congruence scans (mfgm_congruence_scan) of a plan with short segments: several levels of maps
+        plan = amd.Plan(B, T, d, R0=4)
+        hd, hs = tape.band_of_sigma_dP_sigma(dev(np.stack(covs)), dev(np.stack(subs)), dev(dPd), dev(dPs), plan=plan)
+        assert_close(host(hd), np.stack(Xd), rtol=1e-8)
+        assert_close(host(hs), np.stack(Xs), rtol=1e-8)
+
+
+@pytest.mark.parametrize("B,T,d,R0", [(1, 1, 1, 0), (3, 2, 2, 0), (2, 37, 3, 4), (5, 130, 6, 8), (1, 700, 8, 5), (70, 20, 4, 0), (2, 5000, 6, 0)])
+def test_congruence_scan_kernel(amd, rng, B, T, d, R0):
+    """mfgm_congruence_scan (X_t = Phi_t X_{t-1} Phi_t^T + Q_t, X_{-1} = 0; segment maps, their scan, final sweep) against the sequential
+    recurrence in NumPy, on contractive and on mildly expanding transitions, ragged last segments and chains shorter than a segment."""
+    Phi = rng.normal(size=(B, T, d, d)) * (0.9 / np.sqrt(d))
+    Q = rng.normal(size=(B, T, d, d))
+    Q = Q @ np.swapaxes(Q, -1, -2) + 0.1 * np.eye(d)
+    ref = np.zeros_like(Q)
+    X = np.zeros((B, d, d))
+    for t in range(T):
+        X = Phi[:, t] @ X @ np.swapaxes(Phi[:, t], -1, -2) + Q[:, t]
+        ref[:, t] = X
+    plan = amd.Plan(B, T, d, R0=R0)
+    got = plan.unpack(amd.SYM, plan.congruence_scan(plan.pack(amd.FULL, dev(Phi)), plan.pack(amd.SYM, dev(Q))))
+    np.testing.assert_allclose(host(got), ref, rtol=1e-10, atol=1e-12)
 
 
 def test_tape_exact_backward_agrees_with_richardson(amd, rng):

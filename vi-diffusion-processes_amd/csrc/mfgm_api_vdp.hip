@@ -64,7 +64,37 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
 }
 }  // namespace
 
+namespace {
+template <int D>
+int congruence_scan_impl(const Plan& P, const double* Phi, const double* Q, double* X, double* seg, hipStream_t st) {
+    constexpr int ET = MFGM_NTRI(D), STR = 2 * (D + ET) + D * D;
+    const LevelDesc& lv = P.lv[0];
+    double* zeros = seg + (size_t)STR * lv.Lpad;          // q0 = (0, 0) of every chain
+    if (hipMemsetAsync(zeros, 0, (size_t)P.B * (D + ET) * sizeof(double), st) != hipSuccess) return 3;
+    dim3 grid(lv.Lpad / 64), block(64);
+    hipLaunchKernelGGL((k_congruence_scan<D, 1>), grid, block, 0, st, lv, Phi, Q, X, seg);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_vdp_marginals_scan<D>), dim3(P.B), dim3(kScanBlock), 0, st, lv, (const double*)zeros, (const double*)(zeros + (size_t)P.B * D), seg);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_congruence_scan<D, 3>), grid, block, 0, st, lv, Phi, Q, X, seg);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
 extern "C" {
+
+size_t mfgm_congruence_scan_workspace_doubles(const mfgm_plan* plan) {
+    if (!plan || plan->p.wide) return 0;
+    const int d = plan->p.d, et = d * (d + 1) / 2;
+    return (size_t)(2 * (d + et) + d * d) * plan->p.lv[0].Lpad + (size_t)plan->p.B * (d + et);
+}
+
+int mfgm_congruence_scan(const mfgm_plan* plan, const double* Phi, const double* Q, double* X, double* seg, void* stream) {
+    if (!plan || !Phi || !Q || !X || !seg || plan->p.wide) return 1;
+    const Plan& P = plan->p;
+    MFGM_DISPATCH_D(P.d, (congruence_scan_impl<DD>(P, Phi, Q, X, seg, (hipStream_t)stream)));
+}
 
 size_t mfgm_vdp_workspace_doubles(const mfgm_plan* plan) {
     if (!plan) return 0;

@@ -524,6 +524,70 @@ __global__ __launch_bounds__(kScanBlock) void k_vdp_marginals_scan(LevelDesc lv,
     }
 }
 
+// ---- a general congruence recurrence on the same three passes ------------------------------------------------------------------------
+//   X_t = Phi_t X_{t-1} Phi_t^T + Q_t,   X_{-1} = 0        (Phi: FULL blocks, Q / X: SYM blocks, all T nodes of every chain)
+// The two recurrences behind the exact Fisher-vector product of the tape (tape.band_of_sigma_dP_sigma: the band of Sigma dP Sigma
+// from L_{t+1} = A_t L_t A_t^T + QL and its mirror image) are of this form.  PASS 1 composes a segment's nodes into (Phi, Qacc), the
+// segment maps are chained by k_vdp_marginals_scan (mean part zero, start value 0), PASS 3 sweeps each segment from the value that
+// enters it and stores X.  The torch route (a Hillis-Steele scan, ceil(log2 T) rounds of three batched products) moves ~17 x more bytes.
+template <int D, int PASS>
+__global__ __launch_bounds__(64) void k_congruence_scan(LevelDesc lv, const double* __restrict__ Phig, const double* __restrict__ Qg,
+                                                       double* __restrict__ Xg, double* __restrict__ seg) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lv.L) return;
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const int P = lv.P, R = lv.R, n = lv.n;
+    const int p = lane % P;
+    const int len = min(R, n - p * R);
+    double S[ET], Phi[EF];
+    if (PASS == 1) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Phi[e] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) Phi[i * D + i] = 1.0;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) S[e] = 0.0;
+    } else {
+#pragma unroll
+        for (int e = 0; e < ET; ++e) S[e] = seg[(size_t)lane * STR + (MAP + D + e)];     // the value entering the segment
+    }
+    double Pn[EF], Qn[ET];
+    ld_node<EF>(Phig, R, 0, me, Pn);
+    ld_node<ET>(Qg, R, 0, me, Qn);
+    for (int s = 0; s < R; ++s) {
+        if (s < len) {
+            double T[EF], Q[ET];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) T[e] = Pn[e];
+#pragma unroll
+            for (int e = 0; e < ET; ++e) Q[e] = Qn[e];
+            if (s + 1 < len) {
+                ld_node<EF>(Phig, R, s + 1, me, Pn);
+                ld_node<ET>(Qg, R, s + 1, me, Qn);
+            }
+            vdp_congruence<D>(T, S);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) S[e] += Q[e];
+            if (PASS == 3) st_node<ET>(Xg, R, s, me, S);
+            if (PASS == 1) {
+                double t[EF];
+                gemm<D>(T, Phi, t);
+#pragma unroll
+                for (int e = 0; e < EF; ++e) Phi[e] = t[e];
+            }
+        }
+    }
+    if (PASS == 1) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) seg[(size_t)lane * STR + e] = Phi[e];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) seg[(size_t)lane * STR + (EF + e)] = S[e];
+#pragma unroll
+        for (int i = 0; i < D; ++i) seg[(size_t)lane * STR + (EF + ET + i)] = 0.0;
+    }
+}
+
 // ---- E_sde value (per-lane partials; times dt on the host) and optional gradient arrays --------------------------
 template <int D, bool GRAD>
 __global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,

@@ -140,6 +140,14 @@ class Plan:
                    "mfgm_lincomb")
         return out
 
+    def congruence_scan(self, Phi, Q, out=None):
+        """X_t = Phi_t X_{t-1} Phi_t^T + Q_t, X_{-1} = 0, on packed arrays (Phi FULL, Q SYM over all T nodes; d <= 8): packed SYM X."""
+        if getattr(self, "_scan_ws", None) is None:
+            self._scan_ws = torch.empty(max(int(self.lib.mfgm_congruence_scan_workspace_doubles(self.h)), 1), dtype=torch.float64, device=self.device)
+        X = out if out is not None else self.empty(SYM)
+        _lib.check(self.lib.mfgm_congruence_scan(self.h, _ptr(Phi), _ptr(Q), _ptr(X), _ptr(self._scan_ws), _stream()), "mfgm_congruence_scan")
+        return X
+
     def gather_nodes(self, kind, packed, node_ids, out=None):
         """node_ids: int64 device tensor of b*T + t.  Returns natural [n, d] or [n, d, d] (written into `out` when given)."""
         n = node_ids.numel()

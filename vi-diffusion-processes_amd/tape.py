@@ -25,6 +25,8 @@ factorisations are not used).
 `TapeSSM` is a StateSpaceModel whose parameters are leaves of a torch graph and whose marginals / KL / log-determinant are
 differentiable; `SSMNaturalGradient.minimize(loss_fn, ssm)` builds one when `loss_fn` is a plain closure (ssm_natgrad.py).
 """
+import os
+
 import torch
 
 from ._lib import FULL, SYM, VEC
@@ -123,12 +125,18 @@ def _precision_times(plan, g_diag, g_sub, x):
     return out
 
 
-def _congruence_scan(Phi, Q, reverse=False):
+def _congruence_scan(Phi, Q, reverse=False, plan=None):
     """X_t of the recurrence  X_t = Phi_t X_{t-1} Phi_t^T + Q_t  (X_{-1} = 0; reverse: X_t = Phi_t X_{t+1} Phi_t^T + Q_t from the far
-    end) for Phi, Q [B, T, d, d]: an inclusive scan over the maps X -> Phi X Phi^T + Q, whose composition
-    (later after earlier) is (Phi_2 Phi_1, Phi_2 Q_1 Phi_2^T + Q_2) -- ceil(log2 T) rounds of three batched d x d products."""
+    end) for Phi, Q [B, T, d, d] (Q symmetric).  With a lane-per-segment plan of the same (B, T, d) the recurrence runs on the HIP
+    kernels (mfgm_congruence_scan: segment maps, one scan of them per chain, final sweep -- three passes over the data); otherwise
+    as an inclusive scan in torch over the maps X -> Phi X Phi^T + Q, whose composition (later after earlier) is
+    (Phi_2 Phi_1, Phi_2 Q_1 Phi_2^T + Q_2) -- ceil(log2 T) rounds of three batched d x d products."""
     if reverse:
-        return _congruence_scan(Phi.flip(1), Q.flip(1)).flip(1)
+        return _congruence_scan(Phi.flip(1), Q.flip(1), plan=plan).flip(1)
+    if (plan is not None and not plan.wide and Phi.is_cuda and tuple(Phi.shape) == (plan.B, plan.T, plan.d, plan.d)
+            and os.environ.get("VIDP_TAPE_TORCH_SCAN", "0") != "1"):
+        from ._lib import FULL, SYM
+        return plan.unpack(SYM, plan.congruence_scan(plan.pack(FULL, Phi.contiguous()), plan.pack(SYM, Q.contiguous())))
     T = Phi.shape[1]
     Phi, Q = Phi.clone(), Q.clone()
     s = 1
@@ -142,7 +150,7 @@ def _congruence_scan(Phi, Q, reverse=False):
     return Q
 
 
-def band_of_sigma_dP_sigma(cov, csub, dPd, dPs):
+def band_of_sigma_dP_sigma(cov, csub, dPd, dPs, plan=None):
     """Diagonal and sub-diagonal blocks of  X = Sigma dP Sigma  for the covariance Sigma of a Gauss-Markov chain given by its band
     (cov [B,T,d,d] = Sigma_tt, csub [B,T-1,d,d] = Sigma_{t+1,t}) and a symmetric block-tri-diagonal dP (dPd [B,T,d,d] symmetric,
     dPs [B,T-1,d,d] = dP_{t+1,t}).  Exact (module docstring); d x d solves through vidp_amd.linalg (HIP batched Cholesky / trsm)."""
@@ -160,8 +168,8 @@ def band_of_sigma_dP_sigma(cov, csub, dPd, dPs):
     zero = torch.zeros_like(cov[:, :1])
     QL = loc + torch.cat([zero, m1 + _T(m1)], dim=1)
     QR = loc + torch.cat([m2 + _T(m2), zero], dim=1)
-    L = _congruence_scan(torch.cat([zero, A], dim=1), QL)               # pairs (a, b) <= t
-    R = _congruence_scan(torch.cat([J, zero], dim=1), QR, reverse=True)  # pairs (a, b) >= t
+    L = _congruence_scan(torch.cat([zero, A], dim=1), QL, plan=plan)               # pairs (a, b) <= t
+    R = _congruence_scan(torch.cat([J, zero], dim=1), QR, reverse=True, plan=plan)  # pairs (a, b) >= t
     Xd = L + R - loc
     Xs = A @ L[:, :-1] + R[:, 1:] @ _T(J) + csub @ _T(dPs) @ csub + hi @ dPs @ lo
     return Xd, Xs
@@ -209,7 +217,7 @@ def fisher_vector_product(plan, diag, sub, mu, cov, csub, g_lin, g_diag, g_sub):
     dcov, dsub = torch.zeros_like(g_diag), torch.zeros_like(g_sub)
     gm = max(float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
     if gm > 0.0 and not NaturalsToExpectations.richardson:
-        Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub)
+        Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub, plan=plan)
         dcov, dsub = -Xd, -Xs
     elif gm > 0.0:
         h = NaturalsToExpectations.rel_step * float(diag.abs().max()) / gm
