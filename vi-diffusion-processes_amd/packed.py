@@ -63,8 +63,11 @@ class Plan:
         assert natural.dtype == torch.float64 and natural.is_cuda
         assert natural.shape[0] == self.B, (natural.shape, self.B)
         n_nodes = natural.shape[1]
+        given = out is not None
         out = self.zeros(kind) if out is None else out
         _lib.check(self.lib.mfgm_pack(self.h, kind, _ptr(natural), n_nodes, _ptr(out), _stream()), "mfgm_pack")
+        if given:
+            torch.autograd.graph.increment_version(out)      # written behind torch's back: caches keyed on ._version must notice
         return out
 
     def unpack(self, kind, packed, n_nodes=None):
