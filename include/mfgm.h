@@ -479,6 +479,16 @@ int mfgm_packed_vdp_to_naturals(const mfgm_plan* plan, const mfgm_vdp_params* pr
 size_t mfgm_congruence_scan_workspace_doubles(const mfgm_plan* plan);
 int mfgm_congruence_scan(const mfgm_plan* plan, const double* Phi, const double* Q, double* X, double* seg, void* stream);
 
+/* The band of X = Sigma dP Sigma -- X_tt (Xd, SYM) and X_{t+1,t} (Xs, FULL) -- from the band of the covariance of a Gauss-Markov chain
+ * (Sig SYM = Sigma_tt, Sub FULL = Sigma_{t+1,t}, what mfgm_packed_selinv returns) and a symmetric block-tri-diagonal dP (dPd SYM lower
+ * triangles, dPs FULL = dP_{t+1,t}): d Sigma = -Sigma dP Sigma is the covariance half of the derivative of the marginals with respect
+ * to the natural parameters, which the reference takes from a GradientTape through the banded ops (ssm_natgrad.py:154-201).  Exact, no
+ * re-factorisation: one d x d Cholesky per node, two congruence recurrences (mfgm_congruence_scan), two local passes (csrc/mfgm_band.h).
+ * d <= 8.  work: scratch of mfgm_band_workspace_doubles(plan) doubles. */
+size_t mfgm_band_workspace_doubles(const mfgm_plan* plan);
+int mfgm_band_sigma_dP_sigma(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* dPd, const double* dPs, double* Xd,
+                             double* Xs, double* work, void* stream);
+
 /* forward_pass as the moment recursion of the reference (vi_sde.py:171-204), partitioned over the segments of the plan: marginal
  * means mu (VEC) and covariances Sig (SYM) of the Euler chain of the drift (-A, b) started at q(x0) = N(q0_mu[b], q0_cov[b])
  * (q0_mu [B][d], q0_cov [B][d(d+1)/2] packed lower triangles).  No factorisation: 42 doubles read twice and 27 written per node.

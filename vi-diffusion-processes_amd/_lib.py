@@ -38,6 +38,8 @@ EXPORTS = {
                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_congruence_scan_workspace_doubles": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_congruence_scan": (ctypes.c_int, [ctypes.c_void_p] * 6),
+    "mfgm_band_workspace_doubles": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "mfgm_band_sigma_dP_sigma": (ctypes.c_int, [ctypes.c_void_p] * 9),
     "mfgm_site_lerp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_double, ctypes.c_void_p]),
     "mfgm_node_io": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

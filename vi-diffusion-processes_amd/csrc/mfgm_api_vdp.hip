@@ -2,6 +2,7 @@
 #include "mfgm_internal.h"
 #include "mfgm_sweeps.h"
 #include "mfgm_vdp.h"
+#include "mfgm_band.h"
 
 using namespace mfgm;
 
@@ -82,6 +83,42 @@ int congruence_scan_impl(const Plan& P, const double* Phi, const double* Q, doub
 }
 }  // namespace
 
+namespace {
+size_t scan_ws_doubles(const Plan& P) {
+    const int d = P.d, et = d * (d + 1) / 2;
+    return ((size_t)(2 * (d + et) + d * d) * P.lv[0].Lpad + (size_t)P.B * (d + et) + 63) / 64 * 64;
+}
+template <int D>
+int band_impl(const Plan& P, const double* Sig, const double* Sub, const double* dPd, const double* dPs, double* Xd, double* Xs,
+              double* work, hipStream_t st) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    const LevelDesc& lv = P.lv[0];
+    const size_t nF = packed_elems(lv, EF), nS = packed_elems(lv, ET);
+    BandArgs a;
+    a.Sig = Sig; a.Sub = Sub; a.dPd = dPd; a.dPs = dPs; a.Xd = Xd; a.Xs = Xs;
+    double* w = work;
+    a.PhiL = w; w += nF;
+    a.PhiR = w; w += nF;
+    a.QL = w; w += nS;
+    a.QR = w; w += nS;
+    a.loc = w; w += nS;
+    double* Lr = w; w += nS;
+    double* Rr = w; w += nS;
+    double* seg = w;
+    a.Lr = Lr; a.Rr = Rr;
+    dim3 grid(lv.Lpad / 64), block(64);
+    hipLaunchKernelGGL((k_band_prepare<D>), grid, block, 0, st, lv, a);
+    MFGM_CHECK_LAUNCH();
+    int rc = congruence_scan_impl<D>(P, a.PhiL, a.QL, Lr, seg, st);
+    if (rc) return rc;
+    rc = congruence_scan_impl<D>(P, a.PhiR, a.QR, Rr, seg, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_band_finish<D>), grid, block, 0, st, lv, a);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 size_t mfgm_congruence_scan_workspace_doubles(const mfgm_plan* plan) {
@@ -94,6 +131,20 @@ int mfgm_congruence_scan(const mfgm_plan* plan, const double* Phi, const double*
     if (!plan || !Phi || !Q || !X || !seg || plan->p.wide) return 1;
     const Plan& P = plan->p;
     MFGM_DISPATCH_D(P.d, (congruence_scan_impl<DD>(P, Phi, Q, X, seg, (hipStream_t)stream)));
+}
+
+size_t mfgm_band_workspace_doubles(const mfgm_plan* plan) {
+    if (!plan || plan->p.wide) return 0;
+    const Plan& P = plan->p;
+    const int d = P.d;
+    return 2 * packed_elems(P.lv[0], d * d) + 5 * packed_elems(P.lv[0], d * (d + 1) / 2) + scan_ws_doubles(P);
+}
+
+int mfgm_band_sigma_dP_sigma(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* dPd, const double* dPs, double* Xd,
+                             double* Xs, double* work, void* stream) {
+    if (!plan || !Sig || !Sub || !dPd || !dPs || !Xd || !Xs || !work || plan->p.wide) return 1;
+    const Plan& P = plan->p;
+    MFGM_DISPATCH_D(P.d, (band_impl<DD>(P, Sig, Sub, dPd, dPs, Xd, Xs, work, (hipStream_t)stream)));
 }
 
 size_t mfgm_vdp_workspace_doubles(const mfgm_plan* plan) {

@@ -151,6 +151,16 @@ class Plan:
         _lib.check(self.lib.mfgm_congruence_scan(self.h, _ptr(Phi), _ptr(Q), _ptr(X), _ptr(self._scan_ws), _stream()), "mfgm_congruence_scan")
         return X
 
+    def band_of_sigma_dP_sigma(self, Sig, Sub, dPd, dPs):
+        """Packed (X_tt SYM, X_{t+1,t} FULL) of X = Sigma dP Sigma from the packed band of Sigma (Sig SYM, Sub FULL) and of the symmetric
+        block-tri-diagonal dP (dPd SYM, dPs FULL); d <= 8 (mfgm_band_sigma_dP_sigma)."""
+        if getattr(self, "_band_ws", None) is None:
+            self._band_ws = torch.empty(max(int(self.lib.mfgm_band_workspace_doubles(self.h)), 1), dtype=torch.float64, device=self.device)
+        Xd, Xs = self.empty(SYM), self.zeros(FULL)
+        _lib.check(self.lib.mfgm_band_sigma_dP_sigma(self.h, _ptr(Sig), _ptr(Sub), _ptr(dPd), _ptr(dPs), _ptr(Xd), _ptr(Xs), _ptr(self._band_ws),
+                                                     _stream()), "mfgm_band_sigma_dP_sigma")
+        return Xd, Xs
+
     def gather_nodes(self, kind, packed, node_ids, out=None):
         """node_ids: int64 device tensor of b*T + t.  Returns natural [n, d] or [n, d, d] (written into `out` when given)."""
         n = node_ids.numel()

@@ -93,14 +93,16 @@ def spd_inverse_from_chol(L):
 
 
 # ---- theta -> eta through the HIP sweeps -------------------------------------------------------------------------------------------------
-def _marginals(plan, lin, diag, sub):
+def _marginals(plan, lin, diag, sub, mean_only=False):
     """(mu, Sigma_tt, Sigma_{t+1,t}) natural-layout tensors of the chain with naturals (lin or None, diag, sub): pack, factor, selected
-    inverse, unpack."""
+    inverse, unpack.  mean_only: (mu, None, None) -- the sub-diagonal blocks are not formed and nothing but mu is unpacked."""
     T = plan.T
     f = plan.factor(plan.pack(SYM, diag), plan.pack(FULL, sub) if T > 1 else plan.zeros(FULL), None if lin is None else plan.pack(VEC, lin),
                     aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
-    s = plan.selinv(f["L"], f["G"], f["y"], want_sub=True)
+    s = plan.selinv(f["L"], f["G"], f["y"], want_sub=not mean_only)
     plan.check_info()
+    if mean_only:
+        return plan.unpack(VEC, s["x"]), None, None
     mu = None if lin is None else plan.unpack(VEC, s["x"])
     cov = plan.unpack(SYM, s["Sig"])
     if T > 1:
@@ -156,6 +158,12 @@ def band_of_sigma_dP_sigma(cov, csub, dPd, dPs, plan=None):
     dPs [B,T-1,d,d] = dP_{t+1,t}).  Exact (module docstring); d x d solves through vidp_amd.linalg (HIP batched Cholesky / trsm)."""
     from . import linalg
     B, T, d, _ = cov.shape
+    if (plan is not None and not plan.wide and cov.is_cuda and (B, T, d) == (plan.B, plan.T, plan.d) and T > 1
+            and os.environ.get("VIDP_TAPE_TORCH_SCAN", "0") != "1"):
+        # the whole of it on the packed layout (csrc/mfgm_band.h): one Cholesky per node, the two recurrences, the assembly
+        Xd, Xs = plan.band_of_sigma_dP_sigma(plan.pack(SYM, cov.contiguous()), plan.pack(FULL, csub.contiguous()),
+                                             plan.pack(SYM, dPd.contiguous()), plan.pack(FULL, dPs.contiguous()))
+        return plan.unpack(SYM, Xd), plan.unpack(FULL, Xs, T - 1)
     loc = cov @ dPd @ cov                                               # Sigma_t dP_tt Sigma_t
     if T == 1:
         return loc, csub
@@ -208,14 +216,16 @@ def fisher_vector_product(plan, diag, sub, mu, cov, csub, g_lin, g_diag, g_sub):
     g = (g_lin, g_diag, g_sub), which is also the vector-Jacobian product (F is symmetric).  Used by the tape and by
     CVISitesSDE.grad_VE_wrt_prior_params (variational_cvi_sde.py:508-518)."""
     g_diag = 0.5 * (g_diag + _T(g_diag))        # eta_diag is symmetric: only the symmetric part of its cotangent acts
-    gmax = max(float(g_lin.abs().max()), float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
+    # one host round trip for the three magnitudes (a zero cotangent part skips its work)
+    zero = torch.zeros((), dtype=g_lin.dtype, device=g_lin.device)
+    mx = torch.stack([g_lin.abs().max(), g_diag.abs().max(), g_sub.abs().max() if g_sub.numel() else zero]).tolist()
+    gmax, gm = max(mx), max(mx[1], mx[2])
     if gmax == 0.0:
         return torch.zeros_like(g_lin), torch.zeros_like(g_diag), torch.zeros_like(g_sub)
     # d mu: one solve with the unperturbed precision
-    dmu = _marginals(plan, g_lin - _precision_times(plan, g_diag, g_sub, mu), diag, sub)[0]
+    dmu = _marginals(plan, g_lin - _precision_times(plan, g_diag, g_sub, mu), diag, sub, mean_only=True)[0]
     # d Sigma (diagonal and sub-diagonal blocks) = -band(Sigma dP Sigma)
     dcov, dsub = torch.zeros_like(g_diag), torch.zeros_like(g_sub)
-    gm = max(float(g_diag.abs().max()), float(g_sub.abs().max()) if g_sub.numel() else 0.0)
     if gm > 0.0 and not NaturalsToExpectations.richardson:
         Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub, plan=plan)
         dcov, dsub = -Xd, -Xs
