@@ -1660,7 +1660,7 @@ def test_trainers_two_processes_share_the_batch():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
 
 
-@pytest.mark.parametrize("B,T,d", [(2, 9, 3), (1, 130, 2), (3, 33, 6)])
+@pytest.mark.parametrize("B,T,d", [(2, 9, 3), (1, 130, 2), (3, 33, 6), (1, 2, 1), (2, 60, 8), (66, 5, 4), (2, 41, 7)])
 def test_exact_band_of_sigma_dP_sigma(amd, rng, B, T, d):
     """The covariance half of the Fisher-vector product behind `tape.NaturalsToExpectations.backward` (ssm_natgrad.py:142-172 takes it
     from a GradientTape through the banded ops): the band of Sigma dP Sigma from the band of Sigma alone (congruence scans), against the
