@@ -268,7 +268,8 @@ int mfgm_cq_slots(const mfgm_plan* plan, const long long* node_ids, int n, int* 
  * quad [B] (may be NULL). */
 int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
                    int* info, void* stream);
-/* one level-0 kernel of it alone (stage 0 reduce, 1 forward), as mfgm_packed_factor_stage */
+/* one part of it alone (profiling): stage 0 the level-0 reduce, 1 the level-0 forward (as mfgm_packed_factor_stage), 2 the levels above
+ * the finest one (their reduces, the fused coarse kernel, their forwards) on whatever the last stage 0 left in the workspace */
 int mfgm_cq_factor_stage(const mfgm_plan* plan, int stage, const mfgm_cq_state* q, double* L, double* y, void* ws, int* info,
                          void* stream);
 /* backward sweep fused with update_girsanov_sites (variational_cvi_sde.py:279-299): dyn_out = (1 - lr) dyn + lr theta~ (out of place;
@@ -277,7 +278,8 @@ int mfgm_cq_selinv_girsanov(const mfgm_plan* plan, int only_level, const mfgm_cq
                             const mfgm_sde_params* prm, double* dyn_out, void* ws, void* stream);
 /* backward sweep with the KL sum (mfgm_packed_selinv_kl): marginals Sig (SYM), x (VEC) -- both NULL: not written, the ELBO needs only
  * the sums and the observation nodes --, kl_part [B]; obs_mu [n, d] / obs_cov [n, d, d] (both or neither) receive the marginals at
- * the observation nodes, in observation order. */
+ * the observation nodes, in observation order.  only_level 0: the level-0 kernel alone, > 0: the levels above it alone (profiling),
+ * < 0: everything. */
 int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state* q, const double* L, const double* y,
                       const mfgm_sde_params* prm, double* Sig, double* x, double* kl_part, double* obs_mu, double* obs_cov, void* ws,
                       void* stream);

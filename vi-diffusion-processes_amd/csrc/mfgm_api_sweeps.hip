@@ -285,7 +285,7 @@ int cq_factor_impl(const Plan& P, const CqArgs& q, double* Lg, double* yg, doubl
         hipLaunchKernelGGL((k_reduce_cq<D>), grid, block, 0, st, a0, q);
         MFGM_CHECK_LAUNCH();
     }
-    if (only_stage < 0) {
+    if (only_stage < 0 || only_stage == 2) {         // stage 2 (profiling): the levels above the finest one alone
         const int lf = coarse_fuse_from(P);
         for (int l = 1; l < K && l < lf; ++l) {
             SweepArgs a = coarse_level_args(P, l, ws, info);
@@ -357,6 +357,7 @@ int cq_selinv_kl_impl(const Plan& P, const CqArgs& q, const double* Lg, const do
         int rc = cq_coarse_backward<D>(P, ws, st);
         if (rc) return rc;
     }
+    if (only_level > 0) return 0;                    // profiling: the levels above the finest one alone
     SweepArgs a;
     memset(&a, 0, sizeof(a));
     a.lv = P.lv[0];
@@ -573,7 +574,7 @@ int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, dou
 
 int mfgm_cq_factor_stage(const mfgm_plan* plan, int stage, const mfgm_cq_state* q, double* L, double* y, void* ws, int* info,
                          void* stream) {
-    if (!cq_ok(plan, q) || !L || !y || !ws || !info || stage < 0 || stage > 1) return 1;
+    if (!cq_ok(plan, q) || !L || !y || !ws || !info || stage < 0 || stage > 2) return 1;
     const Plan& P = plan->p;
     const CqArgs c = cq_args(q);
     MFGM_DISPATCH_D(P.d, (cq_factor_impl<DD>(P, c, L, y, nullptr, nullptr, (double*)ws, info, (hipStream_t)stream, stage)));
