@@ -82,11 +82,14 @@ int launch_backward(const SweepArgs& a, bool has_rhs, bool has_up, bool want_sub
 }
 
 // First level handled by the fused coarse-level kernels (k_coarse_factor / k_coarse_backward): the lowest level >= 1 whose chains
-// have at most `MFGM_FUSE_P` (default 256 = one lane per segment in a 256-thread workgroup) segments; nlevels when fusing is off
-// (MFGM_COARSE_FUSED=0) or no such level exists.  Levels 1 .. l0-1 keep one launch per level and pass.
+// have at most `MFGM_FUSE_P` segments (default 128); nlevels when fusing is off (MFGM_COARSE_FUSED=0) or no such level exists.
+// Levels 1 .. l0-1 keep one launch per level and pass.  The fused kernels could take 256 segments per chain (one lane each in a
+// 256-thread workgroup), but four wavefronts of one workgroup share their CU's texture-address unit: by the per-phase stamps of
+// DESIGN 5c a 256-segment level costs 1.6 x per block step what a 64-segment level costs inside the fused kernel, while as a launch of
+// its own its wavefronts spread over the idle CUs -- three more launches per refresh, 14 us less at the headline size.
 int coarse_fuse_from(const Plan& P) {
     static const int enabled = [] { const char* e = getenv("MFGM_COARSE_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
-    static const int maxp = [] { const char* e = getenv("MFGM_FUSE_P"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    static const int maxp = [] { const char* e = getenv("MFGM_FUSE_P"); int v = e ? atoi(e) : 0; return v > 0 ? std::min(v, 256) : 128; }();
     if (!enabled || P.nlevels < 2) return P.nlevels;
     for (int l = 1; l < P.nlevels; ++l)
         if (P.lv[l].P <= maxp) return l;
