@@ -52,6 +52,11 @@ def load():
         lib.ref_cvigp_step.restype = ctypes.c_double
         lib.ref_cvigp_step.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, _dp, _dp, ctypes.c_double, ctypes.c_double,
                                        _dp, _dp, _dp]
+        lib.ref_sparse_cvi_step_work_doubles.restype = ctypes.c_size_t
+        lib.ref_sparse_cvi_step_work_doubles.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.ref_sparse_cvi_step.restype = ctypes.c_double
+        lib.ref_sparse_cvi_step.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double,
+                                            _dp, _dp, ctypes.c_double, _dp, _dp, _dp, _dp]
         lib.ref_num_threads.restype = ctypes.c_int
         lib.ref_set_num_threads.argtypes = [ctypes.c_int]
         lib.ref_set_num_threads.restype = None
@@ -211,3 +216,36 @@ class CviGpStepState:
         """update_sites(); elbo() -> the ELBO."""
         return load().ref_cvigp_step(self.T, self.d, _p(self.pd), _p(self.ps), self.half_logdet_prior, _p(self.h), _p(self.y), self.s2,
                                      self.lr, _p(self.nat1), _p(self.nat2), _p(self.work))
+
+
+class SparseCviStepState:
+    """Host arrays for ref_sparse_cvi_step: sparse / inducing-state CVI (oracle/np_conditionals.SparseCVIGaussianProcess), one chain, scalar
+    Gaussian likelihood.  The data-dependent constants -- interval index, h^T P_n, h^T T_n h of every data point -- and the prior's
+    precision blocks come from the NumPy oracle's kernel, once (the GPU model computes its own once as well)."""
+
+    def __init__(self, kernel, z, t, y, noise_variance, learning_rate):
+        from . import np_conditionals as npc
+        z, t = np.asarray(z, dtype=np.float64), np.asarray(t, dtype=np.float64)
+        ssm = kernel.state_space_model(z)
+        pd, ps = ssm.precision()
+        self.pd, self.ps = c64(pd), c64(ps)
+        self.M, self.d = self.pd.shape[0], self.pd.shape[-1]
+        self.pslc = -0.5 * float(ssm.log_det_precision())
+        P, T, idx = npc.conditional_statistics(t, z, kernel)
+        h = kernel.emission_vector()[0]
+        self.w = c64(np.einsum("i,nij->nj", h, P))
+        self.c = c64(np.einsum("i,nij,j->n", h, T, h))
+        self.idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.N = self.idx.shape[0]
+        self.y = c64(y).reshape(-1)
+        self.pinf = c64(kernel.steady_state_covariance() + kernel.jitter * np.eye(self.d))
+        self.s2, self.lr = float(noise_variance), float(learning_rate)
+        self.nat1 = np.zeros((self.M + 1, 2 * self.d))
+        self.nat2 = np.zeros((self.M + 1, 2 * self.d, 2 * self.d))
+        self.work = np.zeros(load().ref_sparse_cvi_step_work_doubles(self.M, self.d))
+
+    def step(self):
+        """update_sites(data); classic_elbo(data) -> the ELBO."""
+        return load().ref_sparse_cvi_step(self.M, self.d, self.N, self.idx.ctypes.data_as(_ip), _p(self.w), _p(self.c), _p(self.y), self.s2,
+                                          self.lr, _p(self.pd), _p(self.ps), self.pslc, _p(self.pinf), _p(self.nat1), _p(self.nat2),
+                                          _p(self.work))

@@ -824,6 +824,116 @@ double ref_cvigp_step(int T, int d, const double* Pd, const double* Ps, double h
     return -0.5 * log(2.0 * M_PI) * T - 0.5 * term1 + 0.5 * term2 + half_logdet_prior - ref_btd_logdet(Ld, T, d) + 0.5 * logdet_r;
 }
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Sparse / inducing-state CVI (SparseCVIGaussianProcess, sparse_variational_cvi.py:38-292), one chain of M inducing states of
+ * dimension d, scalar output, Gaussian likelihood of variance s2, zero-mean prior: one iteration of
+ *   update_sites(data); classic_elbo(data)
+ * as oracle/np_conditionals.SparseCVIGaussianProcess does them.  The sites live on the M + 1 intervals between consecutive inducing
+ * states (nat1 [M+1, 2d], nat2 [M+1, 2d, 2d]; interval j couples states j-1 and j, the two end intervals have one real state and a
+ * virtual one with the prior's stationary covariance Pinf).  Data point n lies in interval idx[n]; w [N, 2d] = h^T P_n and c [N] =
+ * h^T T_n h are the conditional statistics of f(t_n) given the two states (conditionals.py:207-256), computed once by the caller.
+ * Pd [M,d,d], Ps [M-1,d,d]: prior precision blocks; pslc: the prior's sum of log Cholesky diagonals (-1/2 log|K^-1|).
+ * work: ref_sparse_cvi_step_work_doubles(M, d) doubles.  Returns the ELBO.
+ * ------------------------------------------------------------------------------------------------------------ */
+size_t ref_sparse_cvi_step_work_doubles(int M, int d) { return (size_t)M * (7 * d * d + 3 * d) + (size_t)(M + 1) * (2 * d + 4 * d * d); }
+
+static void sparse_posterior(int M, int d, const double* Pd, const double* Ps, const double* nat1, const double* nat2, double* D,
+                             double* S, double* lin, double* Ld, double* Ls, double* yv, double* mu, double* Sd, double* Ss,
+                             double* logdetL) {
+    const int dd = d * d, d2 = 2 * d;
+    /* precision = prior precision - 2 (overlap-added nat2), linear part = overlap-added nat1 */
+    for (int k = 0; k < M; ++k) {
+        const double* a1 = nat1 + (size_t)(k + 1) * d2;          /* interval k+1: its left half belongs to state k */
+        const double* b1 = nat1 + (size_t)k * d2 + d;            /* interval k: its right half belongs to state k */
+        const double* a2 = nat2 + (size_t)(k + 1) * d2 * d2;
+        const double* b2 = nat2 + (size_t)k * d2 * d2;
+        for (int r = 0; r < d; ++r) {
+            lin[(size_t)k * d + r] = a1[r] + b1[r];
+            for (int c = 0; c < d; ++c)
+                D[(size_t)k * dd + IDX(r, c, d)] = Pd[(size_t)k * dd + IDX(r, c, d)] - 2.0 * (a2[(size_t)r * d2 + c] + b2[(size_t)(d + r) * d2 + d + c]);
+        }
+        if (k < M - 1)
+            for (int r = 0; r < d; ++r)
+                for (int c = 0; c < d; ++c)                      /* block (state k+1, state k) of interval k+1: rows d.., columns ..d */
+                    S[(size_t)k * dd + IDX(r, c, d)] = Ps[(size_t)k * dd + IDX(r, c, d)] - 2.0 * a2[(size_t)(d + r) * d2 + c];
+    }
+    ref_btd_cholesky(D, S, Ld, Ls, M, d);
+    ref_btd_solve(Ld, Ls, lin, yv, M, d, 0);
+    ref_btd_solve(Ld, Ls, yv, mu, M, d, 1);
+    ref_btd_inverse_blocks(Ld, Ls, Sd, Ss, M, d);
+    *logdetL = ref_btd_logdet(Ld, M, d);
+}
+
+/* mean and variance of f at data point n from the marginals of the two states of its interval */
+static void sparse_predict(int M, int d, int j, const double* w, double c, const double* mu, const double* Sd, const double* Ss,
+                           const double* Pinf, double* fm, double* fv) {
+    const int dd = d * d;
+    const double* wl = w;
+    const double* wr = w + d;
+    const double* SL = (j > 0) ? Sd + (size_t)(j - 1) * dd : Pinf;
+    const double* SR = (j < M) ? Sd + (size_t)j * dd : Pinf;
+    double m = 0.0, v = c;
+    for (int r = 0; r < d; ++r) {
+        if (j > 0) m += wl[r] * mu[(size_t)(j - 1) * d + r];
+        if (j < M) m += wr[r] * mu[(size_t)j * d + r];
+        for (int q = 0; q < d; ++q) {
+            v += wl[r] * SL[IDX(r, q, d)] * wl[q] + wr[r] * SR[IDX(r, q, d)] * wr[q];
+            if (j > 0 && j < M) v += 2.0 * wr[r] * Ss[(size_t)(j - 1) * dd + IDX(r, q, d)] * wl[q];      /* Sigma_{j,j-1} */
+        }
+    }
+    *fm = m;
+    *fv = v;
+}
+
+double ref_sparse_cvi_step(int M, int d, int N, const int* idx, const double* w, const double* c, const double* y, double s2, double lr,
+                           const double* Pd, const double* Ps, double pslc, const double* Pinf, double* nat1, double* nat2, double* work) {
+    const int dd = d * d, d2 = 2 * d;
+    double* D = work;
+    double* S = D + (size_t)M * dd;
+    double* Ld = S + (size_t)M * dd;
+    double* Ls = Ld + (size_t)M * dd;
+    double* Sd = Ls + (size_t)M * dd;
+    double* Ss = Sd + (size_t)M * dd;
+    double* Pp = Ss + (size_t)M * dd;                 /* scratch for the KL terms */
+    double* lin = Pp + (size_t)M * dd;
+    double* yv = lin + (size_t)M * d;
+    double* mu = yv + (size_t)M * d;
+    double* s1 = mu + (size_t)M * d;
+    double* sq = s1 + (size_t)(M + 1) * d2;
+    double logdetL;
+    /* update_sites */
+    sparse_posterior(M, d, Pd, Ps, nat1, nat2, D, S, lin, Ld, Ls, yv, mu, Sd, Ss, &logdetL);
+    memset(s1, 0, (size_t)(M + 1) * d2 * sizeof(double));
+    memset(sq, 0, (size_t)(M + 1) * d2 * d2 * sizeof(double));
+    for (int n = 0; n < N; ++n) {
+        const int j = idx[n];
+        const double* wn = w + (size_t)n * d2;
+        double fm, fv;
+        sparse_predict(M, d, j, wn, c[n], mu, Sd, Ss, Pinf, &fm, &fv);
+        const double dmu = (y[n] - fm) / s2, dvar = -0.5 / s2 + 0.0 * fv;
+        const double g1 = dmu - 2.0 * dvar * fm, g2 = dvar;
+        for (int r = 0; r < d2; ++r) {
+            s1[(size_t)j * d2 + r] += wn[r] * g1;
+            for (int q = 0; q < d2; ++q) sq[(size_t)j * d2 * d2 + (size_t)r * d2 + q] += g2 * wn[r] * wn[q];
+        }
+    }
+    for (size_t i = 0; i < (size_t)(M + 1) * d2; ++i) nat1[i] = (1.0 - lr) * nat1[i] + lr * s1[i];
+    for (size_t i = 0; i < (size_t)(M + 1) * d2 * d2; ++i) nat2[i] = (1.0 - lr) * nat2[i] + lr * sq[i];
+    /* classic_elbo with the new sites */
+    sparse_posterior(M, d, Pd, Ps, nat1, nat2, D, S, lin, Ld, Ls, yv, mu, Sd, Ss, &logdetL);
+    double ve = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double fm, fv;
+        sparse_predict(M, d, idx[n], w + (size_t)n * d2, c[n], mu, Sd, Ss, Pinf, &fm, &fv);
+        ve += -0.5 * log(2.0 * M_PI) - 0.5 * log(s2) - 0.5 * ((y[n] - fm) * (y[n] - fm) + fv) / s2;
+    }
+    memset(lin, 0, (size_t)M * d * sizeof(double));     /* prior means: zero */
+    double tr, mh;
+    ref_kl_terms(Sd, Ss, mu, Pd, Ps, lin, M, d, &tr, &mh);
+    (void)Pp;
+    return ve - 0.5 * (tr + mh - (double)M * d + 2.0 * pslc + 2.0 * logdetL);
+}
+
 void ref_set_num_threads(int n) {
     if (n > 0) omp_set_num_threads(n);
 }

@@ -162,3 +162,26 @@ def test_c_cvigp_step(rng, kname, T):
         np.testing.assert_allclose(e, o.elbo(), rtol=1e-10)
         np.testing.assert_allclose(st.nat1, o.nat1[:, 0], rtol=1e-10, atol=1e-13)
         np.testing.assert_allclose(st.nat2, o.nat2[:, 0, 0], rtol=1e-10)
+
+
+@pytest.mark.parametrize("kname,M", [("sum", 12), ("m52", 25), ("m12", 7)])
+def test_c_sparse_cvi_step(rng, kname, M):
+    """The C port of the sparse / inducing-state CVI step (ref_sparse_cvi_step: update_sites + classic_elbo -- bench.py's config-5
+    cpu_baseline) against the NumPy oracle model (oracle/np_conditionals.SparseCVIGaussianProcess, pinned to the reference's KA8 known
+    answers), over damped steps, with data before the first and after the last inducing point: ELBO and both site arrays."""
+    from oracle import np_conditionals as npc, np_kernels
+    k = {"sum": np_kernels.Sum([np_kernels.Matern32(1.1, 0.7), np_kernels.Matern12(0.5, 1.2)]), "m52": np_kernels.Matern52(0.7, 1.3),
+         "m12": np_kernels.Matern12(2.0, 2.25)}[kname]
+    z = np.linspace(0.0, 5.0, M) + rng.uniform(0, 0.05, size=M)
+    t = np.sort(np.concatenate([rng.uniform(-0.4, 5.5, size=3 * M), [-0.3, -0.1, 5.2, 5.45]]))
+    y = np.sin(2 * t)[:, None] + 0.2 * rng.normal(size=(t.size, 1))
+    noise, lr = 0.3, 0.6
+    o = npc.SparseCVIGaussianProcess(k, z, np_models.GaussianLik(noise), learning_rate=lr)
+    st = c_ref.SparseCviStepState(k, z, t, y, noise, lr)
+    assert st.idx.min() == 0 and st.idx.max() == M
+    for _ in range(4):
+        e = st.step()
+        o.update_sites(t, y)
+        np.testing.assert_allclose(e, o.classic_elbo(t, y), rtol=1e-9)
+        np.testing.assert_allclose(st.nat1, o.nat1, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(st.nat2, o.nat2, rtol=1e-9, atol=1e-12)
