@@ -76,6 +76,18 @@ class Gaussian:
         v = self.variance
         return -0.5 * math.log(2 * math.pi) - 0.5 * math.log(v) - 0.5 * ((observations - f_means) ** 2 + f_vars) / v
 
+    def variational_expectations_terms(self, f_means, f_vars, observations):
+        """(c, w, [t1, t2]) with  sum of variational_expectations = c + w (t1 + t2): the two reductions |y - m|^2 and sum var as device
+        scalars, for callers that assemble their bound in one launch (mfgm_combine_terms)."""
+        v = self.variance
+        r = (observations - f_means).reshape(-1)
+        return -0.5 * r.numel() * (math.log(2 * math.pi) + math.log(v)), -0.5 / v, [torch.dot(r, r).reshape(1), f_vars.sum().reshape(1)]
+
+    def variational_expectations_sum(self, f_means, f_vars, observations):
+        """sum of variational_expectations over all points, from two reductions instead of seven element-wise passes and one."""
+        c, w, (t1, t2) = self.variational_expectations_terms(f_means, f_vars, observations)
+        return c + w * (t1 + t2)[0]
+
     def ve_gradients_expectation(self, f_means, f_vars, observations):
         # (y / v, -1/2 / v) depend on the observations only: computed once per observation tensor object and version
         v = self.variance

@@ -310,6 +310,14 @@ class SparseCVIGaussianProcess:
         self._marg = dict(version=self._key(), mu=mu, Sig=Sig, Sub=Sub, packed=s, logdetL=f["logdet"])
         return self._marg
 
+    @staticmethod
+    def _own_observations(data, observations):
+        """observations[data["own"]] as ONE tensor object per (data set, observation tensor, version)."""
+        c = data.get("y_own")
+        if c is None or c[0] is not observations or c[1] != observations._version:
+            c = data["y_own"] = (observations, observations._version, observations[data["own"]])
+        return c[2]
+
     def _predict_f_data(self, data):
         """(fmu, fvar) [N, 1] at the data points from the cached marginals (mfgm_sparse_predict)."""
         import ctypes
@@ -349,7 +357,10 @@ class SparseCVIGaussianProcess:
         from .packed import _ptr, _stream
         time_points, observations = input_data
         fx_mus, fx_covs = self._predict_f_data(data)
-        _, grads = self.local_objective_and_gradients(fx_mus, fx_covs, observations[data["own"]])
+        # the gradients alone: the reference's local_objective_and_gradients also returns the objective value, which update_sites drops
+        # (:187-189) -- eight element-wise launches over the observations per step here; and the SAME tensor object for the owned
+        # observations every step, so that a likelihood's per-observation-tensor caches hit (a fresh slice object never would)
+        grads = self._likelihood.ve_gradients_expectation(fx_mus, fx_covs, self._own_observations(data, observations))
         g1, g2 = grads[0].reshape(-1).contiguous(), grads[1].reshape(-1).contiguous()
         pl = self.dist_p.plan
         self._sync_sites()
@@ -417,7 +428,25 @@ class SparseCVIGaussianProcess:
             ve = self._likelihood.variational_expectations(fx_mus, fx_covs, observations).sum()
             return ve - q.kl_divergence(self.dist_p).sum()
         fx_mus, fx_covs = self._predict_f_data(data)
-        ve = self._likelihood.variational_expectations(fx_mus, fx_covs, observations[data["own"]]).sum()
+        y_own = self._own_observations(data, observations)
+        ve_terms = getattr(self._likelihood, "variational_expectations_terms", None)
+        kc = getattr(self, "_kl_cache", None)
+        if ve_terms is not None and self._shard is None and kc is not None and kc[0] == self._key():
+            # every piece of the bound is a device scalar by now: assemble  VE - KL  in one launch (a dozen scalar torch kernels otherwise),
+            # NaN-poisoned when a pivot block of the factorisation was not positive definite
+            import ctypes
+            from . import _lib
+            from .packed import _ptr, _stream
+            m, pn, p = self._marginals(), self._prior_natural(), self.dist_p
+            c, w, (t1, t2) = ve_terms(fx_mus, fx_covs, y_own)
+            terms = torch.cat([t1, t2, kc[1].reshape(1), kc[2].reshape(1), pn["nat"]["sumlogchol"].reshape(1), m["logdetL"].reshape(1)])
+            wts = (ctypes.c_double * 6)(w, w, -0.5, -0.5, -1.0, -1.0)
+            out = torch.empty(1, dtype=torch.float64, device=terms.device)
+            _lib.check(p.plan.lib.mfgm_combine_terms(6, 1, _ptr(terms), wts, c + 0.5 * float(p.T * p.d), None, 0.0, _ptr(p.plan.info), None,
+                                                     _ptr(out), _stream()), "mfgm_combine_terms")
+            return out[0]
+        ve_sum = getattr(self._likelihood, "variational_expectations_sum", None)
+        ve = ve_sum(fx_mus, fx_covs, y_own) if ve_sum is not None else self._likelihood.variational_expectations(fx_mus, fx_covs, y_own).sum()
         # KL[q || p] from the marginal blocks of q and the prior's naturals (state_space_model.py:528-593); the prior mean is zero
         m, pn = self._marginals(), self._prior_natural()
         p = self.dist_p
