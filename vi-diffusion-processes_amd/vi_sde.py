@@ -309,12 +309,20 @@ class VariationalMarkovGP:
         """KL[q(x0) || p(x0)] per trajectory (vi_sde.py:416-420)."""
         d = self.state_dim
         mu0, P0inv, ldP0 = self._prior_x0_device()
+        # a function of q(x0) and p(x0) alone (~15 d x d launches): kept until either moves (update_initial_statistics assigns new tensors,
+        # in-place edits move the version counters, the prior's initial state is compared by value)
+        key = (self.q0_mu, self.q0_mu._version, self.q0_chol, self.q0_chol._version, mu0, P0inv)
+        c = getattr(self, "_kl0", None)
+        if c is not None and len(c[0]) == len(key) and all(a is b if isinstance(a, torch.Tensor) else a == b for a, b in zip(c[0], key)):
+            return c[1]
         S0 = self.q0_chol @ self.q0_chol.transpose(-1, -2)
         dm = mu0 - self.q0_mu
         tr = (P0inv * S0).sum(dim=(-1, -2))
         mh = ((dm @ P0inv) * dm).sum(-1)
         ld0 = 2.0 * torch.log(torch.diagonal(self.q0_chol, dim1=-2, dim2=-1)).sum(-1)
-        return 0.5 * (tr + mh - d + ldP0 - ld0)
+        out = 0.5 * (tr + mh - d + ldP0 - ld0)
+        self._kl0 = (key, out)
+        return out
 
     def _prior_x0_device(self):
         """(mu0, P0^{-1}, log det P0) of the prior initial state on the device: computed once per (p0_mu, p0_cov), not on every
@@ -332,7 +340,9 @@ class VariationalMarkovGP:
         lik = self.likelihood
         if pl.d <= 8 and hasattr(lik, "inv_covariance") and hasattr(lik, "log_det_chol"):
             # multivariate Gaussian likelihood: gather, arithmetic and per-trajectory sums in one launch
-            cst = -float(lik.log_det_chol) - 0.5 * lik.obs_dim * math.log(2.0 * math.pi)
+            cst = getattr(lik, "ve_constant", None)             # host scalar kept by the likelihood: float(device tensor) here is a sync per ELBO
+            if cst is None:
+                cst = -float(lik.log_det_chol) - 0.5 * lik.obs_dim * math.log(2.0 * math.pi)
             e_obs = pl.mvn_obs_ve(m, S, self.obs_node_ids, self.n_obs, self.observations.reshape(n, d).contiguous(), lik.inv_covariance, cst)
         else:
             mu = pl.gather_nodes(VEC, m, self.obs_node_ids)
