@@ -321,6 +321,8 @@ def test_coarse_row_bodies_agree_with_lane_bodies(amd, rng, monkeypatch, B, T, d
     for a, b in zip(*outs):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-9, atol=1e-11)
         differs |= bool((a != b).any())
-    assert differs or d == 1, "the two routes produced bit-identical arrays: the row bodies did not run"   # 1 x 1 blocks: same operations
+    import os
+    fused_off = os.environ.get("MFGM_COARSE_FUSED") == "0"       # the row bodies live in the fused kernels
+    assert differs or d == 1 or fused_off, "the two routes produced bit-identical arrays: the row bodies did not run"   # 1 x 1 blocks: same operations
     Ld, Ls = np_btd.cholesky(diag, sub)
     assert_close(outs[0][0].cpu().numpy(), Ld)
