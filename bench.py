@@ -205,7 +205,7 @@ def vdp_step_rate(B, T, d, dt, noise, idx, ys, device, steps=10):
     grid = np.arange(T) * dt
     lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))
     m = VariationalMarkovGP((grid[idx], torch.from_numpy(ys).to(device)), DoubleWellSDE(q=torch.eye(d, dtype=torch.float64)), grid, lik,
-                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=vidp_amd.Plan(B, T, d, device=device))
+                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=None)
     eye = (4.0 * torch.eye(d, dtype=torch.float64, device=device)).expand(B, T, d, d).contiguous()
     m.plan.pack(vidp_amd.FULL, eye, out=m.A)
     del eye
@@ -321,7 +321,7 @@ def bench_vdp(h, data_rank):
     grid = np.arange(T) * dt
     lik = MultivariateGaussian(torch.from_numpy(obs_chol(d, noise)).to(device))
     m = VariationalMarkovGP((grid[idx], torch.from_numpy(ys).to(device)), DoubleWellSDE(q=torch.eye(d, dtype=torch.float64)), grid, lik,
-                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=vidp_amd.Plan(B, T, d, device=device))
+                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=None)
     # q starts at the OU drift -4 x: from A = 0 the marginal variance of a chain this long reaches T dt and the sixth-order moments
     # overflow the first update
     eye = (4.0 * torch.eye(d, dtype=torch.float64, device=device)).expand(B, T, d, d).contiguous()
@@ -619,9 +619,10 @@ def bench_cvidp(h, data_rank):
         what = (f"CVI-DP site-update loop (CVISitesSDE: update_data_sites + update_girsanov_sites + classic_elbo) on double-well SDE "
                 f"trajectories, T={T}, d={d}, {B} trajectories per GPU, observation every {args.obs_every} steps, correlated "
                 f"observation noise (full d x d data sites)")
-    plan = vidp_amd.Plan(B, T, d, device=device)
     grid = np.arange(T) * dt
-    model = CVISitesSDE(sde, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik, prior_initial_state=init, plan=plan)
+    # plan=None: the model builds its own partition, segments aligned with the equally spaced observation grid (packed.aligned_segment_length)
+    model = CVISitesSDE(sde, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik, prior_initial_state=init, plan=None)
+    plan = model.plan
 
     elbos, first_elbo = [], []
 

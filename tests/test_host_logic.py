@@ -144,3 +144,23 @@ def test_one_chain_exchange_volume_at_config5():
     assert covered == levels[X][0]
     assert lib.mfgm_plan_set_shard_level(h, desc[0], 0, 1) == 1          # no such level
     lib.mfgm_plan_destroy(h)
+
+
+def test_observation_aligned_segment_length():
+    """packed.aligned_segment_length / observation_period (host logic): equally spaced observations move the automatic level-0 segment
+    length up to the next multiple of their spacing; irregular observations, small problems, d > 8 and costly multiples keep the
+    automatic choice (0)."""
+    import numpy as np
+    import torch
+    import vidp_amd  # noqa: F401
+    from vidp_amd.packed import aligned_segment_length, observation_period
+    assert observation_period(torch.arange(49, 100000, 50)) == 50
+    assert observation_period(np.arange(5, 1000, 9)) == 9
+    assert observation_period(torch.tensor([3, 8, 14])) == 0 and observation_period(torch.tensor([7])) == 0
+    assert aligned_segment_length(64, 100000, 6, 50) == 100          # headline: ceil(6.4e6 / 65536) = 98 -> 100
+    assert aligned_segment_length(64, 50000, 6, 50) == 50            # config 3: 49 -> 50
+    assert aligned_segment_length(64, 100000, 6, 7) == 98            # already a multiple
+    assert aligned_segment_length(64, 100000, 6, 0) == 0 and aligned_segment_length(64, 100000, 6, 1) == 0
+    assert aligned_segment_length(1, 1001, 1, 31) == 0               # small problem: the automatic partition
+    assert aligned_segment_length(64, 100000, 16, 50) == 0           # wavefront-per-segment plans
+    assert aligned_segment_length(64, 100000, 6, 97) == 0            # 194 would leave half the lanes idle

@@ -47,13 +47,6 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
         const long long target = P.wide ? 8192 : 65536;
         long long r = ((long long)B * T + target - 1) / target;
         R0 = (int)std::min<long long>(std::max<long long>(r, 8), 1 << 20);
-        // prefer a segment length that divides the chain (no ragged last segment) when one is within 3 of the automatic choice: measured
-        // on the headline (98 -> 100: KL backward sweep 0.39 -> 0.35 ms, forward 0.43 -> 0.41, step -2 %) and on config 3 (49 -> 50: -3 %),
-        // on fast and slow boxes alike; odd lengths next to them (99, 101, 51) are the worst (tools/r0_sweep.sh)
-        // (large problems only -- r > 8, the lanes fill the chip: the partition of small chains stays what the accuracy tests pin)
-        if (!P.wide && r > 8)
-            for (int c = R0; c <= R0 + 3 && c <= T; ++c)
-                if (T % c == 0) { R0 = c; break; }
     }
     int n = T, l = 0;
     // chains this short are swept sequentially by one lane (narrow) or one wavefront (wide)

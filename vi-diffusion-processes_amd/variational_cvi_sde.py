@@ -16,7 +16,7 @@ import os
 import torch
 
 from ._lib import FULL, SYM, VEC
-from .packed import CqState, Plan
+from .packed import CqState, Plan, aligned_segment_length, observation_period
 from .state_space_model import StateSpaceModel
 
 
@@ -54,10 +54,12 @@ class CVISitesSSM:
         self.output_dim = self.state_dim
         self.T = int(self.time_grid.numel())
         self.device = observations.device
-        if plan is None:
-            plan = prior_ssm.plan if prior_ssm is not None else Plan(self.B, self.T, self.state_dim, device=self.device)
-        self.plan = plan
         self.obs_sites_indices = grid_indices(self.time_grid, obs_times).to(self.device)
+        if plan is None:
+            # segments aligned with an equally spaced observation grid (packed.aligned_segment_length)
+            r0 = aligned_segment_length(self.B, self.T, self.state_dim, observation_period(self.obs_sites_indices))
+            plan = prior_ssm.plan if prior_ssm is not None else Plan(self.B, self.T, self.state_dim, R0=r0, device=self.device)
+        self.plan = plan
         self.obs_node_ids = plan.node_ids(self.obs_sites_indices)
         d, pl = self.state_dim, plan
         # Girsanov sites start at nat1 = 0, nat2 = -1e-10 * ones (variational_cvi_sde.py:141-152).  They are not stored:

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib, linalg
 from ._lib import FULL, SYM, TRI, VEC
-from .packed import Plan, _ptr, _stream
+from .packed import Plan, _ptr, _stream, aligned_segment_length, observation_period
 from .variational_cvi_sde import grid_indices
 
 
@@ -37,7 +37,11 @@ class VariationalMarkovGP:
         self.dt = float(self.grid[1] - self.grid[0])
         self.device = observations.device
         d = self.state_dim
-        self.plan = plan if plan is not None else Plan(self.B, self.num_states, d, device=self.device)
+        if plan is None:
+            # segments aligned with an equally spaced observation grid (packed.aligned_segment_length)
+            r0 = aligned_segment_length(self.B, self.num_states, d, observation_period(grid_indices(self.grid, obs_times)))
+            plan = Plan(self.B, self.num_states, d, R0=r0, device=self.device)
+        self.plan = plan
         pl = self.plan
         self.lib = pl.lib
         if prior_initial_state is None:
