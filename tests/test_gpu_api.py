@@ -1242,7 +1242,8 @@ def test_full_size_steps_against_the_c_port(amd):
     idx, ys = bench.synth_double_well(B, T, d, dt, 50, noise, seed=11)
     grid = np.arange(T) * dt
     m = CVISitesSDE(gsde.DoubleWellSDE(q=q), grid, (grid[idx], torch.from_numpy(ys).to(dev_)), lik(),
-                    prior_initial_state=(np.zeros(d), np.eye(d)), plan=amd.Plan(B, T, d))
+                    prior_initial_state=(np.zeros(d), np.eye(d)), plan=None)
+    assert m.plan.R == 100          # the model's own partition: segments aligned with the observation grid (every 50 nodes)
     got = []
     for _ in range(2):
         m.update_data_sites(0.5)
@@ -1268,7 +1269,7 @@ def test_full_size_steps_against_the_c_port(amd):
     idx, ys = bench.synth_double_well(B, T, d, dt, 50, noise, seed=12)
     grid = np.arange(T) * dt
     m = VariationalMarkovGP((grid[idx], torch.from_numpy(ys).to(dev_)), gsde.DoubleWellSDE(q=q), grid, lik(),
-                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=amd.Plan(B, T, d))
+                            prior_initial_state=(np.zeros(d), np.eye(d)), stabilize_system=True, plan=None)
     m.plan.pack(amd.FULL, (4.0 * torch.eye(d, dtype=torch.float64, device=dev_)).expand(B, T, d, d).contiguous(), out=m.A)
     mS = m._forward_packed()
     got = []
