@@ -549,23 +549,48 @@ def bench_sparse(h, data_rank):
         # v_mfma_f64_16x16x4_f64 (64 cycles each on the one fp64 pipe of a SIMD) plus the pivot-block inverses
         out["roofline"] = dict(rows[0], other_kernels=rows[1:])
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_sparse(M, N)
+            out["cpu_baseline"] = cpu_baseline_sparse(M, N, device=device)
     return out
 
 
-def cpu_baseline_sparse(M, N, sample=8000):
-    """The plain-C port (oracle/csrc/btd_ref.c: ref_sparse_cvi_step, one thread -- the step is one chain) of the same update_sites +
-    classic_elbo step on a BOUNDED sample: `sample` inducing states on the same grid spacing with 2 x sample observations, scaled
-    linearly to M (the algorithm is O(M + N); a full-size step is ~25 x longer than the sample's).  The data-dependent constants
-    (interval, h^T P_n, h^T T_n h per observation) and the prior's precision blocks come from the NumPy oracle's kernel, once."""
-    from oracle import c_ref, np_kernels
+def c5_sample_problem(sample):
+    """Config 5's recipe at `sample` inducing states (same grid spacing, 2 x sample observations): the bounded problem the C port is
+    timed on and on which the GPU model is compared with it -- SAME size on both sides, nothing scaled."""
     rng = np.random.default_rng(5)
     span = 0.1 * sample
     z = np.linspace(0, span, sample)
     t = np.sort(rng.uniform(0, span, size=2 * sample))
     y = np.sin(3 * t) + 0.1 * rng.normal(size=t.size)
+    return z, t, y
+
+
+def c5_gpu_elbos(sample, steps, device):
+    """SparseCVIGaussianProcess on c5_sample_problem(sample): the ELBO after each of `steps` damped update_sites (learning rate 0.5)."""
+    import torch
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.sparse_variational_cvi import SparseCVIGaussianProcess
+    z, t, y = c5_sample_problem(sample)
+    td, yd = torch.from_numpy(t).to(device), torch.from_numpy(y).to(device)[:, None]
+    m = SparseCVIGaussianProcess(sum16_kernel(K), torch.from_numpy(z).to(device), Gaussian(0.01), learning_rate=0.5)
+    out = []
+    for _ in range(steps):
+        m.update_sites((td, yd))
+        out.append(float(m.classic_elbo((td, yd))))
+    m.dist_p.plan.check_info()
+    return out
+
+
+def cpu_baseline_sparse(M, N, sample=20000, device=None):
+    """The plain-C port (oracle/csrc/btd_ref.c: ref_sparse_cvi_step, one thread -- the step is one chain) of the same update_sites +
+    classic_elbo step on a BOUNDED sample: `sample` inducing states on the same grid spacing with 2 x sample observations.  Its RATE is
+    scaled linearly to M (the algorithm is O(M + N)) and labelled as such; its ELBOs over the first three damped steps are compared
+    with the GPU model run on the SAME sample (no scaling).  The data-dependent constants (interval, h^T P_n, h^T T_n h per
+    observation) and the prior's precision blocks come from the NumPy oracle's kernel, once."""
+    from oracle import c_ref, np_kernels
+    z, t, y = c5_sample_problem(sample)
     st = c_ref.SparseCviStepState(sum16_kernel(np_kernels), z, t, y, 0.01, 0.5)
-    st.step()
+    first = [st.step() for _ in range(3)]
     n, t0 = 0, time.perf_counter()
     while True:
         st.step()
@@ -574,9 +599,14 @@ def cpu_baseline_sparse(M, N, sample=8000):
         if el > 10.0 or n >= 10:
             break
     per = el / n * (M / sample)
-    return {"value": 1.0 / per, "unit": "ELBO steps/s", "cores": 1, "threads_used": 1, "kind": "port",
-            "sample": f"{n} steps of the C port on {sample} inducing states / {2 * sample} observations ({el / n:.3f} s each, one thread: the "
-                      f"step is one chain), scaled linearly to {M} / {N}"}
+    out = {"value": 1.0 / per, "unit": "ELBO steps/s", "cores": 1, "threads_used": 1, "kind": "port",
+           "sample": f"{n} steps of the C port on {sample} inducing states / {2 * sample} observations ({el / n:.3f} s each, one thread: the "
+                     f"step is one chain); the RATE is an extrapolation, scaled linearly to {M} / {N}"}
+    if device is not None:
+        got = c5_gpu_elbos(sample, 3, device)
+        out["first_steps_elbo_max_rel_diff_vs_gpu"] = float(max(abs(a - b) / abs(b) for a, b in zip(got, first)))
+        out["parity_sample"] = f"GPU model and C port on the same {sample} inducing states / {2 * sample} observations, three damped steps"
+    return out
 
 
 OTHER_CONFIGS = {"c3": bench_vdp, "c2": bench_cvigp, "c5": bench_sparse}

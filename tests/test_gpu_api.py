@@ -388,6 +388,50 @@ def test_cvi_gaussian_process(amd, rng, kname):
         np.testing.assert_allclose(float(g2.classic_elbo()), o2.classic_elbo(), rtol=max(tol, 1e-6))
 
 
+def test_cvi_step_graph_interleaved_with_eager_calls(amd, rng):
+    """CVIGaussianProcess.step_graph(): replays of the captured `update_sites(); elbo()` interleaved with eager update_sites / elbo /
+    classic_elbo / predict_f_at_data calls, and with a foreign factorisation on the same plan, give the ELBO sequence and sites of an
+    all-eager run (the captured order is self-contained and every replay advances the host-side stamps the factor cache keys on)."""
+    import torch
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.variational_cvi import CVIGaussianProcess
+    T = 3000
+    t = np.linspace(0.0, 30.0, T)
+    y = np.sin(2 * t)[:, None] + 0.1 * rng.normal(size=(T, 1))
+    mk = lambda: CVIGaussianProcess((dev(t), dev(y)), K.Matern52(0.5, 1.0), Gaussian(0.05), learning_rate=0.3)
+    a, b = mk(), mk()
+    step = b.step_graph()
+    # the programme: "g" = one replay (a: update_sites + elbo), "u" = eager update_sites alone, "e" = eager elbo, "c" = classic_elbo,
+    # "p" = predict_f_at_data, "x" = a foreign factorisation on the plan (the prior's marginals)
+    got, want = [], []
+    for op in "gugxgceupgxeg":
+        for m, out, replay in ((a, want, False), (b, got, True)):
+            if op == "g":
+                if replay:
+                    out.append(float(step()))
+                else:
+                    m.update_sites()
+                    out.append(float(m.elbo()))
+            elif op == "u":
+                m.update_sites()
+            elif op == "e":
+                out.append(float(m.elbo()))
+            elif op == "c":
+                out.append(float(m.classic_elbo()))
+            elif op == "p":
+                out.append(float(m.predict_f_at_data()[0].sum()))
+            else:
+                pl = m.dist_p.plan
+                nat = pl.ssm_to_naturals(m.dist_p.packed.A, m.dist_p.packed.off, m.dist_p.packed.chol, precision=False)
+                f = pl.factor(nat["diag"], nat["sub"], nat["lin"], aD=-2.0, aS=-1.0)
+                torch.cuda.synchronize()
+    b.dist_p.plan.check_info()
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    np.testing.assert_allclose(host(b.sites.nat1), host(a.sites.nat1), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(host(b.sites.nat2), host(a.sites.nat2), rtol=1e-10, atol=1e-12)
+
+
 @pytest.mark.parametrize("d,B,T,kind", [(1, 1, 60, "dw"), (2, 2, 47, "dw"), (1, 2, 33, "ou"), (3, 1, 140, "dw"),
                                         (2, 2, 700, "ou"),      # 88 segments: more than one per lane of the Lagrange scan
                                         (6, 2, 150, "dw")])     # the bench's state dimension, ragged partition; oracle closed_form
@@ -1286,6 +1330,53 @@ def test_full_size_steps_against_the_c_port(amd):
         np.testing.assert_allclose(got[k], sv.elbo, rtol=1e-9)
 
 
+def test_full_size_cvigp_and_sparse_steps_against_the_c_port(amd):
+    """
+    Config 2 at FULL size (CVIGaussianProcess.update_sites + elbo, Matern-5/2, one chain of 100 000 points; reference
+    variational_cvi.py:351-379) against the C port's ref_cvigp_step, and config 5's model step (SparseCVIGaussianProcess.update_sites +
+    classic_elbo, Sum-of-Matern d = 16; reference sparse_variational_cvi.py:140-221) against ref_sparse_cvi_step on the SAME 40 000
+    inducing states / 80 000 observations (the largest problem the one-thread port finishes in under a minute; nothing is scaled):
+    ELBO after each of three damped steps, 1e-8 (north-star bound 1e-5).
+    """
+    import gc
+    import torch
+    import bench
+    from oracle import c_ref, np_kernels
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.variational_cvi import CVIGaussianProcess
+    dev_ = torch.device("cuda", 0)
+
+    # config 2, full size: bench.bench_cvigp's recipe
+    T = 100000
+    rng_ = np.random.default_rng(71892305 + 2)
+    t = torch.linspace(0, 0.01 * T, T, dtype=torch.float64, device=dev_)
+    y = (torch.sin(12 * t) + 0.1 * torch.from_numpy(rng_.normal(size=T)).to(dev_))[:, None]
+    m = CVIGaussianProcess((t, y), K.Matern52(lengthscale=0.2, variance=1.0), Gaussian(0.01), learning_rate=0.5)
+    got = []
+    for _ in range(3):
+        m.update_sites()
+        got.append(float(m.elbo()))
+    m.dist_p.plan.check_info()
+    k = np_kernels.Matern52(0.2, 1.0)
+    tn = t.cpu().numpy()
+    st = c_ref.CviGpStepState(k.state_space_model(tn), k.emission_matrix(tn[:1])[0, 0], y.cpu().numpy(), 0.01, 0.5)
+    want = [st.step() for _ in range(3)]
+    assert np.isfinite(want).all()
+    np.testing.assert_allclose(got, want, rtol=1e-8)
+    del m, st
+    gc.collect(); torch.cuda.empty_cache()
+
+    # config 5 on the same bounded problem on both sides
+    sample = 40000
+    got = bench.c5_gpu_elbos(sample, 3, dev_)
+    z, ts, ys = bench.c5_sample_problem(sample)
+    st = c_ref.SparseCviStepState(bench.sum16_kernel(np_kernels), z, ts, ys, 0.01, 0.5)
+    want = [st.step() for _ in range(3)]
+    assert np.isfinite(want).all() and want[2] > want[0]
+    np.testing.assert_allclose(got, want, rtol=1e-8)
+
+
 @pytest.mark.parametrize("d,B,T,n_obs", [(1, 2, 40, 5), (3, 3, 77, 9), (6, 2, 131, 300)])
 def test_site_update_and_obs_ve_kernels(amd, rng, d, B, T, n_obs):
     """mfgm_site_update_pair and mfgm_mvn_obs_ve against the torch formulas they replace (blend + difference + scatter; gather +
@@ -1784,7 +1875,7 @@ def test_cvi_classic_elbo_site_gradient_vanishes_at_optimum(amd, rng, kname):
 
 
 @pytest.mark.parametrize("kind", ["vanderpol", "mlp"])
-def test_cvi_sites_sde_quadrature_drifts(amd, rng, kind):
+def test_cvi_sites_sde_coupled_drifts(amd, rng, kind):
     """The drifts that couple the state dimensions / have no polynomial form (markovflow/sde/sde.py:359-518: VanderPolOscillatorSDE, MLPDrift)
     through CVISitesSDEQuadrature -- the reference's Gauss-Hermite formulation with autograd for its GradientTape, sweeps in HIP --
     against the oracle's restatement (quadrature KL, central differences for the tape): linearised prior, KL, its gradient with

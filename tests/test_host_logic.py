@@ -157,6 +157,9 @@ def test_observation_aligned_segment_length():
     assert observation_period(torch.arange(49, 100000, 50)) == 50
     assert observation_period(np.arange(5, 1000, 9)) == 9
     assert observation_period(torch.tensor([3, 8, 14])) == 0 and observation_period(torch.tensor([7])) == 0
+    assert observation_period(torch.arange(49, 1000, 50).expand(4, -1)) == 50          # [B, n], the same grid for every trajectory
+    assert observation_period(np.stack([np.arange(5, 100, 9), np.arange(6, 101, 9)])) == 0     # different grids: no common alignment
+    assert observation_period(torch.arange(3, 40, 4)[None]) == 4
     assert aligned_segment_length(64, 100000, 6, 50) == 100          # headline: ceil(6.4e6 / 65536) = 98 -> 100
     assert aligned_segment_length(64, 50000, 6, 50) == 50            # config 3: 49 -> 50
     assert aligned_segment_length(64, 100000, 6, 7) == 98            # already a multiple
@@ -164,3 +167,19 @@ def test_observation_aligned_segment_length():
     assert aligned_segment_length(1, 1001, 1, 31) == 0               # small problem: the automatic partition
     assert aligned_segment_length(64, 100000, 16, 50) == 0           # wavefront-per-segment plans
     assert aligned_segment_length(64, 100000, 6, 97) == 0            # 194 would leave half the lanes idle
+
+
+def test_no_shadowed_test_functions():
+    """A second top-level `def test_x` in a module silently replaces the first (a Benes / sine parity test was lost that way in
+    round 3): every test module must define each top-level name once."""
+    import ast
+    import glob
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "*.py"))):
+        tree = ast.parse(open(path).read())
+        seen = {}
+        for node in tree.body:
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+                assert node.name not in seen, f"{os.path.basename(path)}: {node.name} defined at lines {seen[node.name]} and {node.lineno}"
+                seen[node.name] = node.lineno

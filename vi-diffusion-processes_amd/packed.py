@@ -23,7 +23,14 @@ def _stream():
 def observation_period(time_index):
     """The common spacing of the observation indices on the grid when they are equally spaced (tensor or array [n] or [B, n], the same
     for every trajectory), else 0."""
-    ti = torch.as_tensor(time_index).reshape(-1) if not torch.is_tensor(time_index) else time_index.reshape(-1)
+    ti = torch.as_tensor(time_index)
+    if ti.dim() > 1:
+        # [B, n]: the spacing along the LAST axis, and only when every trajectory has the same grid (flattening would see a negative
+        # step at each row boundary and report "no period" for every batched index tensor)
+        ti = ti.reshape(-1, ti.shape[-1])
+        if ti.shape[0] > 1 and not bool((ti == ti[:1]).all()):
+            return 0
+        ti = ti[0]
     if ti.numel() < 2:
         return 0
     diffs = (ti[1:] - ti[:-1]).cpu()

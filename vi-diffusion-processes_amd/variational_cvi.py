@@ -255,19 +255,32 @@ class CVIGaussianProcess(GaussianProcessWithSitesBase):
         """`update_sites(); elbo()` -- the inner loop of CVI (variational_cvi.py:351-379) -- captured ONCE in a HIP graph: returns a
         callable that replays it and hands back the ELBO (a device scalar that every replay overwrites).  On one chain the step is a
         sequence of ~20 short dependent launches (level sweeps of a few microseconds each): replayed from a graph they cost no host time
-        at all.  The caches the step relies on (prior, scratch, the factorisation of the current sites) are warmed WITHOUT moving the
-        sites; afterwards eager calls and replays can be mixed freely."""
+        at all.  The captured order is SELF-CONTAINED: update_sites factorises the system of the current sites itself (it does not
+        take the eager shortcut of reusing the factorisation elbo() left in the plan's scratch -- that decision depends on host-side
+        stamps a replay cannot re-evaluate), and every replay advances those stamps (site versions, plan epoch) and drops the
+        "factorisation belongs to these sites" record, so eager calls and replays can be interleaved in any order."""
+        from .kalman_filter import fused_sites_call
         fx_mus, fx_covs = self.predict_f_at_data()
         self._likelihood.ve_gradients_expectation(fx_mus, fx_covs, self._observations)
         self.elbo()
+        call = fused_sites_call(self.dist_p, self._emission(), self.sites)
+        cache = call[2] if call is not None else {}
+        cache["factor_of"] = None                   # capture factor + selected inverse + projection, not the shortcut
+        pl = self.dist_p.plan
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.update_sites()
             e = self.elbo()
+        cache["factor_of"] = None                   # nothing ran during the capture: the scratch holds no factorisation of these sites
 
         def step():
             graph.replay()
+            # the replay moved the sites and overwrote the plan's scratch behind the host's back
+            torch.autograd.graph.increment_version(self.sites.nat1)
+            torch.autograd.graph.increment_version(self.sites.nat2)
+            pl.epoch += 1
+            cache["factor_of"] = None
             return e
         step.graph = graph
         return step
