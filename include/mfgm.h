@@ -268,6 +268,19 @@ int mfgm_cq_slots(const mfgm_plan* plan, const long long* node_ids, int n, int* 
  * quad [B] (may be NULL). */
 int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
                    int* info, void* stream);
+/* The same factorisation, pipelined across the steps of the CVI-DP loop (cvi_dp_trainer.py:72-75 iterates update_data_sites,
+ * update_girsanov_sites, classic_elbo: two factorisations per step).  Under a Gaussian likelihood the data sites of the NEXT step do not
+ * depend on q, so the state the first factorisation of step n + 1 will see -- dyn / offsets as they are now, sites (q_next->site_lin,
+ * q_next->site_sym) -- is known while the second factorisation of step n runs.
+ *   q_next + side_stream: once the coarse levels of THIS factorisation are done, the level-0 reduce of q_next is launched on
+ *     side_stream, next to this call's bandwidth-bound level-0 forward sweep (the two kernels share the SIMDs: 193 + 256 registers);
+ *     its separator system goes to the second copy of the level-1 input region the workspace of such plans holds;
+ *   use_ahead != 0: the record the previous pipelined call on this plan made was for EXACTLY the state q (the caller's
+ *     responsibility): the level-0 reduce of this call is skipped, `stream` waits for the work queued on side_stream, and the coarse
+ *     levels read the record in place (nothing is copied: the two copies of the region swap roles).
+ * Results are those of mfgm_cq_factor (the record holds the same numbers the level-0 reduce would write). */
+int mfgm_cq_factor_pipelined(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
+                             int* info, int use_ahead, const mfgm_cq_state* q_next, void* side_stream, void* stream);
 /* one part of it alone (profiling): stage 0 the level-0 reduce, 1 the level-0 forward (as mfgm_packed_factor_stage), 2 the levels above
  * the finest one (their reduces, the fused coarse kernel, their forwards) on whatever the last stage 0 left in the workspace */
 int mfgm_cq_factor_stage(const mfgm_plan* plan, int stage, const mfgm_cq_state* q, double* L, double* y, void* ws, int* info,

@@ -1330,6 +1330,48 @@ def test_full_size_steps_against_the_c_port(amd):
         np.testing.assert_allclose(got[k], sv.elbo, rtol=1e-9)
 
 
+def test_cvi_dp_pipelined_steps_equal_unpipelined(amd, rng):
+    """The cross-step pipelining of CVISitesSDE (the level-0 reduce of the next step's first factorisation made ahead, on a second
+    stream, by mfgm_cq_factor_pipelined) against the same model with it switched off: ELBO after every step of a loop that keeps its
+    learning rates (records are consumed), changes them (a record is dropped), re-linearises, evaluates the ELBO twice and updates
+    the Girsanov sites twice in a row -- equal to rounding of the last bit (the record holds the numbers the reduce would write)."""
+    import torch
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    B, T, d, dt = 3, 1200, 3, 0.01
+    grid = np.arange(T) * dt
+    idx = np.arange(9, T - 1, 20)
+    y = np.sign(rng.normal(size=(B, len(idx), d))) + 0.1 * rng.normal(size=(B, len(idx), d))
+    cholR = 0.3 * np.eye(d)
+
+    def make(pipe):
+        m = CVISitesSDE(gsde.DoubleWellSDE(torch.eye(d, dtype=torch.float64)), grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)),
+                        prior_initial_state=(np.zeros(d), np.eye(d)), plan=amd.Plan(B, T, d, R0=20, Rup=4))
+        m.pipelined = pipe
+        return m
+    a, b = make(False), make(True)
+    assert b._cq_state() is not None
+    prog = [("s", 0.5, 0.1)] * 4 + [("s", 0.3, 0.1)] * 2 + [("r",)] + [("s", 0.3, 0.2)] * 2 + [("e",), ("g", 0.1), ("s", 0.3, 0.2), ("s", 0.3, 0.2)]
+    got, want, used = [], [], 0
+    for op in prog:
+        for m, out in ((a, want), (b, got)):
+            if op[0] == "s":
+                m.update_data_sites(op[1])
+                if m is b and b._pre is not None and b._pre.get("armed"):
+                    used += 1
+                m.update_girsanov_sites(op[2])
+            elif op[0] == "r":
+                m.relinearize()
+            elif op[0] == "g":
+                m.update_girsanov_sites(op[1])
+            out.append(host(m.classic_elbo_per_trajectory()))
+    b.plan.check_info()
+    assert used >= 6                    # records were made and consumed, not just dropped
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=1e-12)
+    assert_close(host(b.plan.unpack(amd.VEC, b.full_sites().lin)), host(a.plan.unpack(amd.VEC, a.full_sites().lin)), rtol=1e-12)
+
+
 def test_full_size_cvigp_and_sparse_steps_against_the_c_port(amd):
     """
     Config 2 at FULL size (CVIGaussianProcess.update_sites + elbo, Matern-5/2, one chain of 100 000 points; reference

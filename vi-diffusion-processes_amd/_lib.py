@@ -79,6 +79,7 @@ EXPORTS = {
     "mfgm_cq_unpack": (ctypes.c_int, [ctypes.c_void_p] * 6),
     "mfgm_cq_slots": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_cq_factor": (ctypes.c_int, [ctypes.c_void_p] * 9),
+    "mfgm_cq_factor_pipelined": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] + [ctypes.c_void_p] * 3),
     "mfgm_cq_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6),
     "mfgm_cq_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mfgm_cq_selinv_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11),

@@ -87,6 +87,7 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
         P.off_Sig[i] = take(level_elems(P, lv, 2));
         P.off_mu[i] = take(level_elems(P, lv, 0));
     }
+    P.off_alt = (!P.wide && P.nlevels >= 2) ? take(P.off_L[1] - P.off_Dhat[1]) : 0;
     P.ws_doubles = off;
     *out = h;
     return 0;

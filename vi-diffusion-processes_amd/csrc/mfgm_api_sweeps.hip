@@ -271,9 +271,30 @@ CqArgs cq_args(const mfgm_cq_state* q) {
     return c;
 }
 
+// Pipelining across the steps of the CVI-DP loop (mfgm_cq_factor_pipelined).  The workspace holds the level-1 INPUT region (Dhat,
+// Rsub, S, rhat, rho: what a level-0 reduce writes) twice; a factorisation reads one copy while the level-0 reduce of the state the
+// caller knows one factorisation ahead fills the other, on the stream `side`, next to this factorisation's level-0 forward sweep.
+struct CqPipe {
+    const mfgm_plan* owner = nullptr;
+    bool use_ahead = false;             // this state's separator system was made ahead: skip the level-0 reduce
+    const CqArgs* next = nullptr;       // make the separator system of this state ahead
+    hipStream_t side = nullptr;
+};
+// the plan with its level-1 inputs bound to region r (0: its own, 1: off_alt)
+Plan with_l1_region(const Plan& P, int r) {
+    Plan Q = P;
+    if (r) {
+        const size_t sh = P.off_alt - P.off_Dhat[1];
+        Q.off_Dhat[1] += sh; Q.off_Rsub[1] += sh; Q.off_S[1] += sh; Q.off_rhat[1] += sh; Q.off_rho[1] += sh;
+    }
+    return Q;
+}
+
 template <int D>
-int cq_factor_impl(const Plan& P, const CqArgs& q, double* Lg, double* yg, double* logdet, double* quad, double* ws, int* info,
-                   hipStream_t st, int only_stage = -1) {
+int cq_factor_impl(const Plan& P0, const CqArgs& q, double* Lg, double* yg, double* logdet, double* quad, double* ws, int* info,
+                   hipStream_t st, int only_stage = -1, const CqPipe* pipe = nullptr) {
+    const int region = (pipe && pipe->use_ahead) ? pipe->owner->ahead_region : 0;
+    const Plan P = with_l1_region(P0, region);
     const int K = P.nlevels - 1;
     SweepArgs a0;
     memset(&a0, 0, sizeof(a0));
@@ -284,7 +305,11 @@ int cq_factor_impl(const Plan& P, const CqArgs& q, double* Lg, double* yg, doubl
     a0.part = (logdet || quad) ? ws + P.off_part[0] : nullptr;
     bind_up(P, 0, ws, a0);
     dim3 grid(a0.lv.Lpad / 64), block(64);
-    if (only_stage < 0 || only_stage == 0) {
+    if (pipe && pipe->use_ahead) {
+        // the separator system of this state was made ahead, on the side stream, in the region bound above: wait for it
+        if (hipEventRecord(pipe->owner->ev[1], pipe->side) != hipSuccess) return 3;
+        if (hipStreamWaitEvent(st, pipe->owner->ev[1], 0) != hipSuccess) return 3;
+    } else if (only_stage < 0 || only_stage == 0) {
         hipLaunchKernelGGL((k_reduce_cq<D>), grid, block, 0, st, a0, q);
         MFGM_CHECK_LAUNCH();
     }
@@ -304,6 +329,18 @@ int cq_factor_impl(const Plan& P, const CqArgs& q, double* Lg, double* yg, doubl
             int rc = launch_forward<D>(a, true, true, l < K, st);
             if (rc) return rc;
         }
+    }
+    if (pipe && pipe->next) {
+        // the level-0 reduce of the NEXT factorisation's state, into pre_out, on the side stream: from here on the main stream runs
+        // the bandwidth-bound level-0 forward sweep (193 registers), next to whose wavefronts the lean reduce (256) fits on every SIMD
+        if (hipEventRecord(pipe->owner->ev[0], st) != hipSuccess) return 3;
+        if (hipStreamWaitEvent(pipe->side, pipe->owner->ev[0], 0) != hipSuccess) return 3;
+        SweepArgs an = a0;
+        bind_up(with_l1_region(P0, 1 - region), 0, ws, an);
+        pipe->owner->ahead_region = 1 - region;
+        an.part = nullptr;
+        hipLaunchKernelGGL((k_reduce_cq_lean<D>), grid, block, 0, pipe->side, an, *pipe->next);
+        MFGM_CHECK_LAUNCH();
     }
     if (only_stage < 0 || only_stage == 1) {
         hipLaunchKernelGGL((k_forward_cq<D>), grid, block, 0, st, a0, q);
@@ -573,6 +610,22 @@ int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, dou
     const Plan& P = plan->p;
     const CqArgs c = cq_args(q);
     MFGM_DISPATCH_D(P.d, (cq_factor_impl<DD>(P, c, L, y, logdet, quad, (double*)ws, info, (hipStream_t)stream)));
+}
+
+int mfgm_cq_factor_pipelined(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
+                             int* info, int use_ahead, const mfgm_cq_state* q_next, void* side_stream, void* stream) {
+    if (!cq_ok(plan, q) || !L || !y || !ws || !info || plan->p.off_alt == 0) return 1;
+    if ((use_ahead || q_next) && (!side_stream || side_stream == stream)) return 1;
+    if (q_next && !cq_ok(plan, q_next)) return 1;
+    const Plan& P = plan->p;
+    for (int i = 0; i < 2; ++i)
+        if (!plan->ev[i] && hipEventCreateWithFlags(&plan->ev[i], hipEventDisableTiming) != hipSuccess) return 3;
+    const CqArgs c = cq_args(q);
+    CqArgs cn;
+    CqPipe pipe;
+    pipe.owner = plan; pipe.use_ahead = use_ahead != 0; pipe.side = (hipStream_t)side_stream;
+    if (q_next) { cn = cq_args(q_next); pipe.next = &cn; }
+    MFGM_DISPATCH_D(P.d, (cq_factor_impl<DD>(P, c, L, y, logdet, quad, (double*)ws, info, (hipStream_t)stream, -1, &pipe)));
 }
 
 int mfgm_cq_factor_stage(const mfgm_plan* plan, int stage, const mfgm_cq_state* q, double* L, double* y, void* ws, int* info,

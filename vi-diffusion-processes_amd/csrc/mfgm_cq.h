@@ -75,8 +75,25 @@ MFGM_DEV void cq_sub(const double (&sd)[D], double sOff, double (&G)[D * D]) {
 // ---- reduce --------------------------------------------------------------------------------------------------------------------
 // reduce_body<D, true, false> on the cq state.  Record s+1 (and the slot of node s+1) is requested one step ahead; the site's linear
 // part is gathered at the top of the step that ends by consuming it.
+// LEAN: the kernel is held to 256 registers (two wavefronts per SIMD) so that its wavefronts can share a SIMD with those of
+// k_forward_cq (193 registers): launched on a second stream it then rides in the forward sweep's memory waits (that sweep is
+// bandwidth-bound with two thirds of its issue slots idle; this one is arithmetic-bound on 18 doubles per node).  What the reduce only
+// accumulates -- the Gram correction Racc, rho -- lives in LDS, [element][lane]: one conflict-free ds_read / ds_write_b64 per element and
+// node, 13.5 KB per wavefront.
+#ifndef CQ_LEAN_ATTR
+#define CQ_LEAN_ATTR
+#endif
+template <int D, bool LEAN>
+MFGM_DEV void reduce_cq_body(const SweepArgs& a, const CqArgs& q, double* lds_acc);
 template <int D>
-static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) {
+static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) { reduce_cq_body<D, false>(a, q, nullptr); }
+template <int D>
+static __global__ __launch_bounds__(64) CQ_LEAN_ATTR void k_reduce_cq_lean(SweepArgs a, CqArgs q) {
+    __shared__ double lds_acc[(MFGM_NTRI(D) + D) * 64];
+    reduce_cq_body<D, true>(a, q, lds_acc);
+}
+template <int D, bool LEAN>
+MFGM_DEV void reduce_cq_body(const SweepArgs& a, const CqArgs& q, double* lds_acc) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, E3 = 3 * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
@@ -129,27 +146,38 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
     for (int e = 0; e < ET; ++e) Racc[e] = 0.0;
 #pragma unroll
     for (int e = 0; e < D; ++e) rho[e] = 0.0;
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int e = 0; e < ET + D; ++e) lds_acc[e * 64 + me.l] = 0.0;
+    }
 
     double rn[E3];
     int sn = -1;
-    if (len > 1) {
+    if (!LEAN && len > 1) {
         ld_node<E3>(q.dyn, R, 1, me, rn);
         if (sites) sn = cq_slot(q.slot, R, 1, me);
     }
     for (int s = 0; s < R - 1; ++s) {
         if (s < len - 1) {
-            double rc[E3];
+            double rc[E3], sl[D];
+            int sc;
+            if constexpr (LEAN) {
+                // the record of node s + 1 is requested at the top of the step that ends by consuming it (one record in flight instead
+                // of two: 36 registers; the wavefront that shares the SIMD covers what this leaves of the latency)
+                ld_node<E3>(q.dyn, R, s + 1, me, rc);
+                sc = sites ? cq_slot(q.slot, R, s + 1, me) : -1;
+            } else {
 #pragma unroll
-            for (int e = 0; e < E3; ++e) rc[e] = rn[e];
-            const int sc = sn;
-            double sl[D];
+                for (int e = 0; e < E3; ++e) rc[e] = rn[e];
+                sc = sn;
+            }
 #pragma unroll
             for (int i = 0; i < D; ++i) sl[i] = 0.0;
-            if (sc >= 0) {
+            if (!LEAN && sc >= 0) {
 #pragma unroll
                 for (int i = 0; i < D; ++i) sl[i] = q.site_lin[(size_t)sc * D + i];
             }
-            if (s + 1 < len - 1) {
+            if (!LEAN && s + 1 < len - 1) {
                 ld_node<E3>(q.dyn, R, s + 2, me, rn);
                 if (sites) sn = cq_slot(q.slot, R, s + 2, me);
             }
@@ -157,7 +185,17 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
             double invd[D], G[EF];
             chol_inplace<D>(F, invd, bad);
             trsm_left_lower<D>(F, invd, W);        // W := L^{-1} W   (spike towards the left separator)
+            if constexpr (LEAN) {
+#pragma unroll
+                for (int e = 0; e < ET; ++e) Racc[e] = lds_acc[e * 64 + me.l];
+            }
             syrk_t_acc<D>(W, Racc);                // R += W^T W
+            if constexpr (LEAN) {
+#pragma unroll
+                for (int e = 0; e < ET; ++e) lds_acc[e * 64 + me.l] = Racc[e];
+#pragma unroll
+                for (int e = 0; e < D; ++e) rho[e] = lds_acc[(ET + e) * 64 + me.l];
+            }
             {
                 trsv_lower<D>(F, invd, h);         // y := L^{-1} h
                 double t[D];
@@ -165,11 +203,23 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
 #pragma unroll
                 for (int e = 0; e < D; ++e) rho[e] += t[e];
             }
+            if constexpr (LEAN) {
+#pragma unroll
+                for (int e = 0; e < D; ++e) lds_acc[(ET + e) * 64 + me.l] = rho[e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
                 for (int j = 0; j < D; ++j) G[i * D + j] = a.aS * ((i == j) ? sdc[i] : q.sOff);
             trsm_right_lower_t<D>(F, invd, G);     // G := S L^{-T}
+            if constexpr (LEAN) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (sc >= 0) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) sl[i] = q.site_lin[(size_t)sc * D + i];
+                }
+            }
             // Schur complement onto node s+1
             syrk_set<D>(G, F);
             const double cnt = (sc >= 0) ? 1.0 : 0.0;
@@ -202,6 +252,12 @@ static __global__ __launch_bounds__(64) void k_reduce_cq(SweepArgs a, CqArgs q) 
 #pragma unroll
             for (int i = 0; i < D; ++i) sdc[i] = rc[2 * D + i];
         }
+    }
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int e = 0; e < ET; ++e) Racc[e] = lds_acc[e * 64 + me.l];
+#pragma unroll
+        for (int e = 0; e < D; ++e) rho[e] = lds_acc[(ET + e) * 64 + me.l];
     }
     // separator of this segment is node q = p of the coarser level (level >= 1 layout: coarse_off)
     const int uP = a.up.P, uR = a.up.R;

@@ -13,6 +13,14 @@
 
 struct mfgm_plan {
     mfgm::Plan p;
+    // events of the cross-step pipelining of the CVI-DP loop (mfgm_cq_factor_pipelined), created on first use; 0: main stream reached
+    // the point after which the side stream may run, 1: side stream finished the record the main stream is about to consume
+    mutable hipEvent_t ev[2] = {nullptr, nullptr};
+    mutable int ahead_region = 1;      // region (0: the plan's own level-1 inputs, 1: off_alt) the record made ahead lives in
+    ~mfgm_plan() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
 };
 
 namespace mfgm {

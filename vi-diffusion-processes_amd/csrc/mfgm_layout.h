@@ -45,6 +45,8 @@ struct Plan {
     size_t off_L[kMaxLevels], off_G[kMaxLevels], off_y[kMaxLevels], off_Sig[kMaxLevels], off_mu[kMaxLevels];
     size_t off_part[kMaxLevels];   // per-lane partial sums (2 * Lpad doubles), all levels incl. 0
     size_t off_part2;              // second-stage scratch of the split partial sums (2 * B * 128 doubles)
+    size_t off_alt;                // narrow plans with >= 2 levels: a second copy of the level-1 INPUT region [off_Dhat[1], off_L[1])
+                                   // (the separator system mfgm_cq_factor_pipelined makes one factorisation ahead); 0: none
     size_t ws_doubles;             // total workspace size in doubles
 };
 

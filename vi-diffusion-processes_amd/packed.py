@@ -398,15 +398,27 @@ class Plan:
         _lib.check(self.lib.mfgm_cq_slots(self.h, _ptr(node_ids), node_ids.numel(), _ptr(slot), _ptr(dup), _stream()), "mfgm_cq_slots")
         return None if int(dup.item()) else slot
 
-    def cq_factor(self, cq, want_logdet=True, out=None):
-        """Block Cholesky + forward substitution of the posterior precision given as a cq state: dict(L, y, logdet)."""
+    def cq_factor(self, cq, want_logdet=True, out=None, use_ahead=False, next_sites=None, side=None):
+        """Block Cholesky + forward substitution of the posterior precision given as a cq state: dict(L, y, logdet).
+        Pipelined across the steps of the CVI-DP loop (mfgm_cq_factor_pipelined): `use_ahead` says the previous pipelined call made the
+        separator system of exactly this state (the level-0 reduce is skipped); `next_sites` = (site_lin, site_sym) of the state whose
+        separator system is to be made now, on the torch stream `side`, next to this call's level-0 forward sweep."""
         out = {} if out is None else out
         L = out.get("L") if out.get("L") is not None else self.empty(TRI)
         y = out.get("y") if out.get("y") is not None else self.empty(VEC)
         self.epoch += 1
         logdet = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_logdet else None
-        _lib.check(self.lib.mfgm_cq_factor(self.h, ctypes.byref(cq.struct()), _ptr(L), _ptr(y), _ptr(logdet), None, _ptr(self.ws),
-                                           _ptr(self.info), _stream()), "mfgm_cq_factor")
+        if not use_ahead and next_sites is None:
+            _lib.check(self.lib.mfgm_cq_factor(self.h, ctypes.byref(cq.struct()), _ptr(L), _ptr(y), _ptr(logdet), None, _ptr(self.ws),
+                                               _ptr(self.info), _stream()), "mfgm_cq_factor")
+            return dict(L=L, y=y, logdet=logdet)
+        nxt = None
+        if next_sites is not None:
+            nxt = cq.struct()
+            nxt.site_lin, nxt.site_sym = next_sites[0].data_ptr(), next_sites[1].data_ptr()
+        _lib.check(self.lib.mfgm_cq_factor_pipelined(self.h, ctypes.byref(cq.struct()), _ptr(L), _ptr(y), _ptr(logdet), None, _ptr(self.ws),
+                                                     _ptr(self.info), 1 if use_ahead else 0, ctypes.byref(nxt) if nxt is not None else None,
+                                                     ctypes.c_void_p(side.cuda_stream), _stream()), "mfgm_cq_factor_pipelined")
         return dict(L=L, y=y, logdet=logdet)
 
     def cq_selinv_girsanov(self, cq, L, y, prm, dyn_out, only_level=-1):
@@ -456,6 +468,7 @@ class CqState:
 
     def __init__(self, dyn, d_off, s_off, p0_off=None, slot=None, site_lin=None, site_sym=None):
         self.dyn, self.spare = dyn, None
+        self.version = 0          # bumped by whoever moves dyn / d_off / s_off / p0_off (a separator system made ahead is keyed on it)
         self.d_off, self.s_off = float(d_off), float(s_off)
         self.p0_off, self.slot, self.site_lin, self.site_sym = p0_off, slot, site_lin, site_sym
 

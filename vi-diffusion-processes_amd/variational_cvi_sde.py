@@ -533,6 +533,41 @@ class CVISitesSDE(CVISitesSSM):
 
     _need_sub = False    # the closed-form SDE KL needs only (mu, diag Sigma, diag Sigma_sub): the moment array
 
+    # Pipelining across steps (VIDP_PIPELINE=0 switches it off).  The loop of cvi_dp_trainer.py:72-75 is update_data_sites ->
+    # update_girsanov_sites -> classic_elbo, two factorisations of theta_q per step.  Under a Gaussian likelihood the data sites a step
+    # ends up with do not depend on q, so the state the FIRST factorisation of the next step will see (dyn as it is after this step's
+    # Girsanov update, the sites one more blend ahead) is known while this step's SECOND factorisation runs: its level-0 reduce -- an
+    # arithmetic-bound kernel on 18 doubles per node -- is launched on a second stream next to that factorisation's bandwidth-bound
+    # forward sweep (Plan.cq_factor(next_sites=...)), and the next step starts from the separator system it left.  The prediction
+    # assumes the learning rate of the last update_data_sites; it is keyed on the identity / version of the cq state and of the site
+    # tensors, and anything that does not match (another learning rate, a re-linearisation, sites assigned by hand) simply finds no
+    # record and runs the reduce itself.  Results are bit-identical either way (the record holds the numbers the reduce would write).
+    pipelined = os.environ.get("VIDP_PIPELINE", "1") != "0"
+    _pre = None           # the record of a separator system made ahead (dict), None when there is none
+
+    def _pipe_sites_gradient(self):
+        g1, g2 = self.likelihood.ve_gradients_expectation(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
+        if getattr(self, "_cq_g2", (None,))[0] is not g2:
+            self._cq_g2 = (g2, self._sym_packed(g2[0]))
+        return g1, self._cq_g2[1]
+
+    def _pipe_drop(self):
+        """Forget a separator system made ahead (the stream it was made on is joined first: its buffers are about to be reused)."""
+        if getattr(self, "_pre", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._pipe_side)
+            self._pre = None
+
+    def _pipe_predict(self, cq):
+        """(site_lin, site_sym) as the next update_data_sites(self._pipe_lr) will leave them, into the model's two prediction buffers."""
+        g1, g2p = self._pipe_sites_gradient()
+        if getattr(self, "_pipe_bufs", None) is None:
+            self._pipe_bufs = (torch.empty_like(self.data_nat1), torch.empty_like(cq.site_sym))
+            self._pipe_side = torch.cuda.Stream(device=self.device)
+        lin, sym = self._pipe_bufs
+        torch.lerp(self.data_nat1, g1, self._pipe_lr, out=lin)
+        torch.lerp(cq.site_sym, g2p, self._pipe_lr, out=sym)
+        return lin, sym
+
     def update_data_sites(self, lr: float):
         cq = self._cq_state()
         if cq is None or cq.slot is None:
@@ -540,12 +575,33 @@ class CVISitesSDE(CVISitesSSM):
         # the site gradient of such a likelihood does not depend on the marginals: only the small site arrays move, and the sweeps
         # read them where they need them (no scatter into per-node arrays)
         self._started = True
-        g1, g2 = self.likelihood.ve_gradients_expectation(self.fx_mus_obs, self.fx_covs_obs, self._obs_flat())
-        if getattr(self, "_cq_g2", (None,))[0] is not g2:
-            self._cq_g2 = (g2, self._sym_packed(g2[0]))
-        self.data_nat1.lerp_(g1, lr)                     # (1 - lr) site + lr gradient (variational_cvi_sde.py:301-317)
-        cq.site_sym.lerp_(self._cq_g2[1], lr)
+        pre = getattr(self, "_pre", None)
+        if (pre is not None and pre["lr"] == float(lr) and pre["cq"] is cq and pre["ver"] == cq.version
+                and pre["v1"] == self.data_nat1._version and pre["v2"] == cq.site_sym._version):
+            # exactly the blend the last ELBO refresh predicted (same inputs, same learning rate): its result is taken over, and the
+            # separator system of the state it gives is already being made
+            self.data_nat1.copy_(pre["lin"])
+            cq.site_sym.copy_(pre["sym"])
+            pre["armed"] = (self.data_nat1._version, cq.site_sym._version)
+        else:
+            self._pipe_drop()
+            g1, g2p = self._pipe_sites_gradient()
+            self.data_nat1.lerp_(g1, lr)                     # (1 - lr) site + lr gradient (variational_cvi_sde.py:301-317)
+            cq.site_sym.lerp_(g2p, lr)
+        self._pipe_lr = float(lr)
         self._q, self._cq_dense, self._obs_fresh = None, None, False
+
+    def _pipe_take(self, cq):
+        """Whether a separator system was made ahead for the state as it is NOW: consumed by the next factorisation."""
+        pre = getattr(self, "_pre", None)
+        if pre is None:
+            return False
+        ok = (pre.get("armed") == (self.data_nat1._version, cq.site_sym._version) and pre["cq"] is cq and pre["ver"] == cq.version)
+        if not ok or pre["epoch"] != self.plan.epoch:      # (another factorisation on the plan may have used the workspace since)
+            self._pipe_drop()
+            return False
+        self._pre = None          # the consuming call joins the side stream itself
+        return True
 
     def _refresh(self, want_sub=None, want_mom=None, want_marginals=False):
         """want_marginals: the full marginal arrays (mu, Sig) are wanted.  The ELBO / site-update loop needs only the KL sum and the
@@ -559,7 +615,17 @@ class CVISitesSDE(CVISitesSSM):
         obs = cq.slot is not None
         lazy = obs and not want_marginals and os.environ.get("VIDP_LAZY_MARGINALS", "1") != "0"
         if self._q is None:
-            f = pl.cq_factor(cq, want_logdet=True, out=self._bufs["f"])
+            nxt = None
+            if self.pipelined and obs and getattr(self, "_pipe_lr", None) is not None and self._sde_prm.kind == 0:
+                # the level-0 reduce of the next step's first factorisation rides next to this factorisation's forward sweep
+                self._pipe_drop()
+                lin, sym = self._pipe_predict(cq)
+                nxt = dict(lr=self._pipe_lr, cq=cq, ver=cq.version, v1=self.data_nat1._version, v2=cq.site_sym._version, lin=lin, sym=sym)
+            f = pl.cq_factor(cq, want_logdet=True, out=self._bufs["f"], use_ahead=self._pipe_take(cq) if nxt is None else False,
+                             next_sites=(nxt["lin"], nxt["sym"]) if nxt else None, side=getattr(self, "_pipe_side", None))
+            if nxt is not None:
+                nxt["epoch"] = pl.epoch
+            self._pre = nxt
             self._bufs["f"].update(L=f["L"], y=f["y"])
             s = pl.cq_selinv_kl(cq, f["L"], f["y"], self._sde_prm, out=self._bufs["s"], obs_mu=self.fx_mus_obs if obs else None,
                                 obs_cov=self.fx_covs_obs if obs else None, want_marginals=not lazy)
@@ -739,12 +805,13 @@ class CVISitesSDE(CVISitesSSM):
         if cq is not None:
             # reduce -> forward -> backward sweep that writes (1 - lr) dyn + lr theta~ into the spare buffer; the uniform off-diagonals
             # scale by (1 - lr); the data sites do not enter (they are not part of the resident state)
-            f = pl.cq_factor(cq, want_logdet=False, out=self._bufs["f"])
+            f = pl.cq_factor(cq, want_logdet=False, out=self._bufs["f"], use_ahead=self._pipe_take(cq), side=getattr(self, "_pipe_side", None))
             self._bufs["f"].update(L=f["L"], y=f["y"])
             if cq.spare is None:
                 cq.spare = torch.empty_like(cq.dyn)
             pl.cq_selinv_girsanov(cq, f["L"], f["y"], self._sde_prm, cq.spare)
             cq.dyn, cq.spare = cq.spare, cq.dyn
+            cq.version += 1
             cq.d_off *= 1.0 - lr
             cq.s_off *= 1.0 - lr
             if self._cq_p0_moved and cq.p0_off is not None:
