@@ -108,6 +108,17 @@ int mfgm_lincomb(size_t n, double* out, double a, const double* x, double b, con
  * (variational_cvi.py:364-368, two tf.Variable.assign), in place and in one launch: nat1[i] += w (g1[i] - nat1[i]) for i < n1,
  * nat2[i] += w (g2[i] - nat2[i]) for i < n2 (flat device arrays). */
 int mfgm_site_lerp(double* nat1, const double* g1, size_t n1, double* nat2, const double* g2, size_t n2, double w, void* stream);
+/* The same blend out of place: out1[i] = nat1[i] + w (g1[i] - nat1[i]), out2 likewise (out may be the input).  update_data_sites of
+ * the CVI-DP model (variational_cvi_sde.py:301-317) on its two site arrays, and the same blend made one step ahead into spare buffers
+ * by the pipelined loop (mfgm_cq_factor_pipelined). */
+int mfgm_site_lerp_to(double* out1, const double* nat1, const double* g1, size_t n1, double* out2, const double* nat2, const double* g2,
+                      size_t n2, double w, void* stream);
+/* classic_elbo of the CVI-DP model on the structured state (variational_cvi_sde.py:339-352, 446-486) from the pieces the sweeps leave:
+ * elbo[b] = sum_j ve_part[b, j] - (kl_part[b] + logdet[b] + c)  with ve_part [B, nblk] from mfgm_mvn_ve_compact, kl_part [B] from
+ * mfgm_cq_selinv_kl, logdet [B] = log|L_q| from mfgm_cq_factor and c = -T d / 2; total = sum_b elbo[b] (either output may be NULL);
+ * NaN when *info != 0 (a pivot block was not positive definite).  One launch instead of seven element-wise / reduction kernels. */
+int mfgm_cq_elbo(int B, int nblk, const double* ve_part, const double* kl_part, const double* logdet, double c, const int* info,
+                 double* elbo, double* total, void* stream);
 
 /* Sparse node lists (observation times on the grid): node_ids[i] = b*T + t (int64, device), values natural
  * [n, d] / [n, d, d].  mode 0: gather packed -> values; 1: scatter values -> packed (overwrite);

@@ -42,6 +42,9 @@ EXPORTS = {
     "mfgm_band_sigma_dP_sigma": (ctypes.c_int, [ctypes.c_void_p] * 9),
     "mfgm_site_lerp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_double, ctypes.c_void_p]),
+    "mfgm_site_lerp_to": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_double,
+                                         ctypes.c_void_p]),
+    "mfgm_cq_elbo": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_double] + [ctypes.c_void_p] * 4),
     "mfgm_node_io": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     "mfgm_node_io_pair": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,

@@ -260,6 +260,57 @@ int mfgm_site_lerp(double* nat1, const double* g1, size_t n1, double* nat2, cons
 }
 
 namespace {
+// out <- x + w (g - x) on two arrays in one launch (blockIdx.y picks the array); out may be x
+__global__ __launch_bounds__(256) void k_site_lerp_to(double* o1, const double* x1, const double* __restrict__ g1, size_t n1, double* o2,
+                                                      const double* x2, const double* __restrict__ g2, size_t n2, double w) {
+    double* o = blockIdx.y ? o2 : o1;
+    const double* x = blockIdx.y ? x2 : x1;
+    const double* g = blockIdx.y ? g2 : g1;
+    const size_t n = blockIdx.y ? n2 : n1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = __builtin_fma(w, g[i] - x[i], x[i]);
+}
+// per-chain ELBO of the CVI-DP model on the structured state: sum_j ve_part[b, j] - (kl_part[b] + logdet[b] + c)
+__global__ __launch_bounds__(256) void k_cq_elbo(int B, int nblk, const double* __restrict__ ve_part, const double* __restrict__ kl_part,
+                                                 const double* __restrict__ logdet, double c, const int* __restrict__ info,
+                                                 double* __restrict__ out, double* __restrict__ total) {
+    __shared__ double sh[4];
+    const bool bad = info && *info != 0;
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        double v = 0.0;
+        for (int j = 0; j < nblk; ++j) v += ve_part[(size_t)b * nblk + j];
+        v -= kl_part[b] + logdet[b] + c;
+        if (bad) v = __builtin_nan("");
+        if (out) out[b] = v;
+        acc += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && total) *total = sh[0] + sh[1] + sh[2] + sh[3];
+}
+}  // namespace
+
+int mfgm_site_lerp_to(double* out1, const double* nat1, const double* g1, size_t n1, double* out2, const double* nat2, const double* g2,
+                      size_t n2, double w, void* stream) {
+    if (!out1 || !nat1 || !g1 || !out2 || !nat2 || !g2) return 1;
+    if (n1 == 0 && n2 == 0) return 0;
+    const size_t n = std::max(n1, n2);
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_site_lerp_to, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, out1, nat1, g1, n1, out2, nat2, g2, n2, w);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mfgm_cq_elbo(int B, int nblk, const double* ve_part, const double* kl_part, const double* logdet, double c, const int* info,
+                 double* elbo, double* total, void* stream) {
+    if (B < 1 || nblk < 1 || !ve_part || !kl_part || !logdet || (!elbo && !total)) return 1;
+    hipLaunchKernelGGL(k_cq_elbo, dim3(1), dim3(256), 0, (hipStream_t)stream, B, nblk, ve_part, kl_part, logdet, c, info, elbo, total);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
 struct CombineW { double w[8]; };
 // out[i] = c + ce extra[i] + sum_k w[k] terms[k][i]  (NaN when *info != 0: a pivot block was not positive definite), total = sum_i out[i]
 __global__ void k_combine_terms(int n_terms, int n, const double* __restrict__ terms, CombineW w, double c, const double* __restrict__ extra,

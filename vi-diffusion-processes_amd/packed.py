@@ -439,12 +439,25 @@ class Plan:
                                               _ptr(x), _ptr(kl), _ptr(obs_mu), _ptr(obs_cov), _ptr(self.ws), _stream()), "mfgm_cq_selinv_kl")
         return dict(Sig=Sig, x=x, klpart=kl)
 
-    def mvn_ve_compact(self, mu, cov, n_per, y, Sinv, cst):
-        """mvn_obs_ve on marginals already gathered in observation order; returns ve [B]."""
+    def mvn_ve_compact(self, mu, cov, n_per, y, Sinv, cst, partials=False):
+        """mvn_obs_ve on marginals already gathered in observation order; returns ve [B] (partials=True: the per-block sums
+        [B, ceil(n_per / 256)], for cq_elbo)."""
         ve = torch.empty((self.B, (int(n_per) + 255) // 256), dtype=torch.float64, device=self.device)
         _lib.check(self.lib.mfgm_mvn_ve_compact(self.B, int(n_per), self.d, _ptr(mu), _ptr(cov), _ptr(y), _ptr(Sinv), float(cst), _ptr(ve),
                                                 _stream()), "mfgm_mvn_ve_compact")
-        return ve.sum(-1)
+        return ve if partials else ve.sum(-1)
+
+    def cq_elbo(self, ve_part, kl_part, logdet, c):
+        """(elbo [B], total) = per-chain sum_j ve_part[b, j] - (kl_part[b] + logdet[b] + c) and its sum, in one launch (mfgm_cq_elbo)."""
+        out = torch.empty(self.B + 1, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mfgm_cq_elbo(self.B, int(ve_part.shape[-1]), _ptr(ve_part), _ptr(kl_part), _ptr(logdet), float(c), _ptr(self.info),
+                                         _ptr(out), ctypes.c_void_p(out.data_ptr() + 8 * self.B), _stream()), "mfgm_cq_elbo")
+        return out[:self.B], out[self.B]
+
+    def site_lerp_to(self, out1, x1, g1, out2, x2, g2, w):
+        """out = x + w (g - x) on two flat arrays in one launch (mfgm_site_lerp_to); out may be x."""
+        _lib.check(self.lib.mfgm_site_lerp_to(_ptr(out1), _ptr(x1), _ptr(g1), x1.numel(), _ptr(out2), _ptr(x2), _ptr(g2), x2.numel(), float(w),
+                                              _stream()), "mfgm_site_lerp_to")
 
     def check_info(self):
         """Raise ArithmeticError if a pivot block was not positive definite (synchronises); the message names the first failing chain and

@@ -558,14 +558,14 @@ class CVISitesSDE(CVISitesSSM):
             self._pre = None
 
     def _pipe_predict(self, cq):
-        """(site_lin, site_sym) as the next update_data_sites(self._pipe_lr) will leave them, into the model's two prediction buffers."""
+        """(site_lin, site_sym) as the next update_data_sites(self._pipe_lr) will leave them, into the model's two spare buffers (one
+        launch; update_data_sites then takes them over by exchanging the buffers)."""
         g1, g2p = self._pipe_sites_gradient()
         if getattr(self, "_pipe_bufs", None) is None:
-            self._pipe_bufs = (torch.empty_like(self.data_nat1), torch.empty_like(cq.site_sym))
+            self._pipe_bufs = [torch.empty_like(self.data_nat1), torch.empty_like(cq.site_sym)]
             self._pipe_side = torch.cuda.Stream(device=self.device)
         lin, sym = self._pipe_bufs
-        torch.lerp(self.data_nat1, g1, self._pipe_lr, out=lin)
-        torch.lerp(cq.site_sym, g2p, self._pipe_lr, out=sym)
+        self.plan.site_lerp_to(lin, self.data_nat1, g1.contiguous(), sym, cq.site_sym, g2p, self._pipe_lr)
         return lin, sym
 
     def update_data_sites(self, lr: float):
@@ -575,19 +575,23 @@ class CVISitesSDE(CVISitesSSM):
         # the site gradient of such a likelihood does not depend on the marginals: only the small site arrays move, and the sweeps
         # read them where they need them (no scatter into per-node arrays)
         self._started = True
-        pre = getattr(self, "_pre", None)
+        pre = self._pre
         if (pre is not None and pre["lr"] == float(lr) and pre["cq"] is cq and pre["ver"] == cq.version
-                and pre["v1"] == self.data_nat1._version and pre["v2"] == cq.site_sym._version):
-            # exactly the blend the last ELBO refresh predicted (same inputs, same learning rate): its result is taken over, and the
-            # separator system of the state it gives is already being made
-            self.data_nat1.copy_(pre["lin"])
-            cq.site_sym.copy_(pre["sym"])
-            pre["armed"] = (self.data_nat1._version, cq.site_sym._version)
+                and pre["v1"] == (id(self.data_nat1), self.data_nat1._version) and pre["v2"] == (id(cq.site_sym), cq.site_sym._version)):
+            # exactly the blend the last ELBO refresh predicted (same inputs, same learning rate): its result is taken over -- the
+            # site arrays exchange roles with the spare buffers it was written to -- and the separator system of the state it gives
+            # is already being made
+            self._pipe_bufs = [self.data_nat1, cq.site_sym]
+            self.data_nat1, cq.site_sym = pre["lin"], pre["sym"]
+            cq.site_lin = self.data_nat1
+            pre["armed"] = (id(self.data_nat1), self.data_nat1._version, id(cq.site_sym), cq.site_sym._version)
         else:
             self._pipe_drop()
             g1, g2p = self._pipe_sites_gradient()
-            self.data_nat1.lerp_(g1, lr)                     # (1 - lr) site + lr gradient (variational_cvi_sde.py:301-317)
-            cq.site_sym.lerp_(g2p, lr)
+            # (1 - lr) site + lr gradient (variational_cvi_sde.py:301-317), both site arrays in one launch
+            self.plan.site_lerp_to(self.data_nat1, self.data_nat1, g1.contiguous(), cq.site_sym, cq.site_sym, g2p, lr)
+            torch.autograd.graph.increment_version(self.data_nat1)      # written behind torch's back
+            torch.autograd.graph.increment_version(cq.site_sym)
         self._pipe_lr = float(lr)
         self._q, self._cq_dense, self._obs_fresh = None, None, False
 
@@ -596,7 +600,8 @@ class CVISitesSDE(CVISitesSSM):
         pre = getattr(self, "_pre", None)
         if pre is None:
             return False
-        ok = (pre.get("armed") == (self.data_nat1._version, cq.site_sym._version) and pre["cq"] is cq and pre["ver"] == cq.version)
+        ok = (pre.get("armed") == (id(self.data_nat1), self.data_nat1._version, id(cq.site_sym), cq.site_sym._version)
+              and pre["cq"] is cq and pre["ver"] == cq.version)
         if not ok or pre["epoch"] != self.plan.epoch:      # (another factorisation on the plan may have used the workspace since)
             self._pipe_drop()
             return False
@@ -620,7 +625,8 @@ class CVISitesSDE(CVISitesSSM):
                 # the level-0 reduce of the next step's first factorisation rides next to this factorisation's forward sweep
                 self._pipe_drop()
                 lin, sym = self._pipe_predict(cq)
-                nxt = dict(lr=self._pipe_lr, cq=cq, ver=cq.version, v1=self.data_nat1._version, v2=cq.site_sym._version, lin=lin, sym=sym)
+                nxt = dict(lr=self._pipe_lr, cq=cq, ver=cq.version, v1=(id(self.data_nat1), self.data_nat1._version),
+                           v2=(id(cq.site_sym), cq.site_sym._version), lin=lin, sym=sym)
             f = pl.cq_factor(cq, want_logdet=True, out=self._bufs["f"], use_ahead=self._pipe_take(cq) if nxt is None else False,
                              next_sites=(nxt["lin"], nxt["sym"]) if nxt else None, side=getattr(self, "_pipe_side", None))
             if nxt is not None:
@@ -646,14 +652,35 @@ class CVISitesSDE(CVISitesSSM):
             self._q.update(mu=s["x"], Sig=s["Sig"])
         return self._q
 
-    def variational_expectation(self):
+    def variational_expectation(self, partials=False):
         cq, lik = self._cq_state(), self.likelihood
         if cq is None or cq.slot is None:
             return super().variational_expectation()
         self._refresh()
         if not getattr(self, "_obs_fresh", False):
             self._gather_obs()
-        return self.plan.mvn_ve_compact(self.fx_mus_obs, self.fx_covs_obs, self.n_obs, self._obs_flat(), lik.inv_covariance, lik.ve_constant)
+        return self.plan.mvn_ve_compact(self.fx_mus_obs, self.fx_covs_obs, self.n_obs, self._obs_flat(), lik.inv_covariance, lik.ve_constant,
+                                        partials=partials)
+
+    def _cq_elbo(self):
+        """(per-trajectory ELBO [B], their sum) assembled by ONE launch from what the sweeps left (mfgm_cq_elbo): the variational
+        expectations' block sums, the KL sum of the backward sweep and log|L_q|; None when the model is not on that route."""
+        cq = self._cq_state()
+        if cq is None or cq.slot is None:
+            return None
+        q = self._refresh()
+        if q["klpart"] is None:
+            return None
+        ve = self.variational_expectation(partials=True)
+        return self.plan.cq_elbo(ve, q["klpart"], q["logdetL"], -0.5 * self.T * self.state_dim)
+
+    def classic_elbo_per_trajectory(self):
+        e = self._cq_elbo()
+        return e[0] if e is not None else super().classic_elbo_per_trajectory()
+
+    def classic_elbo(self):
+        e = self._cq_elbo()
+        return e[1] if e is not None else super().classic_elbo()
 
     def KL_q_p(self):
         """
