@@ -105,14 +105,18 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None, drift=None, Lc=N
                               np.ones(d), dt, np.zeros(d), v0 * np.eye(d))
     st.step(args.lr_data, args.lr_girsanov)         # first step doubles as warm-up and as a parity probe
     first = st.elbo.copy()
-    n, t0 = 0, time.perf_counter()
-    while True:
+    for _ in range(2):                              # >= 20 steps after 3 warm-ups (bounded at 30 s of CPU work)
         st.step(args.lr_data, args.lr_girsanov)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or n >= 20:
+    times = []
+    t0 = time.perf_counter()
+    while True:
+        t1 = time.perf_counter()
+        st.step(args.lr_data, args.lr_girsanov)
+        times.append(time.perf_counter() - t1)
+        if time.perf_counter() - t0 > 30.0 or len(times) >= 20:
             break
-    per_step_sample = el / n
+    n, el = len(times), float(sum(times))
+    per_step_sample = float(np.median(times))
     value = 1.0 / (per_step_sample * args.B / Bs)
     # one thread, one trajectory (the OpenMP loop runs over trajectories: a single trajectory is the single-thread figure)
     lib.ref_set_num_threads(1)
@@ -125,7 +129,7 @@ def cpu_baseline(args, idx, ys, dt, noise, gpu_first_elbo=None, drift=None, Lc=N
     lib.ref_set_num_threads(threads)
     out = {"value": value, "unit": "ELBO steps/s", "cores": threads, "threads_used": Bs, "kind": "port",
            "single_thread_value": 1.0 / (one * args.B),
-           "sample": f"{n} steps of {Bs} of the {args.B} trajectories (T={T}, d={d}), OpenMP over trajectories ({Bs} of the {threads} "
+           "sample": f"median of {n} steps after 3 warm-ups of {Bs} of the {args.B} trajectories (T={T}, d={d}), OpenMP over trajectories ({Bs} of the {threads} "
                      f"hardware threads busy: one per trajectory); {per_step_sample:.3f} s per sampled step, scaled linearly to "
                      f"{args.B} trajectories; single thread: one step of one trajectory {one:.3f} s, scaled to {args.B}; "
                      f"closed-form cubic-drift moments as on the GPU (the reference's 20^d-point quadrature is infeasible at d={d})"}
@@ -652,6 +656,11 @@ def bench_cvidp(h, data_rank):
     grid = np.arange(T) * dt
     # plan=None: the model builds its own partition, segments aligned with the equally spaced observation grid (packed.aligned_segment_length)
     model = CVISitesSDE(sde, grid, (grid[idx], torch.from_numpy(ys).to(device)), lik, prior_initial_state=init, plan=None)
+    if getattr(args, "dense", False):
+        # the DENSE-naturals route (what VIDP_CQ=0 selects, and what every model without the structure of DESIGN 5b runs on: coupled
+        # drifts, non-Gaussian likelihoods, loaded Girsanov sites): theta_q as full packed (lin, diag, sub) arrays
+        model.cq_enabled = False
+        what += "; DENSE posterior naturals (cq state off)"
     plan = model.plan
 
     elbos, first_elbo = [], []
@@ -723,6 +732,7 @@ def bench_cvidp(h, data_rank):
             cst = cq.struct()
             out["config"]["state_layout"] = ("cq: (theta_lin, diag theta_diag, diag theta_sub) per node + uniform off-diagonals; the data "
                                              "sites are added inside the sweeps (csrc/mfgm_cq.h)")
+            out["config"]["pipelined_across_steps"] = bool(model.pipelined)
 
             def stage(st):
                 assert lib.mfgm_cq_factor_stage(plan.h, st, ctypes.byref(cst), _ptr(f["L"]), _ptr(f["y"]), _ptr(plan.ws), _ptr(plan.info),
@@ -744,7 +754,10 @@ def bench_cvidp(h, data_rank):
                 (f"void mfgm::k_forward_cq<{d}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot) + (ET + d), lambda: stage(1),
                  "level 0 forward: block Cholesky + forward substitution; reads the cq record and the slot, writes L and y"),
                 (f"void mfgm::k_reduce_cq<{d}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot), lambda: stage(0),
-                 "level 0 reduce: segment elimination; reads the cq record and the slot"),
+                 "level 0 reduce: segment elimination; reads the cq record and the slot"
+                 + (" (timed alone; in the pipelined loop one of the step's two reduces runs as k_reduce_cq_lean on a second stream, "
+                    "next to the forward sweep of the previous factorisation: share_of_step counts it as if it ran alone)"
+                    if model.pipelined else "")),
                 (f"void mfgm::k_backward_kl_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs)", 1,
                  (ET + d + d + slot) + (0 if lazy else ET + d), backward,
                  "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, y, diag theta_sub, slot; writes "
@@ -832,6 +845,8 @@ def bench_cvidp(h, data_rank):
             coarse_b = timed(coarse_selinv)
             out["roofline"]["step"].update(coarse_factor_ms_per_refresh=coarse_f, coarse_backward_ms_per_refresh=coarse_b,
                                            coarse_levels_share_of_step=2 * (coarse_f + coarse_b) / ms_per_step)
+        if getattr(args, "through_trainer", False) and args.config in ("headline", "c1"):
+            out["trainer"] = trainer_rate(model, args)
         if world == 1 and not args.no_vdp and args.config == "headline":
             # free the CVI-DP state first: the VDP model keeps its own ~15 GB resident
             del model, f, s, cand, cq
@@ -851,6 +866,27 @@ def bench_cvidp(h, data_rank):
 
 
 
+def trainer_rate(model, args):
+    """The same loop driven by the TRAINER (vidp_amd.trainers.CVISitesTrainer._optimize_sites_under_stable_prior =
+    cvi_dp_trainer.py:63-95: update_data_sites, update_girsanov_sites, classic_elbo, learning-rate decay and convergence rules),
+    continuing from the state the bare loop left: steps/s with the trainer's own control flow around the kernels."""
+    import torch
+    from vidp_amd.trainers import CVISitesTrainer
+    k = max(4, args.steps)
+    tr = CVISitesTrainer(model, max_itr_sites_optim=k, optim_tol=0.0, data_sites_lr=args.lr_data, girsanov_sites_lr=args.lr_girsanov,
+                         sync_every=args.trainer_sync_every)
+    tr._optimize_sites_under_stable_prior()                 # warm-up pass of k iterations
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    elbos, _, _ = tr._optimize_sites_under_stable_prior()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": len(elbos) / el, "unit": "ELBO steps/s", "ms_per_step": 1e3 * el / len(elbos), "iterations": len(elbos),
+            "sync_every": tr.sync_every, "elbo_last": float(elbos[-1]), "learning_rates": [tr.data_sites_lr, tr.girsanov_sites_lr],
+            "workload": "CVISitesTrainer._optimize_sites_under_stable_prior (cvi_dp_trainer.py:63-95) on the same model: the bare "
+                        "loop plus the trainer's ELBO bookkeeping, learning-rate decay and convergence checks"}
+
+
 def other_configs(args, harness, data_rank):
     """BASELINE.json's other configurations, each as a short run of the same contract (value, ms_per_step, roofline, cpu_baseline), so
     that the driver's one default invocation records them all: c1 (the reference's CPU-runnable case), c2, c3 and c5 on one GPU."""
@@ -858,12 +894,16 @@ def other_configs(args, harness, data_rank):
     import gc
     import torch
     res = {}
-    for name in ("c1", "c2", "c3", "c5"):
+    for name in ("c1", "c2", "c3", "c5", "headline_dense"):
         a = copy.copy(args)
         a.config, a.steps, a.warmup, a.no_vdp = name, args.other_steps, 2, True
         a.B, a.T, a.d, a.lr_data, a.lr_girsanov = 64, 100000, 6, 0.5, 0.1      # (c1 / c3 set their own sizes)
+        a.dense = a.through_trainer = False
+        if name == "headline_dense":
+            # the headline workload on the dense-naturals route (no cq state): the path of every model without that structure
+            a.config, a.dense, a.no_cpu_baseline = "headline", True, True
         h = Harness(a, harness.rank, harness.world, harness.device, harness.dist, harness.vdist)
-        fn = bench_cvidp if name == "c1" else OTHER_CONFIGS[name]
+        fn = bench_cvidp if name in ("c1", "headline_dense") else OTHER_CONFIGS[name]
         try:
             o = fn(h, data_rank)
             res[name] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "elbo_last", "roofline", "cpu_baseline")
@@ -890,6 +930,10 @@ def main():
     ap.add_argument("--no-vdp", action="store_true", help="skip the secondary VDP step measurement")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="headline run only: do not append the short runs of BASELINE.json's other configurations (other_configs)")
+    ap.add_argument("--dense", action="store_true", help="CVI-DP on the dense-naturals route (the cq state off, as VIDP_CQ=0)")
+    ap.add_argument("--through-trainer", action="store_true",
+                    help="also time the loop through CVISitesTrainer (cvi_dp_trainer.py:63-95) on the same model: `trainer` in the line")
+    ap.add_argument("--trainer-sync-every", type=int, default=8, help="iterations between host synchronisations of the trainer loop")
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each configuration under other_configs")
     ap.add_argument("--config", default="headline", choices=["headline", "c1", "c2", "c3", "c5"],
                     help="BASELINE.json configuration (default: the size the metric is quoted on)")

@@ -348,3 +348,25 @@ class VariationalMarkovGP:
             m, S = self.forward_pass()
         E_obs = np.sum(self.lik.variational_expectations(m[self.obs_index], S[self.obs_index], self.y))
         return E_obs - self.E_sde() - self.KL_initial_state()
+
+
+def calculate_nlpd(m, S, chol_R, time_grid, test_times, test_obs):
+    """Negative log predictive density at held-out grid points (docs/diffusion_processes/exp_dp_utils.py:189-206 on the output of
+    likelihood.predict_mean_and_var, cvi_dp_trainer.py:189-196 / multivariate_gaussian.py: y* ~ N(m, S + R)): minus the MEAN over the
+    test points of log N(y_i; m_i, S_i + R).  m [T, d], S [T, d, d]."""
+    idx = np.array([int(np.argmin(np.abs(time_grid - t))) for t in test_times])
+    R = chol_R @ chol_R.T
+    tot = 0.0
+    for i, y in zip(idx, test_obs):
+        C = S[i] + R
+        L = np.linalg.cholesky(C)
+        z = np.linalg.solve(L, y - m[i])
+        tot += -0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * len(y) * np.log(2 * np.pi)
+    return -tot / len(idx)
+
+
+def calculate_rmse(m, time_grid, test_times, test_obs):
+    """Root of the mean squared error over all entries at the held-out grid points (exp_dp_utils.py:209-223)."""
+    idx = np.array([int(np.argmin(np.abs(time_grid - t))) for t in test_times])
+    return float(np.sqrt(np.mean((m[idx] - test_obs) ** 2)))
+

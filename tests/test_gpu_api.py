@@ -553,6 +553,87 @@ def test_trainers(amd, rng):
     assert ev[-1] <= loglik + 1e-6
 
 
+def test_trainer_metrics_and_batched_loop(amd, rng):
+    """f-2: (i) NLPD / RMSE of the trainers against the oracle's restatement of exp_dp_utils.py:189-224 on the oracle model's own
+    marginals, after the same site updates (CVI-DP, double well, d = 2; and the VDP trainer's metrics on its forward pass);
+    (ii) CVISitesTrainer with one host synchronisation per 4 iterations (checkpoint + replay when a learning-rate rule fires inside a
+    batch) against the plain per-iteration loop: the same ELBO / NLPD / RMSE sequences, the same learning rates and the same final
+    state, on a problem whose learning rates are too large on purpose so that the decay rule fires."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.trainers import CVISitesTrainer, VIMarkovGPTrainer
+    from vidp_amd.variational_cvi_sde import CVISitesSDE
+    from vidp_amd.vi_sde import VariationalMarkovGP
+    B, T, d, dt = 2, 90, 2, 0.02
+    grid = np.arange(T) * dt
+    idx = np.arange(4, T - 1, 7)
+    tidx = np.array([i for i in range(2, T - 1, 5) if i not in set(idx)])
+    y = np.sign(rng.normal(size=(B, len(idx), d))) + 0.2 * rng.normal(size=(B, len(idx), d))
+    yt = np.sign(rng.normal(size=(B, len(tidx), d))) + 0.2 * rng.normal(size=(B, len(tidx), d))
+    cholR = np.array([[0.3, 0.0], [0.1, 0.25]])
+    init = (np.zeros(d), 0.5 * np.eye(d))
+    mk = lambda: CVISitesSDE(gsde.DoubleWellSDE(torch.eye(d, dtype=torch.float64)), grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)),
+                             prior_initial_state=init, plan=amd.Plan(B, T, d, R0=8, Rup=3))
+    # (i) metrics against the oracle
+    g = mk()
+    os_ = [np_models.CVISitesSDE(np_sde.DoubleWellSDE(np.eye(d)), grid, idx, y[b], np_models.MultivariateGaussianLik(cholR), *init) for b in range(B)]
+    tr = CVISitesTrainer(g, test_data=(grid[tidx], dev(yt)), data_sites_lr=0.5, girsanov_sites_lr=0.2)
+    for m in [g] + os_:
+        m.update_data_sites(0.5)
+        m.update_girsanov_sites(0.2)
+    _, nl, rm = tr._elbo_nlpd_rmse()
+    marg = [o.dist_q.marginals for o in os_]
+    want_nl = np.mean([np_models.calculate_nlpd(mu, S, cholR, grid, grid[tidx], yt[b]) for b, (mu, S) in enumerate(marg)])
+    want_rm = np.sqrt(np.mean([np_models.calculate_rmse(mu, grid, grid[tidx], yt[b]) ** 2 for b, (mu, _) in enumerate(marg)]))
+    np.testing.assert_allclose(nl, want_nl, rtol=1e-7)
+    np.testing.assert_allclose(rm, want_rm, rtol=1e-7)
+    v = VariationalMarkovGP((grid[idx], dev(y)), gsde.DoubleWellSDE(torch.eye(d, dtype=torch.float64)), grid, MultivariateGaussian(dev(cholR)),
+                            prior_initial_state=init, plan=amd.Plan(B, T, d, R0=8, Rup=3))
+    ov = [np_models.VariationalMarkovGP(idx, y[b], np_sde.DoubleWellSDE(np.eye(d)), grid, np_models.MultivariateGaussianLik(cholR), *init)
+          for b in range(B)]
+    tv = VIMarkovGPTrainer(v, test_data=(grid[tidx], dev(yt)))
+    mS = v._forward_packed()
+    ev, nv, rv = tv._elbo_nlpd_rmse(mS)
+    fw = [o.forward_pass() for o in ov]
+    np.testing.assert_allclose(ev, sum(o.elbo(*f) for o, f in zip(ov, fw)), rtol=1e-8)
+    np.testing.assert_allclose(nv, np.mean([np_models.calculate_nlpd(m_, S_, cholR, grid, grid[tidx], yt[b]) for b, (m_, S_) in enumerate(fw)]), rtol=1e-7)
+    np.testing.assert_allclose(rv, np.sqrt(np.mean([np_models.calculate_rmse(m_, grid, grid[tidx], yt[b]) ** 2 for b, (m_, _) in enumerate(fw)])), rtol=1e-7)
+    # (ii) batched loop == plain loop; learning rates large enough for the ELBO to drop at some iteration
+    def run(k, lr_d, lr_g, tol):
+        m = mk()
+        t = CVISitesTrainer(m, test_data=(grid[tidx], dev(yt)), data_sites_lr=lr_d, girsanov_sites_lr=lr_g, max_itr_sites_optim=14,
+                            optim_tol=tol, sync_every=k)
+        e, n, r = t._optimize_sites_under_stable_prior()
+        return (np.array(e), np.array(n), np.array(r), t.data_sites_lr, t.girsanov_sites_lr, host(m.plan.unpack(amd.VEC, m.full_sites().lin)))
+
+    def same(a, b):
+        assert len(a[0]) == len(b[0]) and (a[3], a[4]) == (b[3], b[4])
+        for x, y_ in zip(a[:3], b[:3]):
+            np.testing.assert_allclose(y_, x, rtol=1e-12)
+        assert_close(b[5], a[5], rtol=1e-12)
+
+    # the decay rule: over-relaxed data sites (|1 - lr| < 1: they still converge, but alternating around the fixed point) make the plain
+    # loop's ELBO drop at some iteration without driving the posterior away
+    plain = None
+    for lr_d, lr_g in ((1.8, 0.3), (1.9, 0.3), (1.7, 0.6), (1.95, 0.2)):
+        try:
+            cand = run(1, lr_d, lr_g, 1e-9)
+        except ArithmeticError:
+            continue
+        if cand[3] < lr_d and np.isfinite(cand[0]).all():
+            plain = (lr_d, lr_g, cand)
+            break
+    assert plain is not None, "no learning rate made the decay rule fire"
+    same(plain[2], run(4, plain[0], plain[1], 1e-9))
+    same(plain[2], run(3, plain[0], plain[1], 1e-9))
+    # the convergence rule firing inside a batch
+    conv = run(1, 0.5, 0.2, 0.5)
+    assert 2 < len(conv[0]) < 14
+    same(conv, run(4, 0.5, 0.2, 0.5))
+
+
 def test_ssm_natgrad_one_step_optimum(amd, rng):
     """KA9 (reference tests/integration/test_ssm_natgrad.py:46-65): one natural-gradient step with gamma = 1 and a Gaussian
     likelihood makes the variational ELBO equal to the GPR log-likelihood (atol 1e-5, rtol 1e-6), from any initial q."""

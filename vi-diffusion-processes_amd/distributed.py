@@ -65,6 +65,17 @@ def sum_over_ranks(values):
     return t.tolist()
 
 
+def sum_tensor_over_ranks(t):
+    """Sum a small device tensor over the ranks (one all-reduce, no host synchronisation); the tensor itself without a group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() != "nccl" and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            return c.to(t.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def allgather_(t):
     """[world, *t.shape] tensor of every rank's `t` (the tensor itself, with a leading axis of 1, without a process group)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

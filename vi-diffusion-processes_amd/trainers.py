@@ -4,8 +4,11 @@ Host-side mirror of the experiment trainers that drive the hot path: `CVISitesTr
 (docs/diffusion_processes/vi_markov_gp_trainer.py:17-135): the inference loops with their learning-rate decay and
 convergence rules, NLPD / RMSE on held-out grid points (exp_dp_utils.py:189-224), and the prior-parameter learning loops
 (cvi_dp_trainer.py:138-250, vi_markov_gp_trainer.py:163-215: Adam on the drift parameters).  The wandb / hydra
-plumbing is out of scope.  One host synchronisation per iteration remains (the ELBO scalar decides
-the learning-rate decay), everything else stays on the device.
+plumbing is out of scope.  The site-optimisation loop of CVISitesTrainer synchronises the host once per `sync_every` iterations
+(`_optimize_sites_batched`: the iterations of a batch are issued back to back with their ELBO / metric sums kept on the device; the
+learning-rate decay and convergence rules are then applied to the batch's values exactly as the reference applies them one by one,
+and when a rule fires inside a batch the model is put back to the batch's checkpoint and the iterations up to that point are replayed --
+the kernels are deterministic, so the sequence of states and numbers is the reference's); sync_every=1 is the plain loop.
 
 Trajectories spread over processes (SURVEY 8e first row; each process builds its model on its own shard of the batch): every scalar
 that steers a loop -- the ELBO, the NLPD / RMSE sums -- and every hyper-parameter gradient is summed over the ranks
@@ -55,6 +58,19 @@ class _Metrics:
         logp = -0.5 * (z * z).sum(-1) - torch.log(torch.diagonal(chol, dim1=-2, dim2=-1)).sum(-1) - 0.5 * d * math.log(2 * math.pi)
         return float(logp.sum()), float(((m - self.y.reshape(B * n, d)) ** 2).sum()), float(B * n), float(B * n * d)
 
+    def sums_device(self, mu_packed, Sig_packed):
+        """The same four sums as a device tensor [4] (no host synchronisation)."""
+        pl, lik = self.model.plan, self.model.likelihood
+        B, n, d = self.y.shape
+        m = pl.gather_nodes(VEC, mu_packed, self.node_ids)
+        S = pl.gather_nodes(SYM, Sig_packed, self.node_ids)
+        R = lik.chol_covariance @ lik.chol_covariance.transpose(-1, -2)
+        chol = linalg.cholesky(S + R, check=False)          # (no synchronisation: a failed pivot shows as NaN in the sums)
+        z = linalg.solve_lower(chol, self.y.reshape(B * n, d) - m)
+        logp = -0.5 * (z * z).sum(-1) - torch.log(torch.diagonal(chol, dim1=-2, dim2=-1)).sum(-1) - 0.5 * d * math.log(2 * math.pi)
+        cnt = torch.tensor([float(B * n), float(B * n * d)], dtype=torch.float64, device=m.device)
+        return torch.cat([logp.sum().reshape(1), ((m - self.y.reshape(B * n, d)) ** 2).sum().reshape(1), cnt])
+
     @staticmethod
     def finish(logp_sum, se_sum, n_points, n_entries):
         if n_points == 0:
@@ -87,8 +103,11 @@ class CVISitesTrainer:
 
     def __init__(self, model, test_data=None, prior_sde=None, max_itr=100, optim_tol=1e-2, max_itr_sites_optim=20,
                  girsanov_sites_lr=0.1, data_sites_lr=0.1, learn_prior_sde=False, prior_sde_lr=1e-2, learning_max_itr=100,
-                 learning_tol=1e-2):
+                 learning_tol=1e-2, sync_every=1):
         self.model, self.prior_sde = model, prior_sde
+        # iterations of the site loop between host synchronisations (1: the reference's loop as written; > 1 needs a model with
+        # snapshot() / restore(), i.e. CVISitesSDE)
+        self.sync_every = int(sync_every) if hasattr(model, "snapshot") else 1
         self.max_itr, self.optim_tol, self.max_itr_sites_optim = max_itr, optim_tol, max_itr_sites_optim
         self.girsanov_sites_lr, self.data_sites_lr = girsanov_sites_lr, data_sites_lr
         self._metrics = _Metrics(model, test_data, model.time_grid)
@@ -160,8 +179,71 @@ class CVISitesTrainer:
         tot = sum_over_ranks([e, *self._metrics.sums(q["mu"], q["Sig"])])
         return (tot[0], *self._metrics.finish(*tot[1:]))
 
+    def _device_sums(self):
+        """[ELBO, sum log p, sum of squared errors, points, entries] of the local trajectories as ONE device tensor (no host
+        synchronisation): what _elbo_nlpd_rmse reduces over the ranks and finishes on the host."""
+        e = self.model.classic_elbo().reshape(1)
+        if self._metrics.idx is None:
+            return e
+        q = self.model._refresh(want_marginals=True)
+        return torch.cat([e, self._metrics.sums_device(q["mu"], q["Sig"])])
+
+    def _optimize_sites_batched(self):
+        """cvi_dp_trainer.py:63-95 with one host synchronisation per `sync_every` iterations (module docstring)."""
+        from .distributed import sum_tensor_over_ranks
+        model, k = self.model, self.sync_every
+        elbos = [self._elbo()]
+        nlpds, rmses = [], []
+        done = False
+        while (len(elbos) - 1) < self.max_itr_sites_optim and not done:
+            n_it = min(k, self.max_itr_sites_optim - (len(elbos) - 1))
+            snap = model.snapshot() if n_it > 1 else None
+
+            def run(n):
+                out = []
+                for _ in range(n):
+                    model.update_data_sites(self.data_sites_lr)
+                    model.update_girsanov_sites(self.girsanov_sites_lr)
+                    out.append(self._device_sums())
+                return sum_tensor_over_ranks(torch.stack(out)).cpu()      # the batch's one synchronisation (and one all-reduce)
+
+            vals = run(n_it)
+            # the reference's rules, iteration by iteration, on the batch's values
+            fired, decay = n_it, False
+            for i in range(n_it):
+                prev = elbos[-1] if i == 0 else float(vals[i - 1, 0])
+                cur = float(vals[i, 0])
+                n_seen = len(elbos) + i + 1
+                dec = n_seen > 2 and prev > cur
+                conv = n_seen > 2 and abs(prev - cur) < self.optim_tol
+                if dec or conv:
+                    fired, decay, done = i + 1, dec, conv
+                    break
+            if fired < n_it:
+                # a rule fired inside the batch: the iterations after it ran with learning rates (or at all) the reference would not
+                # have used -- back to the checkpoint, the iterations up to the rule again (deterministic kernels: the same numbers)
+                model.restore(snap)
+                vals = run(fired)
+            for i in range(fired):
+                elbos.append(float(vals[i, 0]))
+                nl, rm = (self._metrics.finish(*[float(v) for v in vals[i, 1:]]) if self._metrics.idx is not None
+                          else (float("nan"), float("nan")))
+                nlpds.append(nl)
+                rmses.append(rm)
+            if not math.isfinite(elbos[-1]):
+                model.plan.check_info()      # a NaN ELBO is how a failed pivot surfaces without a per-iteration synchronisation
+            if decay:
+                logger.info("Decaying LR! ELBO decreasing!!!")
+                self.girsanov_sites_lr /= 10
+                self.data_sites_lr /= 10
+            if done:
+                logger.info("Breaking the site updates loop. ELBO converged!")
+        return elbos[1:], nlpds, rmses
+
     def _optimize_sites_under_stable_prior(self):
         """cvi_dp_trainer.py:63-95."""
+        if self.sync_every > 1:
+            return self._optimize_sites_batched()
         elbos = [self._elbo()]
         nlpds, rmses = [], []
         while (len(elbos) - 1) < self.max_itr_sites_optim:

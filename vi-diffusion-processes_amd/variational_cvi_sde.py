@@ -595,6 +595,41 @@ class CVISitesSDE(CVISitesSSM):
         self._pipe_lr = float(lr)
         self._q, self._cq_dense, self._obs_fresh = None, None, False
 
+    def snapshot(self):
+        """Everything update_data_sites / update_girsanov_sites move, copied: the checkpoint a trainer that synchronises the host once
+        per batch of iterations returns to when a learning-rate rule fires inside a batch (trainers.CVISitesTrainer)."""
+        cq = self._cq_state()
+        if cq is not None:
+            return dict(kind="cq", cq=cq, dyn=cq.dyn.clone(), d_off=cq.d_off, s_off=cq.s_off,
+                        p0=None if cq.p0_off is None else cq.p0_off.clone(), lin=self.data_nat1.clone(),
+                        sym=None if cq.site_sym is None else cq.site_sym.clone(), started=self._started)
+        tq = self.full_sites()
+        return dict(kind="dense", tq=(tq.lin.clone(), tq.diag.clone(), tq.sub.clone()), lin=self.data_nat1.clone(), n2=self.data_nat2.clone(),
+                    started=self._started)
+
+    def restore(self, snap):
+        self._pipe_drop()
+        if snap["kind"] == "cq":
+            cq = snap["cq"]
+            if self._cq is not cq:
+                raise RuntimeError("the model left the structured state since the snapshot was taken")
+            cq.dyn.copy_(snap["dyn"])
+            cq.d_off, cq.s_off = snap["d_off"], snap["s_off"]
+            if snap["p0"] is not None:
+                cq.p0_off.copy_(snap["p0"])
+            self.data_nat1.copy_(snap["lin"])
+            if snap["sym"] is not None:
+                cq.site_sym.copy_(snap["sym"])
+            cq.version += 1
+        else:
+            tq = self.full_sites()
+            for dst, src in zip((tq.lin, tq.diag, tq.sub), snap["tq"]):
+                dst.copy_(src)
+            self.data_nat1.copy_(snap["lin"])
+            self.data_nat2.copy_(snap["n2"])
+        self._started = snap["started"]
+        self._q, self._cq_dense, self._obs_fresh = None, None, False
+
     def _pipe_take(self, cq):
         """Whether a separator system was made ahead for the state as it is NOW: consumed by the next factorisation."""
         pre = getattr(self, "_pre", None)
