@@ -311,6 +311,43 @@ int mfgm_cq_selinv_kl(const mfgm_plan* plan, int only_level, const mfgm_cq_state
 int mfgm_mvn_ve_compact(int B, int n_per, int d, const double* mu, const double* cov, const double* y, const double* Sinv, double cst,
                         double* ve, void* stream);
 
+/* ---- Tensor-product Gauss-Hermite kernels: drifts that couple the state dimensions / have no polynomial form, full diffusion matrix ----
+ * The reference's own formulation of the local CVI-DP / VDP quantities (gpflow.quadrature.mvnquad: nodes m + sqrt(2) L xi, 10 points per
+ * dimension in the linearisation, 20 in the KL / E_sde), with the GradientTape's chain rule written out (the rule is differentiated as a
+ * formula).  Arrays in the reference's NATURAL layout, device pointers; d <= 3; small models (20^d nodes per time step).
+ *   kind 10  Van der Pol (markovflow/sde/sde.py:432-518), d = 2: theta = (a, tau)
+ *   kind 11  ReLU network 1 -> nh -> 1 on every state dimension (sde.py:359-429): theta = (W1 [nh], b1 [nh], W2 [nh], b2), nh <= 13
+ *   kind 12  per-dimension cubic c1 x - c3 x^3 (Ornstein-Uhlenbeck / double well, sde.py:134-224) with a NON-DIAGONAL diffusion
+ *            matrix: theta = (c1, c3) */
+#define MFGM_QUAD_NTHETA 40
+typedef struct mfgm_quad_drift {
+    int kind, d, nh, pad_;
+    double theta[MFGM_QUAD_NTHETA];
+    double dt;
+    double W[6];           /* (dt q)^{-1}, packed lower triangle */
+    double logdetQp;       /* log det (dt q) */
+    double mu0[3];         /* p(x0) */
+    double P0inv[6];       /* packed lower triangle */
+    double logdetP0;
+    double clip_lo, clip_hi;   /* clipping of the linearised A, b (variational_cvi_sde.py:420-432); lo >= hi: none */
+} mfgm_quad_drift;
+/* A [N, d, d] = I + dt E_q[df/dx], b [N, d] = dt (E_q f - E_q[df/dx] m) on N(mean[n], cov[n]) (sde_utils.py:119-179, drift.py:66-117);
+ * *info becomes non-zero when a covariance is not positive definite */
+int mfgm_quad_linearize(const mfgm_quad_drift* drift, int N, const double* mean, const double* cov, double* A, double* b, int* info,
+                        void* stream);
+/* KL[q || p_SDE] of B chains along their Gaussian paths (sde_utils.py:262-359): mu [B, T, d], Sig [B, T, d, d], Sub [B, T-1, d, d] =
+ * Cov(x_{t+1}, x_t) -> kl [B]; with g1 [B, T, d], gd [B, T, d, d], gs [B, T-1, d, d] (all or none) its gradient with respect to the
+ * expectation parameters (sde_utils.py:473-547), and with gtheta [B, np] (np = 2, or 3 nh + 1 for kind 11; may be NULL) the gradient with
+ * respect to the drift parameters (variational_cvi_sde.py:495-506).  scratch: mfgm_quad_kl_scratch_doubles(B, T, d, nh) doubles. */
+size_t mfgm_quad_kl_scratch_doubles(int B, int T, int d, int nh);
+int mfgm_quad_kl(const mfgm_quad_drift* drift, int B, int T, const double* mu, const double* Sig, const double* Sub, double* kl,
+                 double* g1, double* gd, double* gs, double* gtheta, double* scratch, int* info, void* stream);
+/* VDP: E_sde per node without the Riemann factor dt, E [N] = 1/2 E_{N(mean, cov)} |f(x) + A x - b|^2_{q^-1} (the variational drift is
+ * -A x + b, vi_sde.py:422-434, sde_utils.py:182-259), and its gradients with respect to (m, S) (vi_sde.py:205-243), (A, b) and the drift
+ * parameters (vi_sde.py:457-470); every output but E may be NULL. */
+int mfgm_quad_esde(const mfgm_quad_drift* drift, int N, const double* mean, const double* cov, const double* A, const double* b, double* E,
+                   double* dEdm, double* dEdS, double* dEdA, double* dEdb, double* gtheta, int* info, void* stream);
+
 /* ---- Kalman filter with Gaussian sites and a time-invariant emission matrix (kalman_filter.py:86-107, 184-271, 417-500) ----------------
  * The path of KalmanFilterWithSites.log_likelihood / CVIGaussianProcess.elbo and of predict_f at the data points
  * (variational_cvi.py:106-135, 351-379): sites nat1 [Bs, T, o], nat2 [Bs, T, o, o] in natural layout (Bs = 1: shared by all chains,

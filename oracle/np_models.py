@@ -106,13 +106,14 @@ class CVISitesSDE(CVISitesSSM):
     """
 
     def __init__(self, prior_sde, time_grid, obs_index, observations, likelihood, init_mu, init_cov, stabilize_ssm=True,
-                 clip=(-1.0, 1.0), closed_form=False):
+                 clip=(-1.0, 1.0), closed_form=False, exact_q=False):
         """closed_form: every expectation under q (E f, E f', the Girsanov KL) from the cubic drift's Gaussian moments instead of
         the reference's H^d-point Gauss-Hermite grids -- the same numbers (both are exact for a cubic; pinned against each other at
         d <= 2 in tests/test_oracle_sde.py and tests/test_oracle_models.py), tractable at d = 6."""
         from . import np_sde
         self._np_sde = np_sde
         self.closed_form = bool(closed_form)
+        self.exact_q = bool(exact_q)          # full diffusion matrices: np_sde.linearize_sde(exact_q=True)
         self.sde = prior_sde
         self.init_mu, self.init_cov = np.asarray(init_mu, dtype=np.float64), np.asarray(init_cov, dtype=np.float64)
         self.stabilize_ssm, self.clip = stabilize_ssm, clip
@@ -122,7 +123,7 @@ class CVISitesSDE(CVISitesSSM):
 
     def set_linearized_prior(self):
         lin = self._np_sde.linearize_sde(self.sde, self.time_grid, self.fx_mus[1:], self.fx_covs[1:], self.init_mu, self.init_cov,
-                                         closed_form=self.closed_form)
+                                         closed_form=self.closed_form, exact_q=self.exact_q)
         self.dist_p_linearized = lin
         if self.stabilize_ssm:
             self.dist_p = StateSpaceModel(lin.mu0, lin.cholP0, np.clip(lin.A, *self.clip), np.clip(lin.b, *self.clip), lin.cholQ)
@@ -158,12 +159,15 @@ class CVISitesSDE(CVISitesSSM):
     def grad_kl_wrt_exp_param(self):
         q = self.dist_q
         mu, cov = q.marginals
-        if not hasattr(self.sde, "cubic"):
-            # non-polynomial drifts: central differences of the reference's quadrature KL stand in for its GradientTape
+        qm = np.asarray(self.sde.q)
+        if not hasattr(self.sde, "cubic") or np.abs(qm - np.diag(np.diag(qm))).max() > 0.0:
+            # non-polynomial / coupled drifts, full diffusion matrices: fourth-order difference quotients of the reference's quadrature
+            # KL stand in for its GradientTape
             sub = q.subsequent_covariances(cov)
             eta_d = cov + mu[..., :, None] * mu[..., None, :]
             eta_s = sub + mu[1:, :, None] * mu[:-1, None, :]
-            return self._np_sde.sde_ssm_kl_grads_fd(mu, eta_d, eta_s, self.sde, self.dt, self.init_mu, self.init_cov)
+            return self._np_sde.sde_ssm_kl_grads_fd(mu, eta_d, eta_s, self.sde, self.dt, self.init_mu, self.init_cov, eps=2e-4,
+                                                    richardson=True)
         alpha, beta = self.sde.cubic(self.dt)
         _, grads = self._np_sde.sde_ssm_kl_closed_form(mu, cov, q.subsequent_covariances(cov), alpha, beta, np.diag(self.sde.q),
                                                        self.dt, self.init_mu, self.init_cov)

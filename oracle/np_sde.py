@@ -206,12 +206,24 @@ def linear_drift_to_ssm(A, b, q, transition_times, initial_mean, initial_chol_co
     return StateSpaceModel(initial_mean, initial_chol_covariance, At, bt, cholQ)
 
 
-def linearize_sde(sde, transition_times, path_mu, path_cov, init_mu, init_cov, closed_form=False):
+def linearize_sde(sde, transition_times, path_mu, path_cov, init_mu, init_cov, closed_form=False, exact_q=False):
     """
     sde_utils.py:119-179.  path_mu [N, D], path_cov [N, D, D] (N = num transitions).
     A_i = E[f'] (as diag for D > 1), b_i = E[f] - A_i E[x]; then LinearDrift.to_ssm.
     closed_form: the two expectations from the cubic's Gaussian moments instead of the 10^D-point quadrature.
+    exact_q: the process noise of the linearised prior is  chol_q chol_q^T = q  instead of the reference's  chol_q @ chol_q
+    (sde_utils.py:173, no transpose).  The two agree for a diagonal q -- everything the reference ever runs --; for a full matrix the
+    reference's product is not even symmetric, so a full q is only meaningful with this flag (the build under test uses q).
     """
+    if exact_q:
+        class _Sym:                                           # the same SDE with diffusion() @ diffusion() == q
+            def __getattr__(self, name):
+                return getattr(sde, name)
+
+            def diffusion(self, x, t=None):
+                w, v = np.linalg.eigh(np.asarray(sde.q, dtype=np.float64))
+                return np.ones_like(x[..., None]) * ((v * np.sqrt(w)) @ v.T)
+        return linearize_sde(_Sym(), transition_times, path_mu, path_cov, init_mu, init_cov, closed_form=closed_form)
     N, D = path_mu.shape
     if hasattr(sde, "jacobian_drift"):
         # drifts that couple the dimensions: E[f'] is the full Jacobian [N, D, D] (sde.py:500-518 with batch_jacobian, :484-498)
@@ -272,27 +284,35 @@ def sde_ssm_kl_from_expectations(eta1, eta_d, eta_s, sde, dt, init_mu, init_cov,
     return kl + gauss_kl(mu0, cholP0 @ cholP0.T, init_mu, init_cov)
 
 
-def sde_ssm_kl_grads_fd(eta1, eta_d, eta_s, sde, dt, init_mu, init_cov, eps=1e-6, H=20):
+def sde_ssm_kl_grads_fd(eta1, eta_d, eta_s, sde, dt, init_mu, init_cov, eps=1e-6, H=20, richardson=False):
     """
     Central finite differences standing in for the reference's GradientTape (sde_utils.py:496-545).  Symmetric
     perturbations are used for eta_d so the result is the gradient with respect to the symmetric block.
+    richardson: fourth-order quotient (4 D(eps / 2) - D(eps)) / 3 -- with eps ~ 1e-4 the result is good to ~1e-10 of the gradient's
+    scale for a smooth drift (a ReLU drift keeps O(eps) kinks wherever a quadrature node crosses a unit's threshold).
     """
     f = lambda a, b_, c: sde_ssm_kl_from_expectations(a, b_, c, sde, dt, init_mu, init_cov, H)
+
+    def quot(up, dn, h):
+        d1 = (up(h) - dn(h)) / (2 * h)
+        if not richardson:
+            return d1
+        return (4.0 * (up(h / 2) - dn(h / 2)) / h - d1) / 3.0
     g1, gd, gs = np.zeros_like(eta1), np.zeros_like(eta_d), np.zeros_like(eta_s)
     for idx in np.ndindex(eta1.shape):
-        e = np.zeros_like(eta1); e[idx] = eps
-        g1[idx] = (f(eta1 + e, eta_d, eta_s) - f(eta1 - e, eta_d, eta_s)) / (2 * eps)
+        e = np.zeros_like(eta1); e[idx] = 1.0
+        g1[idx] = quot(lambda h: f(eta1 + h * e, eta_d, eta_s), lambda h: f(eta1 - h * e, eta_d, eta_s), eps)
     for idx in np.ndindex(eta_d.shape):
         t, i, j = idx
         if j > i:
             continue
-        e = np.zeros_like(eta_d); e[t, i, j] = eps; e[t, j, i] = eps
-        v = (f(eta1, eta_d + e, eta_s) - f(eta1, eta_d - e, eta_s)) / (2 * eps)
+        e = np.zeros_like(eta_d); e[t, i, j] = 1.0; e[t, j, i] = 1.0
+        v = quot(lambda h: f(eta1, eta_d + h * e, eta_s), lambda h: f(eta1, eta_d - h * e, eta_s), eps)
         # d/d(sym entry): for i != j both mirrored entries move, so the per-entry gradient is half of it
         gd[t, i, j] = gd[t, j, i] = v if i == j else 0.5 * v
     for idx in np.ndindex(eta_s.shape):
-        e = np.zeros_like(eta_s); e[idx] = eps
-        gs[idx] = (f(eta1, eta_d, eta_s + e) - f(eta1, eta_d, eta_s - e)) / (2 * eps)
+        e = np.zeros_like(eta_s); e[idx] = 1.0
+        gs[idx] = quot(lambda h: f(eta1, eta_d, eta_s + h * e), lambda h: f(eta1, eta_d, eta_s - h * e), eps)
     return g1, gd, gs
 
 

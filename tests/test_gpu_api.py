@@ -1997,12 +1997,16 @@ def test_cvi_classic_elbo_site_gradient_vanishes_at_optimum(amd, rng, kname):
         np.testing.assert_allclose(got, fd, rtol=1e-6 if kname == "m12" else 1e-4, atol=1e-8)
 
 
-@pytest.mark.parametrize("kind", ["vanderpol", "mlp"])
+@pytest.mark.parametrize("kind", ["vanderpol", "vanderpol_fullq", "mlp", "doublewell_fullq"])
 def test_cvi_sites_sde_coupled_drifts(amd, rng, kind):
-    """The drifts that couple the state dimensions / have no polynomial form (markovflow/sde/sde.py:359-518: VanderPolOscillatorSDE, MLPDrift)
-    through CVISitesSDEQuadrature -- the reference's Gauss-Hermite formulation with autograd for its GradientTape, sweeps in HIP --
-    against the oracle's restatement (quadrature KL, central differences for the tape): linearised prior, KL, its gradient with
-    respect to the expectation parameters, and the ELBO over damped data / Girsanov updates and a re-linearisation."""
+    """The drifts that couple the state dimensions / have no polynomial form (markovflow/sde/sde.py:359-518: VanderPolOscillatorSDE,
+    MLPDrift) and a NON-DIAGONAL diffusion matrix (sde_utils.py:262-359 takes the full Qp^{-1}), through CVISitesSDEQuadrature on the HIP
+    quadrature kernels (csrc/mfgm_quad.h: the reference's Gauss-Hermite rules with the tape's chain rule written out):
+      * against the batched-torch evaluation + autograd of the same formulas (VIDP_QUAD_TORCH=1's route): linearised prior, KL and its
+        gradient with respect to the expectation parameters, 1e-9;
+      * against the oracle's restatement: KL 1e-10, the gradient against a fourth-order difference quotient of the oracle's quadrature
+        KL -- 1e-8 relative (floor 1e-6 of the gradient's scale: that quotient's rounding noise) for the smooth drifts (a ReLU drift keeps O(step) kinks in any difference quotient: 2e-5 there) --, and the ELBO
+        over damped data / Girsanov updates and a re-linearisation."""
     import torch
     from oracle import np_sde
     from vidp_amd import sde as gsde
@@ -2010,38 +2014,60 @@ def test_cvi_sites_sde_coupled_drifts(amd, rng, kind):
     from vidp_amd.variational_cvi_sde import CVISitesSDEQuadrature
     T, dt = 16, 0.05
     grid = np.arange(T) * dt
-    if kind == "vanderpol":
+    if kind.startswith("vanderpol"):
         d = 2
-        o_sde, g_sde = np_sde.VanderPolSDE(1.3, 0.9, 0.5 * np.eye(2)), gsde.VanderPolOscillatorSDE(1.3, 0.9, torch.from_numpy(0.5 * np.eye(2)))
+        q = 0.5 * np.eye(2) if kind == "vanderpol" else np.array([[0.5, 0.12], [0.12, 0.4]])
+        o_sde, g_sde = np_sde.VanderPolSDE(1.3, 0.9, q), gsde.VanderPolOscillatorSDE(1.3, 0.9, torch.from_numpy(q))
+    elif kind == "doublewell_fullq":
+        d = 2
+        q = np.array([[0.8, -0.2], [-0.2, 0.6]])
+        o_sde, g_sde = np_sde.DoubleWellSDE(q, scale=2.0, c=0.7), gsde.DoubleWellSDE(torch.from_numpy(q), scale=2.0, c=0.7)
     else:
         d = 1
         w = (rng.normal(size=(1, 3)), 0.1 * rng.normal(size=3), rng.normal(size=(3, 1)), np.zeros(1))
         o_sde, g_sde = np_sde.MLPDriftSDE(w), gsde.MLPDrift(weights=[torch.from_numpy(np.asarray(x)) for x in w])
+    smooth = kind != "mlp"
     idx = np.array([3, 7, 12])
     y = rng.normal(size=(1, len(idx), d))
     cholR = 0.4 * np.eye(d)
     init = (np.zeros(d), 0.8 * np.eye(d))
-    g = CVISitesSDEQuadrature(g_sde, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)), prior_initial_state=init)
-    o = np_models.CVISitesSDE(o_sde, grid, idx, y[0], np_models.MultivariateGaussianLik(cholR), *init)
-    assert_close(host(g.dist_p.state_transitions)[0], o.dist_p.A, rtol=1e-9)
-    assert_close(host(g.dist_p.state_offsets)[0], o.dist_p.b, rtol=1e-9)
-    for m in (g, o):
+    mk = lambda: CVISitesSDEQuadrature(g_sde, grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)), prior_initial_state=init)
+    g, gt = mk(), mk()
+    assert g.native
+    gt.native = False
+    gt.set_linearized_prior()
+    # (exact_q: the linearised prior's process noise is q itself; the reference forms chol_q @ chol_q, sde_utils.py:173, which is q only
+    #  when q is diagonal -- oracle/np_sde.linearize_sde)
+    o = np_models.CVISitesSDE(o_sde, grid, idx, y[0], np_models.MultivariateGaussianLik(cholR), *init, exact_q=kind.endswith("fullq"))
+    for ref_A, ref_b, tol in ((host(gt.dist_p.state_transitions)[0], host(gt.dist_p.state_offsets)[0], 1e-12), (o.dist_p.A, o.dist_p.b, 1e-9)):
+        assert_close(host(g.dist_p.state_transitions)[0], ref_A, rtol=tol)
+        assert_close(host(g.dist_p.state_offsets)[0], ref_b, rtol=tol)
+    for m in (g, gt, o):
         m.update_data_sites(0.5)
-    np.testing.assert_allclose(float(g.KL_q_p()[0]), o.KL_q_p(), rtol=1e-8)
-    _, (g1, gd, gs) = g.grad_kl_wrt_exp_param()
-    o1, od, os_ = o.grad_kl_wrt_exp_param()
+    np.testing.assert_allclose(float(g.KL_q_p()[0]), o.KL_q_p(), rtol=1e-10)
+    np.testing.assert_allclose(float(g.KL_q_p()[0]), float(gt.KL_q_p()[0]), rtol=1e-12)
+    kl, (g1, gd, gs) = g.grad_kl_wrt_exp_param()
+    _, (t1, td, ts) = gt.grad_kl_wrt_exp_param()
     pl = g.plan
-    # (the oracle's gradient is a central difference with step 1e-6: 1e-5 is its own accuracy)
-    assert_close(host(pl.unpack(amd.VEC, g1))[0], o1, rtol=2e-5, scale_atol=2e-6)
-    assert_close(host(pl.unpack(amd.SYM, gd))[0], od, rtol=2e-5, scale_atol=2e-6)
-    assert_close(host(pl.unpack(amd.FULL, gs, T - 1))[0], os_, rtol=2e-5, scale_atol=2e-6)
+    un = lambda m_, a, b_, c: (host(m_.plan.unpack(amd.VEC, a))[0], host(m_.plan.unpack(amd.SYM, b_))[0], host(m_.plan.unpack(amd.FULL, c, T - 1))[0])
+    got, tape_ = un(g, g1, gd, gs), un(gt, t1, td, ts)
+    for a_, b_ in zip(got, tape_):
+        assert_close(a_, b_, rtol=1e-9, scale_atol=1e-10)
+    qo = o.dist_q
+    mu, cov = qo.marginals
+    sub = qo.subsequent_covariances(cov)
+    want = np_sde.sde_ssm_kl_grads_fd(mu, cov + mu[:, :, None] * mu[:, None, :], sub + mu[1:, :, None] * mu[:-1, None, :], o_sde, dt,
+                                      init[0], init[1], eps=2e-4, richardson=True)
+    for a_, b_ in zip(got, want):
+        # (absolute floor: the difference quotient's own rounding noise, eps |KL| / step, up to ~8e-7 here; a larger step trades it for truncation error: the KL's logdet / inverse terms have large high derivatives)
+        assert_close(a_, b_, rtol=1e-8 if smooth else 2e-5, scale_atol=1e-6 if smooth else 2e-6)
     for it in range(2):
         for m in (g, o):
             m.update_girsanov_sites(0.2)
             m.update_data_sites(0.4)
-        np.testing.assert_allclose(float(g.classic_elbo()), o.classic_elbo(), rtol=1e-5)
+        np.testing.assert_allclose(float(g.classic_elbo()), o.classic_elbo(), rtol=1e-7 if smooth else 1e-5)
         if it == 0:
             g.relinearize()
             o.relinearize()
-            np.testing.assert_allclose(float(g.classic_elbo()), o.classic_elbo(), rtol=1e-5)
+            np.testing.assert_allclose(float(g.classic_elbo()), o.classic_elbo(), rtol=1e-7 if smooth else 1e-5)
     g.plan.check_info()

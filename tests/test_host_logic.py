@@ -29,8 +29,21 @@ def test_sde_parameter_block():
     assert b.kind == 1 and b.params(0.02, np.zeros(1), np.eye(1)).theta[0] == 1.3
     with pytest.raises(NotImplementedError):
         b.cubic(0.02)
-    with pytest.raises(ValueError):     # non-diagonal diffusion for d > 1
-        sde.DoubleWellSDE(q=torch.tensor([[1.0, 0.2], [0.2, 1.0]], dtype=torch.float64))
+    full = sde.DoubleWellSDE(q=torch.tensor([[1.0, 0.2], [0.2, 1.0]], dtype=torch.float64))      # non-diagonal diffusion for d > 1
+    with pytest.raises(ValueError):     # ... is not for the closed-form kernels
+        full.params(0.01, np.zeros(2), np.eye(2))
+    qp = full.quad_params(0.01, np.array([0.1, -0.2]), np.eye(2), clip=(-1.0, 1.0))     # but for the quadrature kernels
+    Winv = np.linalg.inv(0.01 * np.array([[1.0, 0.2], [0.2, 1.0]]))
+    assert (qp.kind, qp.d) == (12, 2) and list(qp.theta)[:2] == [4.0, 4.0]
+    np.testing.assert_allclose([qp.W[0], qp.W[1], qp.W[2]], [Winv[0, 0], Winv[1, 0], Winv[1, 1]])
+    np.testing.assert_allclose(qp.logdetQp, np.linalg.slogdet(0.01 * np.array([[1.0, 0.2], [0.2, 1.0]]))[1])
+    vdp = sde.VanderPolOscillatorSDE(1.3, 0.9, trainable=True)
+    assert vdp.quad_params(0.05, np.zeros(2), np.eye(2)).kind == 10 and vdp.trainable_variables == ["a", "tau"]
+    mlp = sde.MLPDrift(seed=3)
+    th, nh = mlp.quad_theta()
+    assert nh == 3 and len(th) == 10 and mlp.quad_params(0.05, np.zeros(1), np.eye(1)).nh == 3
+    mlp.assign("weights", np.arange(10.0))
+    assert mlp.quad_theta()[0] == list(np.arange(10.0))
     with pytest.raises(ValueError):
         sde.SineDiffusionSDE(0.1, torch.eye(5, dtype=torch.float64))
 

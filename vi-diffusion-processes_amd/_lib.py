@@ -83,6 +83,10 @@ EXPORTS = {
     "mfgm_cq_slots": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mfgm_cq_factor": (ctypes.c_int, [ctypes.c_void_p] * 9),
     "mfgm_cq_factor_pipelined": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] + [ctypes.c_void_p] * 3),
+    "mfgm_quad_linearize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6),
+    "mfgm_quad_kl_scratch_doubles": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "mfgm_quad_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 11),
+    "mfgm_quad_esde": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 12),
     "mfgm_cq_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6),
     "mfgm_cq_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),
     "mfgm_cq_selinv_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11),
@@ -141,6 +145,17 @@ class CqState(ctypes.Structure):
     """mfgm_cq_state (include/mfgm.h)."""
     _fields_ = [("dyn", ctypes.c_void_p), ("d_off", ctypes.c_double), ("s_off", ctypes.c_double), ("p0_off", ctypes.c_void_p),
                 ("slot", ctypes.c_void_p), ("site_lin", ctypes.c_void_p), ("site_sym", ctypes.c_void_p)]
+
+
+QUAD_NTHETA = 40
+
+
+class QuadDrift(ctypes.Structure):
+    """mfgm_quad_drift (include/mfgm.h)."""
+    _fields_ = [("kind", ctypes.c_int), ("d", ctypes.c_int), ("nh", ctypes.c_int), ("pad_", ctypes.c_int),
+                ("theta", ctypes.c_double * QUAD_NTHETA), ("dt", ctypes.c_double), ("W", ctypes.c_double * 6),
+                ("logdetQp", ctypes.c_double), ("mu0", ctypes.c_double * 3), ("P0inv", ctypes.c_double * 6),
+                ("logdetP0", ctypes.c_double), ("clip_lo", ctypes.c_double), ("clip_hi", ctypes.c_double)]
 
 
 class SparseData(ctypes.Structure):

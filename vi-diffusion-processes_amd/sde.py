@@ -24,8 +24,9 @@ class SDE:
         self.q = q
         self.state_dim = q.shape[0]
         qd = torch.diagonal(q)
-        if self.state_dim > 1 and not torch.equal(torch.diag(qd), q.cpu() if q.is_cuda else q):
-            raise ValueError("the HIP path needs a diagonal diffusion matrix q for state_dim > 1")
+        # a full (non-diagonal) diffusion matrix is served by the tensor-product quadrature kernels (quad_params,
+        # variational_cvi_sde.CVISitesSDEQuadrature); the closed-form kernels (params) need a diagonal one
+        self.q_is_diagonal = bool(self.state_dim == 1 or torch.equal(torch.diag(qd), q.cpu() if q.is_cuda else q))
         self.q_diag = [float(v) for v in qd]
 
     def drift(self, x, t=None):
@@ -64,9 +65,50 @@ class SDE:
         """{parameter: (d af / d parameter, d bf / d parameter)} of f(x) = af x - bf x^3."""
         raise NotImplementedError
 
+    # -- the tensor-product quadrature kernels (csrc/mfgm_quad.h): coupled / non-polynomial drifts, full diffusion matrices ------------
+    quad_kind = 12      # per-dimension cubic f = af x - bf x^3
+
+    def quad_theta(self):
+        """Drift parameters as the quadrature kernels take them (mfgm_quad_drift.theta) and the hidden width (kind 11)."""
+        return list(self.drift_cubic()), 0
+
+    def quad_param_jacobian(self):
+        """{trainable parameter: [d theta_k / d parameter]}: how the kernels' parameter gradient maps onto `trainable_variables`."""
+        jac = self.drift_cubic_jacobian()
+        return {n: list(jac[n]) for n in self.trainable_variables}
+
+    def quad_params(self, dt, init_mu, init_cov, clip=None):
+        """Fill mfgm_quad_drift."""
+        d = self.state_dim
+        if d > 3:
+            raise ValueError("the quadrature kernels cover state dimensions up to 3 (20^d nodes per time step)")
+        th, nh = self.quad_theta()
+        if len(th) > _lib.QUAD_NTHETA:
+            raise ValueError("too many drift parameters for the quadrature kernels")
+        prm = _lib.QuadDrift()
+        prm.kind, prm.d, prm.nh, prm.dt = int(self.quad_kind), d, int(nh), float(dt)
+        for k, v in enumerate(th):
+            prm.theta[k] = float(v)
+        Qp = dt * self.q.cpu().numpy().astype(np.float64)
+        W = np.linalg.inv(Qp)
+        P0 = np.asarray(init_cov, dtype=np.float64).reshape(d, d)
+        P0inv = np.linalg.inv(P0)
+        for i in range(d):
+            prm.mu0[i] = float(np.asarray(init_mu).reshape(-1)[i])
+            for j in range(i + 1):
+                prm.W[i * (i + 1) // 2 + j] = 0.5 * (W[i, j] + W[j, i])
+                prm.P0inv[i * (i + 1) // 2 + j] = P0inv[i, j]
+        prm.logdetQp = float(np.linalg.slogdet(Qp)[1])
+        prm.logdetP0 = float(np.linalg.slogdet(P0)[1])
+        prm.clip_lo, prm.clip_hi = (1.0, 0.0) if clip is None else (float(clip[0]), float(clip[1]))
+        return prm
+
     def params(self, dt, init_mu, init_cov, lr=0.0, clip=None):
         """Fill the C parameter block (mfgm_sde_params)."""
         d = self.state_dim
+        if not self.q_is_diagonal:
+            raise ValueError("the closed-form HIP kernels need a diagonal diffusion matrix q for state_dim > 1: a full q runs on the "
+                             "quadrature kernels (CVISitesSDEQuadrature, VariationalMarkovGP with d <= 3)")
         al, be = self.cubic(dt) if self.kind == 0 else (1.0, 0.0)
         prm = _lib.SdeParams()
         prm.kind, prm.dt = int(self.kind), float(dt)
@@ -277,6 +319,14 @@ class VanderPolOscillatorSDE(QuadratureSDE):
         self.a, self.tau = float(a), float(tau)
         self._trainable = {"a": bool(trainable), "tau": bool(trainable)}
 
+    quad_kind = 10
+
+    def quad_theta(self):
+        return [self.a, self.tau], 0
+
+    def quad_param_jacobian(self):
+        return {n: [1.0 if n == "a" else 0.0, 1.0 if n == "tau" else 0.0] for n in self.trainable_variables}
+
     def drift(self, x, t=None):
         x1, x2 = x[..., 0], x[..., 1]
         return self.tau * torch.stack([self.a * (x1 - x1 ** 3 / 3.0 - x2), x1 / self.a], dim=-1)
@@ -303,6 +353,29 @@ class MLPDrift(QuadratureSDE):
             weights = (torch.randn((1, 3), generator=g, dtype=torch.float64), torch.zeros(3, dtype=torch.float64),
                        torch.randn((3, 1), generator=g, dtype=torch.float64), torch.zeros(1, dtype=torch.float64))
         self.weights = tuple(torch.as_tensor(w, dtype=torch.float64) for w in weights)
+        self._trainable_weights = False
+
+    quad_kind = 11
+
+    def quad_theta(self):
+        W1, b1, W2, b2 = self.weights
+        return [float(v) for v in torch.cat([W1.reshape(-1), b1.reshape(-1), W2.reshape(-1), b2.reshape(-1)])], int(b1.numel())
+
+    # the network's weights as ONE trainable vector "weights" (the reference trains MLP.trainable_variables, sde.py:375-381)
+    @property
+    def trainable_variables(self):
+        return ["weights"] if self._trainable_weights else []
+
+    def get(self, name):
+        return np.array(self.quad_theta()[0])
+
+    def assign(self, name, value):
+        v = torch.as_tensor(np.asarray(value, dtype=np.float64))
+        nh = int(self.weights[1].numel())
+        self.weights = (v[:nh].reshape(1, nh).clone(), v[nh:2 * nh].clone(), v[2 * nh:3 * nh].reshape(nh, 1).clone(), v[3 * nh:3 * nh + 1].clone())
+
+    def quad_param_jacobian(self):
+        return {"weights": None}         # the kernels' parameter gradient IS the gradient of the weight vector
 
     def drift(self, x, t=None):
         W1, b1, W2, b2 = (w.to(x.device) for w in self.weights)

@@ -13,6 +13,7 @@ Same method names as the reference (`full_sites`, `dist_q`, `update_data_sites`,
 import math
 import os
 
+import numpy as np
 import torch
 
 from ._lib import FULL, SYM, VEC
@@ -927,8 +928,21 @@ class CVISitesSDEQuadrature(CVISitesSSM):
         self.stabilize_ssm, self.clip_state_transitions = stabilize_ssm, clip_state_transitions
         super().__init__(None, time_grid, input_data, likelihood, prior_initial_state=prior_initial_state,
                          initial_posterior_path=initial_posterior_path, plan=plan)
+        # the local quantities on the HIP quadrature kernels (csrc/mfgm_quad.h; drifts with a `quad_kind`, d <= 3); VIDP_QUAD_TORCH=1
+        # keeps the batched torch evaluation + autograd of round 3, which the tests hold the kernels to
+        self.native = (os.environ.get("VIDP_QUAD_TORCH", "0") != "1" and getattr(prior_sde, "quad_kind", None) is not None
+                       and self.state_dim <= 3)
         self.dist_p_linearized = None
         self.set_linearized_prior()
+
+    def _quad_prm(self, clip=None):
+        return self.prior_sde.quad_params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1], clip=clip)
+
+    def _refresh_sde_params(self):
+        """The drift parameters moved (trainers call this after every optimiser step): nothing is cached on this route."""
+
+    def set_prior_initial_state(self, mean, cov):
+        self.prior_initial_state = (mean, cov)
 
     # -- linearisation ------------------------------------------------------------------------------------------------------------
     def _path_natural(self):
@@ -950,13 +964,23 @@ class CVISitesSDEQuadrature(CVISitesSSM):
         sde, d, dt = self.prior_sde, self.state_dim, self.dt
         mu, cov = self._path_natural()
         # transition k is linearised on the marginal at k + 1, as the reference hands `fx_mus[1:]` to linearize_sde (:412)
-        m, chol = mu[:, 1:], linalg.cholesky(cov[:, 1:].contiguous())
-        with torch.no_grad():
-            Ef = sde.expected_drift(m, chol)
-            J = sde.expected_gradient_drift(m, chol)
-        eye = torch.eye(d, dtype=torch.float64, device=self.device)
-        A = eye + dt * J
-        b = dt * (Ef - (J @ m[..., None])[..., 0])
+        m = mu[:, 1:]
+        if self.native:
+            from . import quad
+            A, b = quad.linearize(self._quad_prm(), m, cov[:, 1:])
+        else:
+            chol = linalg.cholesky(cov[:, 1:].contiguous())
+            from .sde import mvnquad
+            with torch.no_grad():
+                if hasattr(sde, "expected_drift"):
+                    Ef = sde.expected_drift(m, chol)
+                    J = sde.expected_gradient_drift(m, chol)
+                else:       # per-dimension drifts (here for their full diffusion matrix): the same 10-point rule, diagonal Jacobian
+                    Ef = mvnquad(lambda x: sde.drift(x), m, chol, 10, (d,))
+                    J = torch.diag_embed(mvnquad(lambda x: sde.gradient_drift(x), m, chol, 10, (d,)))
+            eye = torch.eye(d, dtype=torch.float64, device=self.device)
+            A = eye + dt * J
+            b = dt * (Ef - (J @ m[..., None])[..., 0])
         cholQ = linalg.cholesky((dt * sde.q).to(self.device)).expand(self.B, self.T - 1, d, d).contiguous()
         mu0 = torch.as_tensor(self.prior_initial_state[0], dtype=torch.float64, device=self.device).expand(self.B, d).contiguous()
         cholP0 = linalg.cholesky(torch.as_tensor(self.prior_initial_state[1], dtype=torch.float64, device=self.device))
@@ -1011,13 +1035,94 @@ class CVISitesSDEQuadrature(CVISitesSSM):
         mu, cov, sub = pl.unpack(VEC, q["mu"]), pl.unpack(SYM, q["Sig"]), pl.unpack(FULL, q["Sub"], T - 1)
         return mu, cov + mu[..., :, None] * mu[..., None, :], sub + mu[:, 1:, :, None] * mu[:, :-1, None, :]
 
+    def _marginals_natural(self):
+        pl, T = self.plan, self.T
+        q = self._refresh(want_sub=True, want_marginals=True)
+        return pl.unpack(VEC, q["mu"]), pl.unpack(SYM, q["Sig"]), pl.unpack(FULL, q["Sub"], T - 1)
+
     def KL_q_p(self):
+        if self.native:
+            from . import quad
+            return quad.kl(self._quad_prm(), *self._marginals_natural())
         with torch.no_grad():
             return self._kl_from_expectations(*self._expectations_natural())
+
+    def grad_KL_wrt_prior_params(self):
+        """d KL[q || p_SDE] / d (trainable drift parameters), summed over the trajectories, in `trainable_variables` order
+        (variational_cvi_sde.py:495-506); a parameter that is a vector (the network's weights) gets a vector."""
+        from . import quad
+        sde = self.prior_sde
+        _, gth = quad.kl(self._quad_prm(), *self._marginals_natural(), param_grad=True)
+        g = gth.sum(0).cpu().numpy()
+        out = []
+        for n, jac in sde.quad_param_jacobian().items():
+            out.append(g.copy() if jac is None else float(sum(gk * jk for gk, jk in zip(g, jac))))
+        return out
+
+    def grad_VE_wrt_prior_params(self, rel_step=1e-4):
+        """d(-E_q log p(Y | X)) / d (trainable drift parameters) with q = prior re-linearised on the current path + sites
+        (variational_cvi_sde.py:508-518), as CVISitesSDE.grad_VE_wrt_prior_params: ONE exact Fisher-vector product F_q g serves every
+        parameter, contracted with d theta_p / d kappa of the local linearisation map on the fixed path (a fourth-order central
+        difference of the quadrature kernel's linearisation; the map is smooth in the drift parameters)."""
+        from . import quad, tape
+        sde, pl = self.prior_sde, self.plan
+        T, d, B = self.T, self.state_dim, self.B
+        mu0, cov0 = self._path_natural()
+        path = (pl.pack(VEC, mu0.reshape(B, T, d).contiguous()), pl.pack(SYM, cov0.reshape(B, T, d, d).contiguous()))
+        self._path, self._q = path, None
+        self.set_linearized_prior()
+        self._path = path
+        mu, cov, csub = self._marginals_natural()
+        tq = self.full_sites()
+        diag, sub = pl.unpack(SYM, tq.diag), pl.unpack(FULL, tq.sub, T - 1)
+        mu_o, cov_o = self._obs_marginals()
+        g1, g2 = self.likelihood.ve_gradients_expectation(mu_o, cov_o, self._obs_flat())
+        g_lin = torch.zeros((B * T, d), dtype=torch.float64, device=self.device).index_add_(0, self.obs_node_ids, g1.reshape(-1, d))
+        g_diag = torch.zeros((B * T, d, d), dtype=torch.float64, device=self.device).index_add_(0, self.obs_node_ids, g2.reshape(-1, d, d))
+        u = tape.fisher_vector_product(pl, diag, sub, mu, cov, csub, g_lin.view(B, T, d), g_diag.view(B, T, d, d), torch.zeros_like(sub))
+
+        def prior_nat():
+            clip = self.clip_state_transitions if self.stabilize_ssm else None
+            A, b = quad.linearize(self._quad_prm(clip=clip), mu0[:, 1:], cov0[:, 1:])
+            ssm = StateSpaceModel(self.dist_p.initial_mean, self.dist_p.cholesky_initial_covariance, A, b,
+                                  self.dist_p.cholesky_process_covariances, plan=pl)
+            nat = pl.ssm_to_naturals(ssm.packed.A, ssm.packed.off, ssm.packed.chol)
+            return pl.unpack(VEC, nat["lin"]), pl.unpack(SYM, nat["diag"]), pl.unpack(FULL, nat["sub"], T - 1)
+
+        def directional(assign, h):
+            vals = {}
+            for k in (-2, -1, 1, 2):
+                assign(k * h)
+                vals[k] = prior_nat()
+            assign(0.0)
+            return [(8.0 * (a1 - b1) - (a2 - b2)) / (12.0 * h) for a1, b1, a2, b2 in zip(vals[1], vals[-1], vals[2], vals[-2])]
+
+        grads = []
+        for n in sde.trainable_variables:
+            v0 = sde.get(n)
+            if isinstance(v0, float):
+                dth = directional(lambda e: sde.assign(n, v0 + e), rel_step * max(abs(v0), 1.0))
+                grads.append(-float(sum((a * w).sum() for a, w in zip(dth, u))))
+            else:
+                comp = []
+                for k in range(len(v0)):
+                    def assign(e, k=k):
+                        v = v0.copy()
+                        v[k] += e
+                        sde.assign(n, v)
+                    dth = directional(assign, rel_step * max(abs(float(v0[k])), 1.0))
+                    comp.append(-float(sum((a * w).sum() for a, w in zip(dth, u))))
+                grads.append(np.array(comp))
+        self._q = None
+        return grads
 
     def grad_kl_wrt_exp_param(self):
         """(KL [B], (d/d eta_lin, d/d eta_diag, d/d eta_sub) packed) (variational_cvi_sde.py:488-493)."""
         pl = self.plan
+        if self.native:
+            from . import quad
+            kl, (g1, gd, gs) = quad.kl(self._quad_prm(), *self._marginals_natural(), grad=True)
+            return kl, (pl.pack(VEC, g1), pl.pack(SYM, gd), pl.pack(FULL, gs))
         eta = [e.detach().requires_grad_(True) for e in self._expectations_natural()]
         kl = self._kl_from_expectations(*eta)
         g1, gd, gs = torch.autograd.grad(kl.sum(), eta)
