@@ -348,6 +348,12 @@ int mfgm_quad_kl(const mfgm_quad_drift* drift, int B, int T, const double* mu, c
 int mfgm_quad_esde(const mfgm_quad_drift* drift, int N, const double* mean, const double* cov, const double* A, const double* b, double* E,
                    double* dEdm, double* dEdS, double* dEdA, double* dEdb, double* gtheta, int* info, void* stream);
 
+/* VDP Lagrange sweep with jump conditions (vi_sde.py:289-347) on natural-layout arrays, d <= 3: A, dEdS, psi [B, N, d, d], dEdm, lam
+ * [B, N, d], dobsm [B, N + 1, d], dobsS [B, N + 1, d, d] (the likelihood's gradients scattered on the grid); clip > 0: stabilize_system
+ * (NaN -> 1e-8, clipping to [-clip, clip] of the four gradient arrays).  The reference's loop, sequential per chain. */
+int mfgm_quad_vdp_lagrange(int B, int N, int d, double dt, double clip, const double* A, const double* dEdm, const double* dEdS,
+                           const double* dobsm, const double* dobsS, double* psi, double* lam, void* stream);
+
 /* ---- Kalman filter with Gaussian sites and a time-invariant emission matrix (kalman_filter.py:86-107, 184-271, 417-500) ----------------
  * The path of KalmanFilterWithSites.log_likelihood / CVIGaussianProcess.elbo and of predict_f at the data points
  * (variational_cvi.py:106-135, 351-379): sites nat1 [Bs, T, o], nat2 [Bs, T, o, o] in natural layout (Bs = 1: shared by all chains,

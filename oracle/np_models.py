@@ -289,7 +289,18 @@ class VariationalMarkovGP:
             return self._np_sde.e_sde_closed_form(af, bf, np.diag(self.sde.q), -self.A, self.b, m, S, self.dt, want_grads=False)
         return self._np_sde.squared_drift_difference_along_gaussian_path(self.sde, -self.A, self.b, m, S, self.dt)
 
+    def _general(self):
+        """A drift the per-dimension cubic closed forms do not cover (coupled / network drifts) or a full diffusion matrix."""
+        q = np.asarray(self.sde.q)
+        return hasattr(self.sde, "jacobian_drift") or hasattr(self.sde, "weights") or np.abs(q - np.diag(np.diag(q))).max() > 0.0
+
     def _grad_E_sde(self, m, S):
+        if self._general():
+            # fourth-order difference quotients of the reference's quadrature stand in for its GradientTape (vi_sde.py:205-243)
+            if hasattr(self.sde, "hessian_drift"):
+                # a polynomial drift: exact through the Gaussian identities (np_sde.e_sde_grads_stein)
+                return self._np_sde.e_sde_grads_stein(self.sde, -self.A, self.b, m[:-1], S[:-1])
+            return self._np_sde.e_sde_grads_fd(self.sde, -self.A, self.b, m[:-1], S[:-1])
         af, bf = self._np_sde.drift_cubic(self.sde)
         _, dm, dS = self._np_sde.e_sde_closed_form(af, bf, np.diag(self.sde.q), -self.A, self.b, m[:-1], S[:-1], self.dt)
         return dm / self.dt, dS / self.dt
@@ -328,9 +339,15 @@ class VariationalMarkovGP:
             Ef, Jf = self._np_sde.expected_drift_closed_form(self.sde, m, S)
             Egrad = -Jf
         else:
-            Egrad = -self.sde.expected_gradient_drift(m[None], S[None])[0]
             Ef = self.sde.expected_drift(m[None], S[None])[0]
-        A_tilde = Egrad[:, :, None] * np.eye(self.d) + 2.0 * q[None] @ self.psi
+            if not hasattr(self.sde, "jacobian_drift"):
+                Egrad = -self.sde.expected_gradient_drift(m[None], S[None])[0]
+        if hasattr(self.sde, "jacobian_drift"):
+            # drifts that couple the dimensions: the full expected Jacobian (sde.py:484-518)
+            Egrad = -self._np_sde.mvnquad(lambda x: self.sde.jacobian_drift(x), m, S, 10, self.d, (self.d, self.d))
+            A_tilde = Egrad + 2.0 * q[None] @ self.psi
+        else:
+            A_tilde = Egrad[:, :, None] * np.eye(self.d) + 2.0 * q[None] @ self.psi
         b_tilde = Ef + (A_tilde @ m[..., None])[..., 0] - (q[None] @ self.lam[..., None])[..., 0]
         self.A = (1 - lr) * self.A + lr * A_tilde
         self.b = (1 - lr) * self.b + lr * b_tilde

@@ -179,6 +179,16 @@ class VanderPolSDE(SDE):
         return self.tau * np.stack([np.stack([self.a * (1.0 - x1 * x1), -self.a * one], axis=-1), np.stack([one / self.a, zero], axis=-1)], axis=-2)
 
 
+def _vanderpol_hessian(self, x, t=None):
+    """d^2 f_k / dx_i dx_j [..., k, i, j]: only f_1 = tau a (x1 - x1^3 / 3 - x2) is non-linear."""
+    H = np.zeros(x.shape[:-1] + (2, 2, 2))
+    H[..., 0, 0, 0] = -2.0 * self.tau * self.a * x[..., 0]
+    return H
+
+
+VanderPolSDE.hessian_drift = _vanderpol_hessian
+
+
 class MLPDriftSDE(SDE):
     """sde.py:359-429: the one-dimensional 1 -> 3 -> 1 ReLU network drift, weights (W1 [1,3], b1 [3], W2 [3,1], b2 [1]) given."""
 
@@ -389,6 +399,66 @@ def squared_drift_difference_along_gaussian_path(sde, A, b, m, S, dt, H=20):
 
     val = mvnquad(func, m, S, H, D)
     return 0.5 * np.sum(val) * dt
+
+
+def squared_drift_difference_terms(sde, A, b, m, S, H=20):
+    """The per-node terms of squared_drift_difference_along_gaussian_path WITHOUT the Riemann factor dt: [N]."""
+    N, D = m.shape
+    qinv = np.linalg.inv(sde.q)
+
+    def func(x):
+        x = x.reshape(-1, N, D)
+        tmp = ((A[None] @ x[..., None])[..., 0] + b[None]) - sde.drift(x)
+        return np.einsum("pni,ij,pnj->pn", tmp, qinv, tmp).reshape(-1)
+
+    return 0.5 * mvnquad(func, m, S, H, D)
+
+
+def e_sde_grads_fd(sde, A, b, m, S, eps=2e-4):
+    """d E_sde / d (m, S) per node without the factor dt (what vi_sde.py:205-243 tapes and divides by dt), by fourth-order difference
+    quotients of the reference's quadrature.  E_sde is a SUM of per-node terms, each a function of its own (m_t, S_t): one perturbed
+    evaluation moves the same entry of every node at once."""
+    N, D = m.shape
+    f = lambda mm, SS: squared_drift_difference_terms(sde, A, b, mm, SS)
+
+    def quot(up, dn):
+        d1 = (up(eps) - dn(eps)) / (2 * eps)
+        return (4.0 * (up(eps / 2) - dn(eps / 2)) / eps - d1) / 3.0
+    dm, dS = np.zeros_like(m), np.zeros_like(S)
+    for i in range(D):
+        e = np.zeros(D); e[i] = 1.0
+        dm[:, i] = quot(lambda h: f(m + h * e, S), lambda h: f(m - h * e, S))
+        for j in range(i + 1):
+            E = np.zeros((D, D)); E[i, j] = 1.0; E[j, i] = 1.0
+            v = quot(lambda h: f(m, S + h * E), lambda h: f(m, S - h * E))
+            dS[:, i, j] = dS[:, j, i] = v if i == j else 0.5 * v
+    return dm, dS
+
+
+def e_sde_grads_stein(sde, A, b, m, S, H=20):
+    """d E_sde / d (m, S) per node without the factor dt, EXACT for a polynomial drift: with h(x) = 1/2 |f(x) - f_L(x)|^2_{q^-1},
+    d/dm E h = E grad h and d/dS E h = 1/2 E hess h (Gaussian identities), both polynomials of degree <= 6 for the Van der Pol drift,
+    which the 20-point rule integrates exactly.  (A, b) are the LINEAR DRIFT's parameters, as in squared_drift_difference_along_gaussian_path.)"""
+    N, D = m.shape
+    qinv = np.linalg.inv(sde.q)
+
+    def parts(x):
+        x = x.reshape(-1, N, D)
+        r = sde.drift(x) - ((A[None] @ x[..., None])[..., 0] + b[None])            # f - f_L
+        G = sde.jacobian_drift(x) - A[None]                                        # d r / d x
+        qr = r @ qinv
+        return x, G, qr
+
+    def grad(x):
+        x, G, qr = parts(x)
+        return np.einsum("pnki,pnk->pni", G, qr).reshape(-1, D)
+
+    def hess(x):
+        x, G, qr = parts(x)
+        Hf = sde.hessian_drift(x)
+        return (np.einsum("pnki,kl,pnlj->pnij", G, qinv, G) + np.einsum("pnk,pnkij->pnij", qr, Hf)).reshape(-1, D, D)
+
+    return mvnquad(grad, m, S, H, D, (D,)), 0.5 * mvnquad(hess, m, S, H, D, (D, D))
 
 
 def drift_cubic(sde):

@@ -1081,6 +1081,72 @@ def test_cvi_sites_sde_quadrature_drifts(amd, rng, kind):
     np.testing.assert_allclose(host(g.classic_elbo_per_trajectory())[0], o.classic_elbo(), rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("kind", ["vanderpol", "vanderpol_fullq", "mlp"])
+def test_variational_markov_gp_quadrature_drifts(amd, rng, kind):
+    """VDP with the drifts the closed-form kernels do not cover and with a full diffusion matrix (the reference's VariationalMarkovGP
+    takes any SDE: vi_sde.py:377-414, 422-434): VariationalMarkovGPQuadrature on the HIP quadrature kernels against the oracle's
+    restatement of the reference loop -- forward pass, E_sde and its gradients (oracle: exact for the polynomial drift, fourth-order quotients of its quadrature for the network), the
+    Lagrange sweep, parameter / initial-state updates and the ELBO over a few iterations; and the drift-parameter gradient against a
+    difference quotient of E_sde."""
+    import torch
+    from oracle import np_sde
+    from vidp_amd import sde as gsde
+    from vidp_amd.likelihoods import MultivariateGaussian
+    from vidp_amd.vi_sde import VariationalMarkovGPQuadrature
+    T, dt = 30, 0.02
+    grid = np.arange(T) * dt
+    if kind.startswith("vanderpol"):
+        d = 2
+        q = 0.5 * np.eye(2) if kind == "vanderpol" else np.array([[0.5, 0.12], [0.12, 0.4]])
+        o_sde, g_sde = np_sde.VanderPolSDE(1.3, 0.9, q), gsde.VanderPolOscillatorSDE(1.3, 0.9, torch.from_numpy(q), trainable=True)
+    else:
+        d = 1
+        w = (rng.normal(size=(1, 3)), 0.1 * rng.normal(size=3), rng.normal(size=(3, 1)), np.zeros(1))
+        o_sde, g_sde = np_sde.MLPDriftSDE(w), gsde.MLPDrift(weights=[torch.from_numpy(np.asarray(x)) for x in w])
+    smooth = kind != "mlp"
+    idx = np.arange(4, T - 1, 6)
+    y = rng.normal(size=(1, len(idx), d))
+    cholR = 0.5 * np.eye(d)
+    init = (np.zeros(d), 0.6 * np.eye(d))
+    g = VariationalMarkovGPQuadrature((grid[idx], dev(y)), g_sde, grid, MultivariateGaussian(dev(cholR)), prior_initial_state=init)
+    o = np_models.VariationalMarkovGP(idx, y[0], o_sde, grid, np_models.MultivariateGaussianLik(cholR), *init)
+    # (Van der Pol: the oracle's gradient is exact -- Gaussian identities on a polynomial drift; the network drift's is a difference quotient)
+    tol = dict(rtol=1e-8 if smooth else 2e-5, scale_atol=1e-9 if smooth else 2e-6)
+    for it in range(4):
+        mS = g._forward_packed()
+        m, S = o.forward_pass()
+        gm, gS = g._natural(mS)
+        assert_close(host(gm)[0], m, rtol=1e-9)
+        assert_close(host(gS)[0], S, rtol=1e-9)
+        np.testing.assert_allclose(float(g.E_sde(mS)[0]), o.E_sde(m[:-1], S[:-1]), rtol=1e-10)
+        dm, dS = g._grad_E_sde(mS)
+        odm, odS = o._grad_E_sde(m, S)
+        assert_close(host(dm)[0], odm, **tol)
+        assert_close(host(dS)[0], odS, **tol)
+        g.update_lagrange(mS)
+        o.update_lagrange(m, S)
+        assert_close(host(g.psi_lagrange)[0], o.psi, **tol)
+        assert_close(host(g.lambda_lagrange)[0], o.lam, **tol)
+        g.update_param(mS, lr=0.1)
+        o.update_param(m, S, 0.1)
+        assert_close(host(g.A)[0], o.A, **tol)
+        assert_close(host(g.b)[0], o.b, **tol)
+        if it > 1:
+            g.update_initial_statistics(0.1)
+            o.update_initial_statistics(0.1)
+        np.testing.assert_allclose(float(g.elbo()), o.elbo(), rtol=1e-8 if smooth else 1e-4)
+    if kind.startswith("vanderpol"):
+        # d E_sde / d (a, tau) on the path m[1:], S[1:] (vi_sde.py:457-470) against a fourth-order quotient of the oracle's E_sde
+        got = g.grad_prior_sde_params()
+        m, S = o.forward_pass()
+
+        def e_at(a, tau):
+            return np_sde.squared_drift_difference_along_gaussian_path(np_sde.VanderPolSDE(a, tau, q), -o.A, o.b, m[1:], S[1:], dt)
+        h = 1e-3
+        fd = lambda f: (8 * (f(h) - f(-h)) - (f(2 * h) - f(-2 * h))) / (12 * h)
+        np.testing.assert_allclose(got, [fd(lambda e: e_at(1.3 + e, 0.9)), fd(lambda e: e_at(1.3, 0.9 + e))], rtol=1e-7)
+
+
 def test_variational_markov_gp_stabilized(amd, rng):
     """stabilize_system (vi_sde.py:186-200, 312-323, 393-397): with a step size and observation precision at which the plain
     fixed-point iteration leaves the clipping ranges, the clipped / NaN-scrubbed iteration follows the oracle's."""

@@ -86,6 +86,7 @@ EXPORTS = {
     "mfgm_quad_linearize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6),
     "mfgm_quad_kl_scratch_doubles": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "mfgm_quad_kl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 11),
+    "mfgm_quad_vdp_lagrange": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_double] * 2 + [ctypes.c_void_p] * 8),
     "mfgm_quad_esde": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 12),
     "mfgm_cq_factor_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6),
     "mfgm_cq_selinv_girsanov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7),

@@ -73,4 +73,13 @@ int mfgm_quad_esde(const mfgm_quad_drift* drift, int N, const double* mean, cons
     return 0;
 }
 
+int mfgm_quad_vdp_lagrange(int B, int N, int d, double dt, double clip, const double* A, const double* dEdm, const double* dEdS,
+                           const double* dobsm, const double* dobsS, double* psi, double* lam, void* stream) {
+    if (B < 1 || N < 1 || d < 1 || d > kQD || !A || !dEdm || !dEdS || !dobsm || !dobsS || !psi || !lam) return 1;
+    hipLaunchKernelGGL(k_quad_vdp_lagrange, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, N, d, dt, clip, A, dEdm, dEdS, dobsm,
+                       dobsS, psi, lam);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // extern "C"

@@ -523,4 +523,45 @@ static __global__ void k_quad_esde(mfgm_quad_drift q, int N, const double* __res
         for (int p = 0; p < np; ++p) gtheta[(size_t)n * np + p] = gth[p];
 }
 
+// ---- VDP: the Lagrange sweep with jump conditions (vi_sde.py:289-347), one thread per chain ---------------------------------------------
+// psi [B, N, d, d], lam [B, N, d] (N = transitions): row N - 1 is (1e-10 I, 0), then for t = N - 1 .. 1
+//   psi_{t-1} = psi_t - dt (psi_t A_t + psi_t A_t - dEdS_t) - dobsS_t,   lam_{t-1} = lam_t - dt (A_t lam_t - dEdm_t) - dobsm_t
+// exactly as the reference's loop writes it (`psi @ A + psi @ A`).  clip > 0: stabilize_system -- NaN -> 1e-8 and clipping to [-clip, clip]
+// of the four gradient arrays on load (vi_sde.py:312-323).  These are the small models of the quadrature route (T ~ 500).
+MFGM_DEV double quad_stab(double x, double c) {
+    if (c <= 0.0) return x;
+    if (x != x) x = 1e-8;
+    return fmin(fmax(x, -c), c);
+}
+static __global__ void k_quad_vdp_lagrange(int B, int N, int d, double dt, double clip, const double* __restrict__ A,
+                                           const double* __restrict__ dEdm, const double* __restrict__ dEdS,
+                                           const double* __restrict__ dobsm, const double* __restrict__ dobsS, double* __restrict__ psi,
+                                           double* __restrict__ lam) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double P[kQD * kQD], l[kQD];
+    for (int i = 0; i < d; ++i) {
+        l[i] = 0.0;
+        for (int j = 0; j < d; ++j) P[i * d + j] = (i == j) ? 1e-10 : 0.0;
+    }
+    for (int t = N - 1; t >= 0; --t) {
+        const size_t n = (size_t)b * N + t;
+        for (int i = 0; i < d; ++i) lam[n * d + i] = l[i];
+        for (int e = 0; e < d * d; ++e) psi[n * d * d + e] = P[e];
+        if (t == 0) break;
+        const double* At = A + n * d * d;
+        const size_t no = (size_t)b * (N + 1) + t;
+        double PA[kQD * kQD], Al[kQD];
+        q_mm(d, P, At, PA);
+        for (int i = 0; i < d; ++i) {
+            double tt = 0.0;
+            for (int j = 0; j < d; ++j) tt += At[i * d + j] * l[j];
+            Al[i] = tt;
+        }
+        for (int e = 0; e < d * d; ++e)
+            P[e] = P[e] - dt * (PA[e] + PA[e] - quad_stab(dEdS[n * d * d + e], clip)) - quad_stab(dobsS[no * d * d + e], clip);
+        for (int i = 0; i < d; ++i) l[i] = l[i] - dt * (Al[i] - quad_stab(dEdm[n * d + i], clip)) - quad_stab(dobsm[no * d + i], clip);
+    }
+}
+
 }  // namespace mfgm

@@ -89,3 +89,29 @@ def logdet_spd(A=None, chol=None):
     """log det A for SPD blocks."""
     L = cholesky(A) if chol is None else chol
     return 2.0 * torch.log(torch.diagonal(L, dim1=-2, dim2=-1)).sum(-1)
+
+
+def small_inverse(M):
+    """Inverse of GENERAL (not necessarily symmetric) blocks [..., d, d], d <= 3, by cofactors (element-wise torch arithmetic; the
+    reference's `tf.linalg.inv` on the 2 psi(0) + P0^{-1} of update_initial_statistics, vi_sde.py:241-260, whose psi is not symmetric)."""
+    d = M.shape[-1]
+    if d == 1:
+        return 1.0 / M
+    if d == 2:
+        a, b, c, e = M[..., 0, 0], M[..., 0, 1], M[..., 1, 0], M[..., 1, 1]
+        det = a * e - b * c
+        return torch.stack([torch.stack([e, -b], -1), torch.stack([-c, a], -1)], -2) / det[..., None, None]
+    if d != 3:
+        raise ValueError("small_inverse covers d <= 3")
+    m = [[M[..., i, j] for j in range(3)] for i in range(3)]
+    cof = [[None] * 3 for _ in range(3)]
+    for i in range(3):
+        for j in range(3):
+            r = [k for k in range(3) if k != i]
+            c = [k for k in range(3) if k != j]
+            minor = m[r[0]][c[0]] * m[r[1]][c[1]] - m[r[0]][c[1]] * m[r[1]][c[0]]
+            cof[i][j] = minor if (i + j) % 2 == 0 else -minor
+    det = m[0][0] * cof[0][0] + m[0][1] * cof[0][1] + m[0][2] * cof[0][2]
+    adj = torch.stack([torch.stack([cof[j][i] for j in range(3)], -1) for i in range(3)], -2)
+    return adj / det[..., None, None]
+

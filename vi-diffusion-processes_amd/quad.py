@@ -86,3 +86,13 @@ def esde(prm, mean, cov, A, b, grads=True, param_grad=False, check=True):
     if check:
         _check_info(info, "quad.esde")
     return E, (dm, dS, dA, db), gth
+
+
+def vdp_lagrange(A, dEdm, dEdS, dobsm, dobsS, dt, clip=0.0):
+    """(psi [B, N, d, d], lam [B, N, d]) of the VDP Lagrange sweep with jump conditions (vi_sde.py:289-347)."""
+    B, N, d = dEdm.shape
+    A, dEdm, dEdS, dobsm, dobsS = (x.contiguous() for x in (A, dEdm, dEdS, dobsm, dobsS))
+    psi, lam = torch.empty_like(dEdS), torch.empty_like(dEdm)
+    _lib.check(_lib.load().mfgm_quad_vdp_lagrange(B, N, d, float(dt), float(clip), _ptr(A), _ptr(dEdm), _ptr(dEdS), _ptr(dobsm), _ptr(dobsS),
+                                                  _ptr(psi), _ptr(lam), _stream()), "mfgm_quad_vdp_lagrange")
+    return psi, lam

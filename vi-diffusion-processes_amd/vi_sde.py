@@ -358,3 +358,170 @@ class VariationalMarkovGP:
     def elbo(self, mS=None):
         """Variational lower bound summed over trajectories (vi_sde.py:436-455)."""
         return self.elbo_per_trajectory(mS).sum()
+
+
+class VariationalMarkovGPQuadrature(VariationalMarkovGP):
+    """
+    VDP (vi_sde.py:63-482) for the drifts the closed-form kernels do not cover -- drifts that couple the state dimensions
+    (`sde.VanderPolOscillatorSDE`), the network drift (`sde.MLPDrift`), the per-dimension non-polynomial ones (through their own
+    classes: not here) -- and for a full diffusion matrix: the reference takes any SDE (vi_sde.py:377-414 calls
+    `expected_drift` / `expected_gradient_drift`, :422-434 the 20-point quadrature of the squared drift difference).  The local
+    quantities come from the HIP quadrature kernels (csrc/mfgm_quad.h: E_sde and its gradients with respect to (m, S) and the drift
+    parameters, E f / E df/dx), the Lagrange sweep from `mfgm_quad_vdp_lagrange`, the marginals of the linear drift's SSM from the
+    HIP sweeps (StateSpaceModel.marginals).  State (A, b, psi, lambda) is held in the reference's natural layout: these are the small
+    models of that formulation (20^d quadrature nodes per time step, d <= 3).  Same method names as VariationalMarkovGP, so that
+    VIMarkovGPTrainer drives either.
+    """
+
+    def __init__(self, input_data, prior_sde, grid, likelihood, prior_initial_state=None, stabilize_system=False, plan=None):
+        self.stabilize_system = bool(stabilize_system)
+        obs_times, observations = input_data
+        if observations.dim() == 2:
+            observations = observations[None]
+        self.observations = observations.contiguous()
+        self.B, self.n_obs, self.state_dim = observations.shape
+        self.prior_sde, self.likelihood = prior_sde, likelihood
+        self.grid = torch.as_tensor(grid, dtype=torch.float64)
+        self.num_states = int(self.grid.numel())
+        self.num_transitions = self.num_states - 1
+        self.dt = float(self.grid[1] - self.grid[0])
+        self.device = observations.device
+        d, B, N = self.state_dim, self.B, self.num_transitions
+        if getattr(prior_sde, "quad_kind", None) is None or d > 3:
+            raise ValueError("VariationalMarkovGPQuadrature needs a drift of the quadrature kernels and a state dimension <= 3")
+        self.plan = plan if plan is not None else Plan(B, self.num_states, d, device=self.device)
+        self.lib = self.plan.lib
+        if prior_initial_state is None:
+            prior_initial_state = (np.zeros(d), prior_sde.q.cpu().numpy() * np.eye(d))
+        self.p0_mu = np.asarray(prior_initial_state[0], dtype=np.float64).reshape(d)
+        self.p0_cov = np.asarray(prior_initial_state[1], dtype=np.float64).reshape(d, d)
+        self.q0_mu = torch.from_numpy(self.p0_mu).to(self.device).expand(B, d).contiguous()
+        self.q0_chol = torch.from_numpy(np.linalg.cholesky(self.p0_cov)).to(self.device).expand(B, d, d).contiguous()
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self.A, self.b = z(B, N, d, d), z(B, N, d)
+        self.lambda_lagrange = z(B, N, d)
+        self.psi_lagrange = (1e-10 * torch.eye(d, dtype=torch.float64, device=self.device)).expand(B, N, d, d).contiguous()
+        self.obs_index = grid_indices(self.grid, obs_times).to(self.device)
+        self.obs_node_ids = self.plan.node_ids(self.obs_index)
+        self._q = prior_sde.q.to(self.device)
+        self._cholQ = linalg.cholesky((self.dt * self._q).contiguous())
+        self._param_version = 0
+        self._mS = None
+
+    def _quad_prm(self):
+        return self.prior_sde.quad_params(self.dt, self.p0_mu, self.p0_cov)
+
+    def _refresh_drift_params(self):
+        self._param_version += 1
+
+    def _reset_lagrange(self):
+        self.lambda_lagrange.zero_()
+        d = self.state_dim
+        self.psi_lagrange = (1e-10 * torch.eye(d, dtype=torch.float64, device=self.device)).expand(self.B, self.num_transitions, d, d).contiguous()
+
+    def _natural(self, mS):
+        pl = self.plan
+        return pl.unpack(VEC, mS[0]), pl.unpack(SYM, mS[1])
+
+    def _forward_packed(self):
+        """Marginals of the SSM of the linear drift -A x + b (vi_sde.py:171-204): transitions I - dt A, offsets dt b, process noise
+        dt q; stabilised: NaN -> 1e-8 and clipping to [-1, 1] of both."""
+        from .state_space_model import StateSpaceModel
+        d = self.state_dim
+        T_ = torch.eye(d, dtype=torch.float64, device=self.device) - self.dt * self.A
+        off = self.dt * self.b
+        if self.stabilize_system:
+            T_ = torch.nan_to_num(T_, nan=1e-8).clamp(-1.0, 1.0)
+            off = torch.nan_to_num(off, nan=1e-8).clamp(-1.0, 1.0)
+        cholQ = self._cholQ.expand(self.B, self.num_transitions, d, d).contiguous()
+        self.dist_q_ssm = StateSpaceModel(self.q0_mu, self.q0_chol, T_.contiguous(), off.contiguous(), cholQ, plan=self.plan)
+        post = self.dist_q_ssm._posterior_packed()["s"]
+        self._mS = (post["x"], post["Sig"])
+        return self._mS
+
+    def _esde_terms(self, mS, param_grad=False, shift=0):
+        from . import quad
+        m, S = self._natural(mS if mS is not None else self._forward_packed())
+        N = self.num_transitions
+        return quad.esde(self._quad_prm(), m[:, shift:shift + N], S[:, shift:shift + N], self.A, self.b, grads=not param_grad,
+                         param_grad=param_grad)
+
+    def E_sde(self, mS=None):
+        return self._esde_terms(mS)[0].sum(-1) * self.dt
+
+    def _grad_E_sde(self, mS=None):
+        _, (dm, dS, _, _), _ = self._esde_terms(mS)
+        return dm, dS
+
+    def grad_prior_sde_params(self):
+        """d E_sde / d (trainable drift parameters) on the path m[1:], S[1:] against the N transitions' (A, b), as the reference
+        (vi_sde.py:457-470); a vector-valued parameter (the network's weights) gets a vector."""
+        _, _, gth = self._esde_terms(None, param_grad=True, shift=1)
+        g = (self.dt * gth.sum(dim=(0, 1))).cpu().numpy()
+        out = []
+        for n, jac in self.prior_sde.quad_param_jacobian().items():
+            out.append(g.copy() if jac is None else float(sum(gk * jk for gk, jk in zip(g, jac))))
+        return out
+
+    def _jump_arrays(self, m, S):
+        """The likelihood's gradients with respect to (m, S) at the observation nodes, scattered on the grid (vi_sde.py:262-287)."""
+        B, T, d = m.shape
+        n = B * self.n_obs
+        mo = m.reshape(B * T, d)[self.obs_node_ids]
+        Rinv = self.likelihood.inv_covariance
+        dmu = (self.observations.reshape(n, d) - mo) @ Rinv
+        dobsm = torch.zeros((B * T, d), dtype=torch.float64, device=self.device).index_add_(0, self.obs_node_ids, dmu)
+        dobsS = torch.zeros((B * T, d, d), dtype=torch.float64, device=self.device).index_add_(
+            0, self.obs_node_ids, (-0.5 * Rinv).expand(n, d, d))
+        return dobsm.view(B, T, d), dobsS.view(B, T, d, d)
+
+    def update_lagrange(self, mS=None):
+        from . import quad
+        mS = mS if mS is not None else self._mS
+        m, S = self._natural(mS)
+        dEdm, dEdS = self._grad_E_sde(mS)
+        dobsm, dobsS = self._jump_arrays(m, S)
+        self.psi_lagrange, self.lambda_lagrange = quad.vdp_lagrange(self.A, dEdm, dEdS, dobsm, dobsS, self.dt,
+                                                                    clip=5000.0 if self.stabilize_system else 0.0)
+
+    def update_param(self, mS=None, lr=0.1):
+        """A~ = -E[df/dx] + 2 q psi, b~ = E f + A~ m - q lambda, damped (vi_sde.py:377-414); the expectations by the 10-point rule."""
+        from . import quad
+        self._param_version += 1
+        m, S = self._natural(mS if mS is not None else self._mS)
+        N, d = self.num_transitions, self.state_dim
+        m, S = m[:, :N], S[:, :N]
+        if self.stabilize_system:
+            self.psi_lagrange = torch.nan_to_num(self.psi_lagrange, nan=1e-8).clamp(-5000.0, 5000.0)
+            self.lambda_lagrange = torch.nan_to_num(self.lambda_lagrange, nan=1e-8).clamp(-5000.0, 5000.0)
+        Al, bl = quad.linearize(self._quad_prm(), m, S)                 # I + dt E J,  dt (E f - E J m)
+        EJ = (Al - torch.eye(d, dtype=torch.float64, device=self.device)) / self.dt
+        Ef = bl / self.dt + (EJ @ m[..., None])[..., 0]
+        A_t = -EJ + 2.0 * self._q @ self.psi_lagrange
+        b_t = Ef + (A_t @ m[..., None])[..., 0] - (self._q @ self.lambda_lagrange[..., None])[..., 0]
+        self.A = (1 - lr) * self.A + lr * A_t
+        self.b = (1 - lr) * self.b + lr * b_t
+
+    def update_lagrange_and_param(self, mS=None, lr=0.1):
+        self.update_lagrange(mS)
+        self.update_param(mS, lr)
+
+    def update_initial_statistics(self, lr):
+        lam0, psi0 = self.lambda_lagrange[:, 0], self.psi_lagrange[:, 0]
+        P0 = torch.from_numpy(self.p0_cov).to(self.device)
+        mu0 = torch.from_numpy(self.p0_mu).to(self.device)
+        mean = mu0 - (P0 @ lam0[..., None])[..., 0]
+        # psi is not symmetric (the sweep adds psi A + psi A): a general inverse, as the reference's tf.linalg.inv
+        cov = linalg.small_inverse(linalg.spd_inverse(P0) + 2.0 * psi0)
+        q0_cov = self.q0_chol @ self.q0_chol.transpose(-1, -2)
+        self.q0_mu = (1 - lr) * self.q0_mu + lr * mean
+        self.q0_chol = linalg.cholesky(((1 - lr) * q0_cov + lr * cov).contiguous())
+
+    def elbo_per_trajectory(self, mS=None):
+        pl = self.plan
+        m, S = mS if mS is not None else self._forward_packed()
+        n, d = self.B * self.n_obs, self.state_dim
+        mu = pl.gather_nodes(VEC, m, self.obs_node_ids)
+        cov = pl.gather_nodes(SYM, S, self.obs_node_ids)
+        e_obs = self.likelihood.variational_expectations(mu, cov, self.observations.reshape(n, d)).reshape(self.B, self.n_obs).sum(-1)
+        return e_obs - self.E_sde((m, S)) - self.KL_initial_state()
