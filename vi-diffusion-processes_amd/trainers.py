@@ -28,6 +28,18 @@ from .variational_cvi_sde import grid_indices
 logger = logging.getLogger(__name__)
 
 
+def _sum_grads_over_ranks(grads):
+    """sum_over_ranks for a list whose entries are floats or NumPy vectors (one all-reduce of the flattened list)."""
+    import numpy as np
+    sizes = [int(np.size(g)) for g in grads]
+    flat = sum_over_ranks(np.concatenate([np.atleast_1d(np.asarray(g, dtype=np.float64)).reshape(-1) for g in grads]).tolist())
+    out, at = [], 0
+    for g, n in zip(grads, sizes):
+        out.append(float(flat[at]) if np.ndim(g) == 0 else np.array(flat[at:at + n]))
+        at += n
+    return out
+
+
 class _Metrics:
     """NLPD / RMSE of the (batched) posterior at held-out grid points."""
 
@@ -88,13 +100,15 @@ class _Adam:
         self.lr, self.m, self.v, self.t = float(lr), [0.0] * n, [0.0] * n, 0
 
     def step(self, values, grads):
+        """values / grads: floats, or NumPy vectors for a vector-valued parameter (the network drift's weights)."""
+        import numpy as np
         self.t += 1
         out = []
         for i, (x, g) in enumerate(zip(values, grads)):
             self.m[i] = 0.9 * self.m[i] + 0.1 * g
             self.v[i] = 0.999 * self.v[i] + 0.001 * g * g
             a = self.lr * math.sqrt(1.0 - 0.999 ** self.t) / (1.0 - 0.9 ** self.t)
-            out.append(x - a * self.m[i] / (math.sqrt(self.v[i]) + 1e-7))
+            out.append(x - a * self.m[i] / (np.sqrt(self.v[i]) + 1e-7))
         return out
 
 
@@ -137,7 +151,7 @@ class CVISitesTrainer:
             grads_ve = model.grad_VE_wrt_prior_params()
             names = sde.trainable_variables
             # the gradient of the whole batch: summed over the ranks before the optimiser sees it
-            grads = sum_over_ranks([a + b for a, b in zip(grads_kl, grads_ve)])
+            grads = _sum_grads_over_ranks([a + b for a, b in zip(grads_kl, grads_ve)])
             new = self.prior_sde_optim.step([sde.get(n) for n in names], grads)
             for n, v in zip(names, new):
                 sde.assign(n, v)
@@ -394,7 +408,7 @@ class VIMarkovGPTrainer:
         mdl, sde = self.model, self.model.prior_sde
         elbo_vals, nlpd_vals, rmse_vals = [self._elbo_nlpd_rmse()[0]], [], []
         for _ in range(self.learning_max_itr):
-            grads = sum_over_ranks(mdl.grad_prior_sde_params())      # of the whole batch, before the optimiser sees it
+            grads = _sum_grads_over_ranks(mdl.grad_prior_sde_params())      # of the whole batch, before the optimiser sees it
             names = sde.trainable_variables
             for n, v in zip(names, self.prior_sde_optim.step([sde.get(n) for n in names], grads)):
                 sde.assign(n, v)
