@@ -318,7 +318,9 @@ int mfgm_mvn_ve_compact(int B, int n_per, int d, const double* mu, const double*
  *   kind 10  Van der Pol (markovflow/sde/sde.py:432-518), d = 2: theta = (a, tau)
  *   kind 11  ReLU network 1 -> nh -> 1 on every state dimension (sde.py:359-429): theta = (W1 [nh], b1 [nh], W2 [nh], b2), nh <= 13
  *   kind 12  per-dimension cubic c1 x - c3 x^3 (Ornstein-Uhlenbeck / double well, sde.py:134-224) with a NON-DIAGONAL diffusion
- *            matrix: theta = (c1, c3) */
+ *            matrix: theta = (c1, c3)
+ *   kind 13 / 14 / 15  theta tanh x / sin(x - theta) / sqrt(theta |x|) per dimension (sde.py:227-356): theta = (theta, unused) -- the VDP
+ *            model and prior learning with these drifts (the closed-form-moment kernels serve their CVI-DP inference) */
 #define MFGM_QUAD_NTHETA 40
 typedef struct mfgm_quad_drift {
     int kind, d, nh, pad_;

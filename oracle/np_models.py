@@ -292,7 +292,8 @@ class VariationalMarkovGP:
     def _general(self):
         """A drift the per-dimension cubic closed forms do not cover (coupled / network drifts) or a full diffusion matrix."""
         q = np.asarray(self.sde.q)
-        return hasattr(self.sde, "jacobian_drift") or hasattr(self.sde, "weights") or np.abs(q - np.diag(np.diag(q))).max() > 0.0
+        cubic = isinstance(self.sde, (self._np_sde.OrnsteinUhlenbeckSDE, self._np_sde.DoubleWellSDE))
+        return not cubic or np.abs(q - np.diag(np.diag(q))).max() > 0.0
 
     def _grad_E_sde(self, m, S):
         if self._general():

@@ -1081,7 +1081,7 @@ def test_cvi_sites_sde_quadrature_drifts(amd, rng, kind):
     np.testing.assert_allclose(host(g.classic_elbo_per_trajectory())[0], o.classic_elbo(), rtol=2e-6, atol=2e-6)
 
 
-@pytest.mark.parametrize("kind", ["vanderpol", "vanderpol_fullq", "mlp"])
+@pytest.mark.parametrize("kind", ["vanderpol", "vanderpol_fullq", "mlp", "benes", "sine"])
 def test_variational_markov_gp_quadrature_drifts(amd, rng, kind):
     """VDP with the drifts the closed-form kernels do not cover and with a full diffusion matrix (the reference's VariationalMarkovGP
     takes any SDE: vi_sde.py:377-414, 422-434): VariationalMarkovGPQuadrature on the HIP quadrature kernels against the oracle's
@@ -1099,11 +1099,15 @@ def test_variational_markov_gp_quadrature_drifts(amd, rng, kind):
         d = 2
         q = 0.5 * np.eye(2) if kind == "vanderpol" else np.array([[0.5, 0.12], [0.12, 0.4]])
         o_sde, g_sde = np_sde.VanderPolSDE(1.3, 0.9, q), gsde.VanderPolOscillatorSDE(1.3, 0.9, torch.from_numpy(q), trainable=True)
+    elif kind in ("benes", "sine"):
+        # VDP with the per-dimension non-polynomial drifts (the review's "VDP with Benes / sine"; sde.py:227-312), d = 2
+        d = 2
+        o_sde, g_sde = _theta_sdes(kind, d, np.array([0.7, 0.4]))
     else:
         d = 1
         w = (rng.normal(size=(1, 3)), 0.1 * rng.normal(size=3), rng.normal(size=(3, 1)), np.zeros(1))
         o_sde, g_sde = np_sde.MLPDriftSDE(w), gsde.MLPDrift(weights=[torch.from_numpy(np.asarray(x)) for x in w])
-    smooth = kind != "mlp"
+    smooth = kind.startswith("vanderpol")
     idx = np.arange(4, T - 1, 6)
     y = rng.normal(size=(1, len(idx), d))
     cholR = 0.5 * np.eye(d)

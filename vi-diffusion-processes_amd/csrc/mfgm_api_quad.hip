@@ -9,7 +9,7 @@ bool quad_ok(const mfgm_quad_drift* q) {
     if (!q || q->d < 1 || q->d > kQD) return false;
     if (q->kind == 10) return q->d == 2;
     if (q->kind == 11) return q->nh >= 1 && 3 * q->nh + 1 <= kQP;
-    return q->kind == 12;
+    return q->kind >= 12 && q->kind <= 15;
 }
 int nparam(const mfgm_quad_drift* q) { return q->kind == 11 ? 3 * q->nh + 1 : 2; }
 }  // namespace

@@ -49,6 +49,7 @@ MFGM_DEV void gh_node(int H, int k, double& xi, double& w) {
 //   kind 11  ReLU network 1 -> nh -> 1 applied to every state dimension (sde.py:359-429),  theta = (W1 [nh], b1 [nh], W2 [nh], b2)
 //   kind 12  per-dimension cubic f_i = c1 x_i - c3 x_i^3 (Ornstein-Uhlenbeck: (-decay, 0); double well scale x (c - x^2): (scale c, scale);
 //            sde.py:134-224) -- on this route when the diffusion matrix is not diagonal,  theta = (c1, c3)
+//   kind 13 / 14 / 15  theta tanh x / sin(x - theta) / sqrt(theta |x|) per dimension (sde.py:227-356),  theta = (theta, -)
 MFGM_DEV int quad_nparam(const mfgm_quad_drift& q) { return q.kind == 11 ? 3 * q.nh + 1 : 2; }
 
 template <bool PGRAD>
@@ -88,6 +89,26 @@ MFGM_DEV void quad_drift(const mfgm_quad_drift& q, const double* x, double* f, d
             if (PGRAD) fp[(3 * nh) * d + i] = 1.0;                   // d / d b2
             f[i] = acc;
             J[i * d + i] = jac;
+        }
+    } else if (q.kind >= 13) {
+        // per-dimension non-polynomial drifts (sde.py:227-356): 13 theta tanh x, 14 sin(x - theta), 15 sqrt(theta |x|); one parameter
+        const double th = q.theta[0];
+        for (int e = 0; e < d * d; ++e) J[e] = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double xi = x[i];
+            double fv, f1, ft;
+            if (q.kind == 13) {
+                const double t = tanh(xi);
+                fv = th * t; f1 = th * (1.0 - t * t); ft = t;
+            } else if (q.kind == 14) {
+                fv = sin(xi - th); f1 = cos(xi - th); ft = -f1;
+            } else {
+                const double a = fabs(xi), r = sqrt(th * a);
+                fv = r; f1 = (xi < 0.0 ? -0.5 : 0.5) * r / a; ft = 0.5 * r / th;
+            }
+            f[i] = fv;
+            J[i * d + i] = f1;
+            if (PGRAD) { fp[i] = ft; fp[d + i] = 0.0; }
         }
     } else {
         const double c1 = q.theta[0], c3 = q.theta[1];

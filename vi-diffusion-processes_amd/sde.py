@@ -196,7 +196,14 @@ class DoubleWellSDE(SDE):
 
 class _ThetaSDE(SDE):
     """Per-dimension non-polynomial drifts with one parameter theta (sde.py:227-356): Gaussian expectations by the reference's
-    Gauss-Hermite rules inside the kernels (state_dim <= 4); no VDP / prior-learning support (those kernels are cubic-only)."""
+    Gauss-Hermite rules inside the kernels (state_dim <= 4).  CVI-DP inference runs on the moment-array kernels (CVISitesSDE); the VDP
+    model and prior learning on the tensor-product quadrature kernels (VariationalMarkovGPQuadrature, CVISitesSDEQuadrature; d <= 3)."""
+
+    def quad_theta(self):
+        return [self.theta, 0.0], 0
+
+    def quad_param_jacobian(self):
+        return {n: [1.0, 0.0] for n in self.trainable_variables}
 
     _param_names = ("theta",)
 
@@ -216,6 +223,7 @@ class _ThetaSDE(SDE):
 class BenesSDE(_ThetaSDE):
     """dx = theta tanh(x) dt + dB (sde.py:227-268)."""
     kind = 1
+    quad_kind = 13
 
     def __init__(self, theta=1.0, q=None, trainable=False):
         super().__init__(theta, q, trainable)
@@ -230,6 +238,7 @@ class BenesSDE(_ThetaSDE):
 class SineDiffusionSDE(_ThetaSDE):
     """dx = sin(x - theta) dt + dB (sde.py:271-312)."""
     kind = 2
+    quad_kind = 14
 
     def __init__(self, theta=0.0, q=None, trainable=False):
         super().__init__(theta, q, trainable)
@@ -244,6 +253,7 @@ class SineDiffusionSDE(_ThetaSDE):
 class SqrtDiffusionSDE(_ThetaSDE):
     """dx = sqrt(theta |x|) dt + dB (sde.py:315-356)."""
     kind = 3
+    quad_kind = 15
 
     def __init__(self, theta=1.0, q=None, trainable=False):
         super().__init__(theta, q, trainable)
