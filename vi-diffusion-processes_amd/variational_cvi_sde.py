@@ -784,15 +784,31 @@ class CVISitesSDE(CVISitesSSM):
         jac = self.prior_sde.cubic_jacobian(self.dt)
         return [dal * jac[n][0] + dbe * jac[n][1] for n in self.prior_sde.trainable_variables]
 
-    def _prior_naturals_on(self, path):
+    def _prior_naturals_on(self, path, frozen=None):
         """Naturals (lin [B,T,d], diag [B,T,d,d], sub [B,T-1,d,d], natural layout) of the prior linearised on the packed path (mu, Sigma)
-        with the CURRENT drift parameters -- the (stabilised) prior `set_linearized_prior` installs; the model's state is not touched."""
+        with the CURRENT drift parameters -- the (stabilised) prior `set_linearized_prior` installs; the model's state is not touched.
+        frozen = (keep_A, A_clipped, keep_off, off_clipped) (packed): the clipping DECISION of another parameter value -- entries that
+        were inside the clipping range there follow the unclipped linearisation here, the others stay at their bound -- which is how a
+        tape differentiates tf.clip_by_value (zero through a clipped entry, one through a free one)."""
         pl = self.plan
-        prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1],
-                                    clip=self.clip_state_transitions if self.stabilize_ssm else None)
+        clip = self.clip_state_transitions if (self.stabilize_ssm and frozen is None) else None
+        prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1], clip=clip)
         A, off, chol = pl.linearize_cubic(prm, path[0], path[1])
+        if frozen is not None:
+            A = torch.where(frozen[0], A, frozen[1])
+            off = torch.where(frozen[2], off, frozen[3])
         nat = pl.ssm_to_naturals(A, off, chol)
         return pl.unpack(VEC, nat["lin"]), pl.unpack(SYM, nat["diag"]), pl.unpack(FULL, nat["sub"], self.T - 1)
+
+    def _clip_decision(self, path):
+        """(keep_A, A_clipped, keep_off, off_clipped) of the linearisation at the current drift parameters (None without clipping)."""
+        if not self.stabilize_ssm:
+            return None
+        pl = self.plan
+        lo, hi = self.clip_state_transitions
+        prm = self.prior_sde.params(self.dt, self.prior_initial_state[0], self.prior_initial_state[1], clip=None)
+        A, off, _ = pl.linearize_cubic(prm, path[0], path[1])
+        return (A > lo) & (A < hi), A.clamp(lo, hi), (off > lo) & (off < hi), off.clamp(lo, hi)
 
     def grad_VE_wrt_prior_params(self, rel_step=1e-6, finite_difference=False):
         """
@@ -804,7 +820,8 @@ class CVISitesSDE(CVISitesSSM):
         with g = d VE / d eta the likelihood's site gradient at the observation nodes, F_q the Fisher matrix of the re-linearised q
         (symmetric: ONE Fisher-vector product, tape.fisher_vector_product, serves every parameter) and d theta_p / d kappa the derivative
         of the LOCAL linearisation map on the fixed path -- a polynomial of degree two in the Euler-map coefficients, for which the
-        central difference used here is exact up to rounding.  `finite_difference=True` is the round-2 evaluation (two re-linearised
+        central difference used here is exact up to rounding; with `stabilize_ssm` the clipping decision of the current parameters is
+        held fixed across the difference (zero slope through a clipped entry, as a tape through tf.clip_by_value).  `finite_difference=True` is the round-2 evaluation (two re-linearised
         posterior refreshes per parameter), kept as a cross-check.  Like the reference's, the call leaves the prior re-linearised at
         the current posterior.
         """
@@ -848,13 +865,17 @@ class CVISitesSDE(CVISitesSSM):
         g_diag = torch.zeros((B * T, d, d), dtype=torch.float64, device=self.device).index_add_(0, self.obs_node_ids, g2.reshape(-1, d, d))
         u = tape.fisher_vector_product(pl, diag, sub, mu, cov, csub, g_lin.view(B, T, d), g_diag.view(B, T, d, d), torch.zeros_like(sub))
         grads = []
+        # the clipping decision is taken ONCE, at the current parameters, and held while they are stepped: the unclipped map is a
+        # polynomial of degree two in the Euler-map coefficients (the central difference is exact for it), whereas a difference taken
+        # THROUGH the clipping blends the two slopes of every transition within h |dA / d kappa| of a bound
+        frozen = self._clip_decision(path)
         for n in sde.trainable_variables:
             v0 = sde.get(n)
-            h = 1e-3 * max(abs(v0), 1.0)          # exact for the quadratic dependence of theta_p on the Euler-map coefficients
+            h = 1e-3 * max(abs(v0), 1.0)
             sde.assign(n, v0 + h)
-            up = self._prior_naturals_on(path)
+            up = self._prior_naturals_on(path, frozen)
             sde.assign(n, v0 - h)
-            dn = self._prior_naturals_on(path)
+            dn = self._prior_naturals_on(path, frozen)
             sde.assign(n, v0)
             grads.append(-float(sum(((a - b) * w).sum() for a, b, w in zip(up, dn, u))) / (2.0 * h))
         self._path, self._q = path, None
