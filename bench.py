@@ -358,15 +358,26 @@ def bench_vdp(h, data_rank):
         mS = state["mS"]
         prm = m._params(lr=0.01)
 
+        lean = not m.store_multipliers
+        psi0, lam0 = (torch.empty((B, d, d), dtype=torch.float64, device=device), torch.empty((B, d), dtype=torch.float64, device=device))
+
         def final():
-            assert lib.mfgm_packed_vdp_lagrange_update_final(pl.h, ctypes.byref(prm), _ptr(mS[0]), _ptr(mS[1]), _ptr(A2), _ptr(b2),
-                                                             _ptr(m._yR), _ptr(m._dobsS), _ptr(m.psi_lagrange), _ptr(m.lambda_lagrange),
-                                                             _ptr(m._seg), *m._jump_args(), _stream()) == 0
+            if lean:
+                rc = lib.mfgm_packed_vdp_lagrange_update0(pl.h, ctypes.byref(prm), _ptr(mS[0]), _ptr(mS[1]), _ptr(A2), _ptr(b2), _ptr(m._yR),
+                                                          _ptr(m._dobsS), _ptr(psi0), _ptr(lam0), _ptr(m._seg), *m._jump_args(), 1, _stream())
+            else:
+                rc = lib.mfgm_packed_vdp_lagrange_update_final(pl.h, ctypes.byref(prm), _ptr(mS[0]), _ptr(mS[1]), _ptr(A2), _ptr(b2),
+                                                               _ptr(m._yR), _ptr(m._dobsS), _ptr(m.psi_lagrange), _ptr(m.lambda_lagrange),
+                                                               _ptr(m._seg), *m._jump_args(), _stream())
+            assert rc == 0
         ET = d * (d + 1) // 2
-        # reads m, S, A, b, yR, the observation count (half a double); writes psi, lambda and the new A, b
-        doubles = (d + ET + d * d + d + d + 0.5) + (d * d + d) + (d * d + d)
-        out["roofline"] = h.roofline(f"void mfgm::k_vdp_lagrange<{d}, 4>(...)",
-                                     "final Lagrange sweep with the parameter update: reads m, S, A, b, R^-1 y, writes psi, lambda, A, b",
+        # reads m, S, A, b, yR, the observation count (half a double); writes the new A, b (and, unless the sweep keeps the multipliers
+        # of node 0 only, psi and lambda)
+        doubles = (d + ET + d * d + d + d + 0.5) + (0 if lean else d * d + d) + (d * d + d)
+        out["roofline"] = h.roofline(f"void mfgm::k_vdp_lagrange<{d}, {5 if lean else 4}>(...)",
+                                     "final Lagrange sweep with the parameter update: reads m, S, A, b, R^-1 y, writes A, b"
+                                     + (" (the multipliers are kept at node 0 only: the fused update has consumed the others)" if lean
+                                        else ", psi, lambda"),
                                      h.timed(final), 8 * doubles * B * T, 1, out["ms_per_step"])
         if h.world == 1 and not a.no_cpu_baseline:
             try:

@@ -587,6 +587,14 @@ int mfgm_packed_vdp_lagrange(const mfgm_plan* plan, const mfgm_vdp_params* prm, 
 int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
                                     double* bm, const double* yR, const double* dobsS, double* psi, double* lam, double* seg,
                                     const int* obs_count, const double* dobs_const, void* stream);
+/* The same with the multipliers kept at NODE 0 only: psi0 [B, d, d], lam0 [B, d] (natural layout) instead of the packed arrays.  In the
+ * trainer's loop (vi_markov_gp_trainer.py:56-58: update_lagrange, update_param, update_initial_statistics) every other multiplier has
+ * been consumed by the fused parameter update when the sweep leaves its node; only psi(0), lambda(0) are read afterwards
+ * (vi_sde.py:241-260).  Saves the d^2 + d stores per node nobody loads (42 of 153 doubles at d = 6).  final_only != 0: the last kernel
+ * alone (roofline timing; seg must hold the segment scans of a full call). */
+int mfgm_packed_vdp_lagrange_update0(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
+                                     double* bm, const double* yR, const double* dobsS, double* psi0, double* lam0, double* seg,
+                                     const int* obs_count, const double* dobs_const, int final_only, void* stream);
 /* Profiling / roofline entry point: the LAST kernel of mfgm_packed_vdp_lagrange_update alone (the final sweep that also replaces
  * (Am, bm)); seg must hold the segment scans of a full call with the same arguments. */
 int mfgm_packed_vdp_lagrange_update_final(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

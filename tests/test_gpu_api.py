@@ -1342,7 +1342,7 @@ def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind)
     # a small observation noise makes the multipliers large enough for stabilize_system to clip them
     lik_chol = (0.02 if stab else 0.5) * np.eye(d)
 
-    def run(fused):
+    def run(fused, lean=False):
         q = torch.eye(d, dtype=torch.float64)
         VariationalMarkovGP.dense_jumps = not fused      # the two-call form also reads the dense jump-condition array
         g = VariationalMarkovGP((grid[idx], dev(y)), gsde.DoubleWellSDE(q) if kind == "dw" else gsde.OrnsteinUhlenbeckSDE(0.9, q), grid,
@@ -1352,23 +1352,37 @@ def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind)
         for _ in range(3):
             mS = g._forward_packed()
             if fused:
-                g.update_lagrange_and_param(mS, lr=0.05)
+                g.update_lagrange_and_param(mS, lr=0.05, store_multipliers=not lean)
             else:
                 g.update_lagrange(mS)
                 g.update_param(mS, lr=0.05)
             pl = g.plan
-            out.append([host(pl.unpack(amd.FULL, g.A, T - 1)), host(pl.unpack(amd.VEC, g.b, T - 1)),
-                        host(pl.unpack(amd.FULL, g.psi_lagrange, T - 1)), host(pl.unpack(amd.VEC, g.lambda_lagrange, T - 1))])
+            if lean:
+                # the sweep kept the multipliers of node 0 only: (A, b), psi(0), lambda(0) and what update_initial_statistics makes of them
+                psi0, lam0 = g._mult0
+                if not stab:        # (clipped multipliers of +-5000 do not give a positive definite q(x0): the scenario is about clipping)
+                    g.update_initial_statistics(0.1)
+                out.append([host(pl.unpack(amd.FULL, g.A, T - 1)), host(pl.unpack(amd.VEC, g.b, T - 1)), host(psi0), host(lam0),
+                            host(g.q0_mu), host(g.q0_chol)])
+            else:
+                rec = [host(pl.unpack(amd.FULL, g.A, T - 1)), host(pl.unpack(amd.VEC, g.b, T - 1)),
+                       host(pl.unpack(amd.FULL, g.psi_lagrange, T - 1)), host(pl.unpack(amd.VEC, g.lambda_lagrange, T - 1))]
+                if not stab:
+                    g.update_initial_statistics(0.1)
+                out.append(rec + [host(g.q0_mu), host(g.q0_chol)])
         return out
 
     try:
-        ra, rb = run(True), run(False)
+        ra, rb, rc = run(True), run(False), run(True, lean=True)
     finally:
         VariationalMarkovGP.dense_jumps = False
-    for sa, sb in zip(ra, rb):
+    for sa, sb, sc in zip(ra, rb, rc):
         for xa, xb in zip(sa, sb):
             assert np.isfinite(xb).all()
             np.testing.assert_allclose(xa, xb, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(xb).max()))
+        # lean form: A, b | psi(0), lambda(0) | q(x0)
+        for xc, xb in zip(sc, [sb[0], sb[1], sb[2][:, 0], sb[3][:, 0], sb[4], sb[5]]):
+            np.testing.assert_allclose(xc, xb, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(xb).max()))
 
 
 def test_full_size_fused_model_steps(amd):

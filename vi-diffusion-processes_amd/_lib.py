@@ -65,6 +65,7 @@ EXPORTS = {
     "mfgm_packed_vdp_update_param": (ctypes.c_int, [ctypes.c_void_p] * 9),
     "mfgm_packed_vdp_lagrange_update": (ctypes.c_int, [ctypes.c_void_p] * 14),
     "mfgm_packed_vdp_lagrange_update_final": (ctypes.c_int, [ctypes.c_void_p] * 14),
+    "mfgm_packed_vdp_lagrange_update0": (ctypes.c_int, [ctypes.c_void_p] * 13 + [ctypes.c_int, ctypes.c_void_p]),
     "mfgm_packed_selinv_mom": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9),
     "mfgm_packed_selinv_mom_s": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
                                  + [ctypes.c_void_p] * 6),

@@ -23,7 +23,7 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         else hipLaunchKernelGGL((k_vdp_esde<D, false>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, part, o1, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, o0, (double*)nullptr);
-    } else if (what == 2 || what == 5) {
+    } else if (what == 2 || what == 5 || what == 8) {
         // segment summaries, per-chain scan of the segment maps, final sweep (what == 5: the sweep also makes update_param)
         double* Aw = const_cast<double*>(a2);
         double* bw = const_cast<double*>(a3);
@@ -36,12 +36,16 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 1>), dim3(P.B), dim3(kScanBlock), 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
         if (what == 2) hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
-        else hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
-    } else if (what == 7) {
-        // the final Lagrange sweep with the parameter update alone (roofline timing; the segment scans of a full call must be in o2)
+        else if (what == 5) hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
+        // what == 8: the multipliers of node 0 only (o0 = psi0 [B, d, d], o1 = lam0 [B, d], natural layout)
+        else hipLaunchKernelGGL((k_vdp_lagrange<D, 5>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
+    } else if (what == 7 || what == 9) {
+        // the final Lagrange sweep with the parameter update alone (roofline timing; the segment scans of a full call must be in o2);
+        // what == 9: its node-0-multipliers form
         double* Aw = const_cast<double*>(a2);
         double* bw = const_cast<double*>(a3);
-        hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
+        if (what == 7) hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
+        else hipLaunchKernelGGL((k_vdp_lagrange<D, 5>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
     } else if (what == 6) {
         // forward_pass as the partitioned moment recursion: a2 = q0_mu [B, d], a3 = q0_cov [B, ET]; o0 = mu, o1 = Sig, o2 = seg
         // a4 (optional) = E_sde / dt per trajectory [B], then ws holds the per-lane partials
@@ -221,6 +225,17 @@ int mfgm_packed_vdp_lagrange_update_final(const mfgm_plan* plan, const mfgm_vdp_
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
     MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(7, P, pr, mu, Sig, Am, bm, yR, dobsS, psi, lam, seg, nullptr, st, obs_count, dobs_const)));
+}
+
+int mfgm_packed_vdp_lagrange_update0(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
+                                     double* bm, const double* yR, const double* dobsS, double* psi0, double* lam0, double* seg,
+                                     const int* obs_count, const double* dobs_const, int final_only, void* stream) {
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !psi0 || !lam0 || !seg) return 1;
+    if ((obs_count != nullptr) != (dobs_const != nullptr) || (!obs_count && !dobsS)) return 1;
+    const Plan& P = plan->p;
+    VdpParams pr; memcpy(&pr, prm, sizeof(pr));
+    hipStream_t st = (hipStream_t)stream;
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(final_only ? 9 : 8, P, pr, mu, Sig, Am, bm, yR, dobsS, psi0, lam0, seg, nullptr, st, obs_count, dobs_const)));
 }
 
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

@@ -629,6 +629,10 @@ __global__ __launch_bounds__(64) void k_vdp_esde(LevelDesc lv, VdpParams pr, con
 // at the segment's last node (bpsi, blam: [lanes] arrays written by k_vdp_lagrange_scan_wave).
 // PASS 4: PASS 3 that also makes update_param at every node it visits (A, b replaced in place; with pr.clip > 0 the stored psi /
 // lambda are the clipped values update_param would leave, the recurrence itself continues with the unclipped ones).
+// PASS 5: PASS 4 that keeps the multipliers of NODE 0 only, in psig [B, d, d] / lamg [B, d] (natural layout): in the trainer's loop
+// (vi_markov_gp_trainer.py:56-58) update_param has consumed every other multiplier by the time the sweep leaves its node and only
+// update_initial_statistics reads psi(0), lambda(0) afterwards -- 42 of the 153 doubles per node the sweep moves at d = 6 are stores
+// nobody loads.
 template <int D, int PASS>
 __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr, const double* __restrict__ mug,
                                                     const double* __restrict__ Sigg, double* Am,
@@ -678,13 +682,13 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                     st_node<D>(lamg, R, s, me, lam);
                 }
                 double m[D], S[ET], A[EF], bb[D];
-                if (PASS == 4 || t >= 1) {
+                if (PASS >= 4 || t >= 1) {
                     ld_node<D>(mug, R, s, me, m);
                     ld_node<ET>(Sigg, R, s, me, S);
                     ld_node<EF>(Am, R, s, me, A);
                     ld_node<D>(bm, R, s, me, bb);
                 }
-                if (PASS == 4) {
+                if (PASS >= 4) {
                     // update_param at node t (vi_sde.py:377-414) from the multipliers just obtained.  Element by element, straight to
                     // memory: the clipped multipliers, A~ = 2 q psi_c - diag(J) and the blended A never exist as arrays (this kernel
                     // has no registers to spare: three more d x d arrays put it into scratch)
@@ -702,13 +706,19 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange(LevelDesc lv, VdpParams pr,
                             const double pc = pr.clip > 0.0 ? vdp_stab(psi[i * D + j], pr.clip) : psi[i * D + j];
                             const double At = 2.0 * pr.q[i] * pc - (i == j ? Jf[i] : 0.0);
                             bt = __builtin_fma(At, m[j], bt);
-                            pP[(i * D + j) * 64] = pc;
+                            if (PASS == 4) pP[(i * D + j) * 64] = pc;
+                            else if (t == 0) psig[(size_t)b * EF + i * D + j] = pc;
                             pA[(i * D + j) * 64] = (1.0 - pr.lr) * A[i * D + j] + pr.lr * At;
                         }
                         t0[i] = lc;
                         bn[i] = (1.0 - pr.lr) * bb[i] + pr.lr * bt;
                     }
-                    st_node<D>(lamg, R, s, me, t0);
+                    if (PASS == 4) {
+                        st_node<D>(lamg, R, s, me, t0);
+                    } else if (t == 0) {
+#pragma unroll
+                        for (int i = 0; i < D; ++i) lamg[(size_t)b * D + i] = t0[i];
+                    }
                     st_node<D>(bm, R, s, me, bn);
                 }
                 if (t >= 1) {

@@ -271,6 +271,7 @@ class VariationalMarkovGP:
                                                      _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
                                                      _ptr(self.lambda_lagrange), _ptr(self._seg), *self._jump_args(), _stream()),
                    "mfgm_packed_vdp_lagrange")
+        self._mult0 = None
 
     def update_param(self, mS=None, lr=0.1):
         """A <- (1-lr) A + lr A~, b <- (1-lr) b + lr b~ (vi_sde.py:377-414)."""
@@ -282,25 +283,47 @@ class VariationalMarkovGP:
                                                          _ptr(self.psi_lagrange), _ptr(self.lambda_lagrange), _ptr(self.A),
                                                          _ptr(self.b), _stream()), "mfgm_packed_vdp_update_param")
 
-    def update_lagrange_and_param(self, mS=None, lr=0.1):
+    # update_lagrange_and_param keeps the multipliers of node 0 only (VIDP_VDP_STORE_MULTIPLIERS=1: the [B, T] arrays every time)
+    store_multipliers = os.environ.get("VIDP_VDP_STORE_MULTIPLIERS", "0") == "1"
+
+    def update_lagrange_and_param(self, mS=None, lr=0.1, store_multipliers=None):
         """
         update_lagrange(mS) followed by update_param(mS, lr), as the trainer calls them (vi_markov_gp_trainer.py:56-57), in one
         set of sweeps: the final Lagrange sweep makes the parameter update node by node (mfgm_packed_vdp_lagrange_update).
+        By default the sweep keeps the multipliers of node 0 only (mfgm_packed_vdp_lagrange_update0): the fused update has consumed every
+        other psi_t / lambda_t when it leaves node t, and update_initial_statistics -- the one later reader in the loop -- needs node 0;
+        `psi_lagrange` / `lambda_lagrange` are then NOT current until update_lagrange (or a call with store_multipliers=True) runs.
         """
         self._param_version += 1
         pl = self.plan
         m, S = mS if mS is not None else self._mS
-        _lib.check(self.lib.mfgm_packed_vdp_lagrange_update(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
-                                                            _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
-                                                            _ptr(self.lambda_lagrange), _ptr(self._seg), *self._jump_args(), _stream()),
-                   "mfgm_packed_vdp_lagrange_update")
+        if self.store_multipliers if store_multipliers is None else store_multipliers:
+            _lib.check(self.lib.mfgm_packed_vdp_lagrange_update(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
+                                                                _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
+                                                                _ptr(self.lambda_lagrange), _ptr(self._seg), *self._jump_args(), _stream()),
+                       "mfgm_packed_vdp_lagrange_update")
+            self._mult0 = None
+            return
+        if getattr(self, "_mult0_bufs", None) is None:
+            d = self.state_dim
+            self._mult0_bufs = (torch.empty((self.B, d, d), dtype=torch.float64, device=self.device),
+                                torch.empty((self.B, d), dtype=torch.float64, device=self.device))
+        psi0, lam0 = self._mult0_bufs
+        _lib.check(self.lib.mfgm_packed_vdp_lagrange_update0(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
+                                                             _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(psi0), _ptr(lam0),
+                                                             _ptr(self._seg), *self._jump_args(), 0, _stream()),
+                   "mfgm_packed_vdp_lagrange_update0")
+        self._mult0 = (psi0, lam0)          # what update_initial_statistics reads until the arrays are current again
 
     def update_initial_statistics(self, lr):
         """q(x0) from the multipliers at t = 0 (vi_sde.py:241-260); tiny per-trajectory d x d algebra."""
         pl = self.plan
-        node0 = pl.node_ids(torch.zeros(1, dtype=torch.int64))
-        lam0 = pl.gather_nodes(VEC, self.lambda_lagrange, node0)
-        psi0 = pl.gather_nodes(FULL, self.psi_lagrange, node0)
+        if getattr(self, "_mult0", None) is not None:
+            psi0, lam0 = self._mult0
+        else:
+            node0 = pl.node_ids(torch.zeros(1, dtype=torch.int64))
+            lam0 = pl.gather_nodes(VEC, self.lambda_lagrange, node0)
+            psi0 = pl.gather_nodes(FULL, self.psi_lagrange, node0)
         P0 = torch.from_numpy(self.p0_cov).to(self.device)
         mu0 = torch.from_numpy(self.p0_mu).to(self.device)
         mean = mu0 - (P0 @ lam0[..., None])[..., 0]
