@@ -2130,6 +2130,51 @@ def test_cvi_classic_elbo_site_gradient_vanishes_at_optimum(amd, rng, kname):
         np.testing.assert_allclose(got, fd, rtol=1e-6 if kname == "m12" else 1e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("kname", ["m32", "m52", "sum"])
+def test_cvi_classic_elbo_kernel_hyperparameter_gradient(amd, rng, kname):
+    """The gradient of classic_elbo with respect to the KERNEL's hyper-parameters through the tape (the reference differentiates its
+    models through the banded ops with a GradientTape over every trainable variable, tests/integration/models/test_variational_cvi.py:93-110;
+    its own test freezes the kernel, so the known answer used here is ours): with a Gaussian likelihood the optimal sites (y / s2, -1/2 / s2)
+    do not depend on the kernel and classic_elbo at them IS the GPR log marginal likelihood for every hyper-parameter value, so
+    d classic_elbo / d (lengthscale, variance) at fixed optimal sites = the derivative of the oracle's gpr_log_likelihood (fourth-order
+    difference quotient)."""
+    import torch
+    from oracle import np_kernels
+    from vidp_amd import kernels as K
+    from vidp_amd.likelihoods import Gaussian
+    from vidp_amd.variational_cvi import CVIGaussianProcess
+    hyp = {"m32": [(1.1, 0.7)], "m52": [(0.9, 1.3)], "sum": [(1.4, 0.6), (0.5, 1.2)]}[kname]
+
+    def mk(mod, h):
+        if kname == "m32":
+            return mod.Matern32(*h[0])
+        if kname == "m52":
+            return mod.Matern52(*h[0])
+        return mod.Sum([mod.Matern32(*h[0]), mod.Matern12(*h[1])])
+    # evenly spaced points: with gaps of ~0.5 lengthscales the prior's natural parameters are O(10); at the tiny random gaps of the other
+    # CVI tests they reach 1e7 and the O(1) total derivative is what is left of terms that size cancelling (3e-5 relative on the
+    # Matern-3/2 case -- the conditioning of differentiating in natural parameters, in the reference's tape as much as here)
+    t = np.linspace(0.0, 5.0, 10) + 0.05 * rng.uniform(-1, 1, size=10)
+    y = np.sin(2 * t)[:, None] + 0.1 * rng.normal(size=(10, 1))
+    noise = 0.4
+    g = CVIGaussianProcess((dev(t), dev(y)), mk(K, hyp), Gaussian(noise), learning_rate=1.0)
+    g.update_sites()
+    elbo, leaves = g.classic_elbo_tape_hyper()
+    ref = lambda h: np_models.gpr_log_likelihood(t, y, mk(np_kernels, h), noise)
+    np.testing.assert_allclose(float(elbo.detach()), ref(hyp), rtol=1e-8)
+    flat = [leaves] if isinstance(leaves, dict) else leaves
+    names = [(c, n) for c in range(len(flat)) for n in ("lengthscale", "variance")]
+    grads = torch.autograd.grad(elbo, [flat[c][n] for c, n in names])
+    for (c, n), gr in zip(names, grads):
+        def at(e):
+            h = [list(x) for x in hyp]
+            h[c][0 if n == "lengthscale" else 1] += e
+            return ref([tuple(x) for x in h])
+        e = 1e-3
+        fd = (8 * (at(e) - at(-e)) - (at(2 * e) - at(-2 * e))) / (12 * e)
+        np.testing.assert_allclose(float(gr), fd, rtol=1e-6, atol=1e-8)
+
+
 @pytest.mark.parametrize("kind", ["vanderpol", "vanderpol_fullq", "mlp", "doublewell_fullq"])
 def test_cvi_sites_sde_coupled_drifts(amd, rng, kind):
     """The drifts that couple the state dimensions / have no polynomial form (markovflow/sde/sde.py:359-518: VanderPolOscillatorSDE,

@@ -166,6 +166,57 @@ class StationaryKernel:
         Q = Pinf - A @ Pinf @ A.transpose(-1, -2) + self.jitter * torch.eye(d, dtype=dt.dtype, device=dt.device)
         return A, Q
 
+    # -- hyper-parameters as leaves of a torch graph (the reference differentiates classic_elbo through the kernel's tf.Variables with a
+    #    GradientTape, tests/integration/models/test_variational_cvi.py:93-110) ------------------------------------------------------------
+    def hyperparameter_leaves(self, device="cpu"):
+        """{name: 0-dim tensor with requires_grad} of this kernel's trainable hyper-parameters (a list of such dicts for a Sum)."""
+        raise NotImplementedError
+
+    def _components_t(self, leaves):
+        """[(order, lam, var)] with lam / var torch expressions of the leaves (the differentiable twin of _components)."""
+        raise NotImplementedError
+
+    def differentiable_ssm(self, time_points, leaves=None, plan=None):
+        """(tape.TapeSSM, leaves): the prior state-space model at the sorted time points [T] (one chain) as a differentiable function of
+        the hyper-parameter leaves -- the closed forms of k_stationary_ssm (A = e^{-lam dt}(I + N dt + N^2 dt^2 / 2), Q = Pinf - A Pinf A^T
+        + jitter) in torch, d <= 8; everything sequential in time downstream (marginals, log-determinants) goes through vidp_amd.tape,
+        i.e. the HIP sweeps with exact backward passes."""
+        from . import tape
+        t = time_points.reshape(-1)
+        dev = t.device
+        if leaves is None:
+            leaves = self.hyperparameter_leaves(dev)
+        dt = (t[1:] - t[:-1])[:, None, None]
+        d = self.state_dim
+        A = torch.zeros((t.numel() - 1, d, d), dtype=torch.float64, device=dev)
+        Pinf = torch.zeros((d, d), dtype=torch.float64, device=dev)
+        o = 0
+        for order, lam, var in self._components_t(leaves):
+            ex = torch.exp(-lam * dt)
+            eye = torch.eye(order, dtype=torch.float64, device=dev)
+            one, zero = torch.ones_like(lam), torch.zeros_like(lam)
+            if order == 1:
+                blk, pinf = ex * eye, var.reshape(1, 1)
+            elif order == 2:
+                N = torch.stack([torch.stack([lam, one]), torch.stack([-lam ** 2, -lam])])
+                blk = ex * (eye + N * dt)
+                pinf = var * torch.stack([torch.stack([one, zero]), torch.stack([zero, lam ** 2])])
+            else:
+                N = torch.stack([torch.stack([lam, one, zero]), torch.stack([zero, lam, one]),
+                                 torch.stack([-lam ** 3, -3.0 * lam ** 2, -2.0 * lam])])
+                blk = ex * (eye + N * dt + (N @ N) * (0.5 * dt * dt))
+                l23 = lam ** 2 / 3.0
+                pinf = var * torch.stack([torch.stack([one, zero, -l23]), torch.stack([zero, l23, zero]), torch.stack([-l23, zero, lam ** 4])])
+            A = A + torch.nn.functional.pad(blk, (o, d - o - order, o, d - o - order))
+            Pinf = Pinf + torch.nn.functional.pad(pinf, (o, d - o - order, o, d - o - order))
+            o += order
+        jit = self.jitter * torch.eye(d, dtype=torch.float64, device=dev)
+        Q = Pinf - A @ Pinf @ A.transpose(-1, -2) + jit
+        m = self.state_mean.to(dev)
+        b = m - (A @ m[:, None])[..., 0]
+        ssm = tape.TapeSSM(m[None], tape.cholesky(Pinf + jit)[None], A[None], b[None], tape.cholesky(0.5 * (Q + Q.transpose(-1, -2)))[None], plan=plan)
+        return ssm, leaves
+
     def initial_mean(self, batch_shape=()):
         return self.state_mean.expand(tuple(batch_shape) + (self.state_dim,))
 
@@ -200,6 +251,13 @@ class Matern12(StationaryKernel):
     def _components(self):
         return [(1, 1.0 / self.lengthscale, self.variance)]
 
+    def hyperparameter_leaves(self, device="cpu"):
+        mk = lambda v: torch.tensor(float(v), dtype=torch.float64, device=device, requires_grad=True)
+        return {"lengthscale": mk(self.lengthscale), "variance": mk(self.variance)}
+
+    def _components_t(self, leaves):
+        return [(1, 1.0 / leaves["lengthscale"], leaves["variance"])]
+
 
 class OrnsteinUhlenbeck(StationaryKernel):
     """matern.py:130-234: decay lambda, diffusion q, Pinf = q / (2 lambda)."""
@@ -212,6 +270,13 @@ class OrnsteinUhlenbeck(StationaryKernel):
 
     def _components(self):
         return [(1, self.decay, self.diffusion / (2.0 * self.decay))]
+
+    def hyperparameter_leaves(self, device="cpu"):
+        mk = lambda v: torch.tensor(float(v), dtype=torch.float64, device=device, requires_grad=True)
+        return {"decay": mk(self.decay), "diffusion": mk(self.diffusion)}
+
+    def _components_t(self, leaves):
+        return [(1, leaves["decay"], leaves["diffusion"] / (2.0 * leaves["decay"]))]
 
 
 class Matern32(StationaryKernel):
@@ -226,6 +291,13 @@ class Matern32(StationaryKernel):
     def _components(self):
         return [(2, math.sqrt(3.0) / self.lengthscale, self.variance)]
 
+    def hyperparameter_leaves(self, device="cpu"):
+        mk = lambda v: torch.tensor(float(v), dtype=torch.float64, device=device, requires_grad=True)
+        return {"lengthscale": mk(self.lengthscale), "variance": mk(self.variance)}
+
+    def _components_t(self, leaves):
+        return [(2, math.sqrt(3.0) / leaves["lengthscale"], leaves["variance"])]
+
 
 class Matern52(StationaryKernel):
     """matern.py:376-520."""
@@ -238,6 +310,13 @@ class Matern52(StationaryKernel):
 
     def _components(self):
         return [(3, math.sqrt(5.0) / self.lengthscale, self.variance)]
+
+    def hyperparameter_leaves(self, device="cpu"):
+        mk = lambda v: torch.tensor(float(v), dtype=torch.float64, device=device, requires_grad=True)
+        return {"lengthscale": mk(self.lengthscale), "variance": mk(self.variance)}
+
+    def _components_t(self, leaves):
+        return [(3, math.sqrt(5.0) / leaves["lengthscale"], leaves["variance"])]
 
 
 class Sum(StationaryKernel):
@@ -256,6 +335,15 @@ class Sum(StationaryKernel):
         out = []
         for k in self.kernels:
             out.extend(k._components())
+        return out
+
+    def hyperparameter_leaves(self, device="cpu"):
+        return [k.hyperparameter_leaves(device) for k in self.kernels]
+
+    def _components_t(self, leaves):
+        out = []
+        for k, lv in zip(self.kernels, leaves):
+            out.extend(k._components_t(lv))
         return out
 
     def _spec(self):

@@ -334,6 +334,21 @@ class _TapeChain:
         return 0.5 * (tr + mh - dim + 2.0 * pp["sumlogchol"] + self.log_det_precision())
 
 
+def kl_divergence_tape(q, p):
+    """KL(q || p) for two differentiable chains (state_space_model.py:528-593), differentiable in BOTH: p's precision blocks and
+    log-determinant are torch expressions of its parameters (e.g. a TapeSSM built from kernel hyper-parameter leaves,
+    kernels.StationaryKernel.differentiable_ssm), q's marginals go through the HIP sweeps with their exact backward pass."""
+    _, pdiag, psub = p.naturals()
+    Pd, Ps = -2.0 * pdiag, -psub                               # precision blocks: diagonal -2 theta_diag, sub-diagonal -theta_sub
+    mu, cov = q.marginals
+    sub = q.subsequent_covariances()
+    dm = mu - p.marginal_means
+    tr = (Pd * cov).sum(dim=(-1, -2, -3)) + 2.0 * (Ps * sub).sum(dim=(-1, -2, -3))
+    mh = ((dm[..., None, :] @ Pd @ dm[..., :, None]).sum(dim=(-1, -2, -3))
+          + 2.0 * (dm[:, 1:, None, :] @ Ps @ dm[:, :-1, :, None]).sum(dim=(-1, -2, -3)))
+    return 0.5 * (tr + mh - float(q.T * q.d) - p.log_det_precision() + q.log_det_precision())
+
+
 class TapeNaturals(_TapeChain):
     """A chain given by NATURAL parameters that are nodes of a torch graph -- e.g. the CVI posterior  prior naturals + back-projected
     sites  (variational_cvi.py:106-135) with the sites as leaves: what the reference differentiates in

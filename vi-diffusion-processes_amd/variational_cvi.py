@@ -251,6 +251,27 @@ class CVIGaussianProcess(GaussianProcessWithSitesBase):
         ve = self._likelihood.variational_expectations(fmu, fvar, obs).sum()
         return ve - q.kl_divergence(ssm).sum(), (n1, n2)
 
+    def classic_elbo_tape_hyper(self, leaves=None):
+        """classic_elbo as a differentiable function of the KERNEL's hyper-parameters (the sites held fixed): (elbo, leaves) with leaves
+        the kernel's hyperparameter_leaves -- what the reference gets from a GradientTape over the kernel's tf.Variables
+        (tests/integration/models/test_variational_cvi.py:93-110 with the kernel not frozen).  One chain; d <= 8."""
+        from . import tape
+        ssm = self.dist_p
+        pl, T, d = ssm.plan, ssm.T, ssm.d
+        if ssm.B != 1 or d > 8:
+            raise NotImplementedError("the hyper-parameter tape runs on one chain with state dimension <= 8")
+        p, leaves = self._kernel.differentiable_ssm(self._time_points, leaves, plan=pl)
+        plin, pdiag, psub = p.naturals()
+        H = self._emission().emission_matrix
+        bp1, bp2 = back_project_nats(self.sites.nat1.detach(), self.sites.nat2.detach()[..., 0], H)
+        q = tape.TapeNaturals(plin + bp1.reshape(1, T, d), pdiag + bp2.reshape(1, T, d, d), psub, pl)
+        mu, cov = q.marginals
+        Hb = H.reshape(1, T, H.shape[-2], d)
+        fmu = (Hb @ mu[..., None])[..., 0]
+        fvar = torch.diagonal(Hb @ cov @ Hb.transpose(-1, -2), dim1=-2, dim2=-1)
+        ve = self._likelihood.variational_expectations(fmu, fvar, self._observations.reshape(1, T, -1)).sum()
+        return ve - tape.kl_divergence_tape(q, p).sum(), leaves
+
     def step_graph(self):
         """`update_sites(); elbo()` -- the inner loop of CVI (variational_cvi.py:351-379) -- captured ONCE in a HIP graph: returns a
         callable that replays it and hands back the ELBO (a device scalar that every replay overwrites).  On one chain the step is a
