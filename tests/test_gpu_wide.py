@@ -628,9 +628,12 @@ def test_sparse_cvi_one_chain_sharded(amd, rng, M, world):
     assert covered == M + 1
 
 
-def test_sparse_cvi_one_chain_two_processes():
-    """The sharded model through a real process group: 2 ranks (gloo, rendezvous on 127.0.0.1) sharing the one GPU; each checks its
-    ELBO sequence and owned sites against a whole-chain model run locally (tests/mp_sparse_shard.py)."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_sparse_cvi_one_chain_two_processes(world):
+    """The sharded model through a real process group: 2 and 4 ranks (gloo, rendezvous on 127.0.0.1) sharing the one GPU (at most 6
+    processes may use it together); each checks its ELBO sequence and owned sites against a whole-chain model run locally
+    (tests/mp_sparse_shard.py).  With 4 ranks the exchange level has about one node per rank and the interior ranks have a neighbour on
+    both sides -- what a 2-rank run never exercises."""
     import os
     import socket
     import subprocess
@@ -640,7 +643,7 @@ def test_sparse_cvi_one_chain_two_processes():
     with socket.socket() as sk:          # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "mp_sparse_shard.py")]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
