@@ -233,23 +233,29 @@ def vdp_step_rate(B, T, d, dt, noise, idx, ys, device, steps=10):
 
 def pmc_traffic(kernel_name, B, T, d, build):
     """(HBM bytes per launch of `kernel_name`, source note) from the committed rocprofv3 PMC passes of this bench
-    (profiles/r03_pmc/pmc_traffic.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, read side doubled as the gfx950 guide
-    prescribes).  The figure is archival, not measured by this run: it is used only when the file was collected on THIS build of the
-    library (mfgm_version()) and this workload size; otherwise (None, why)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            prof = json.load(fh)
-    except (OSError, ValueError):
-        return None, "no PMC profile committed"
-    if prof.get("workload") != {"B": B, "T": T, "d": d}:
-        return None, "the committed PMC profile is for another workload size"
-    if prof.get("library_build") != build:
-        return None, f"the committed PMC profile was collected on library build {prof.get('library_build')!r}, this is {build!r}"
-    try:
-        return float(prof["kernels"][kernel_name]["hbm_bytes_per_launch"]), f"profiles/r03_pmc/pmc_traffic.json (build {build})"
-    except KeyError:
-        return None, "kernel not in the committed PMC profile"
+    (profiles/rNN_pmc/pmc_traffic.json, newest round first: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, read side doubled as the
+    gfx950 guide prescribes).  The figure is archival, not measured by this run: it is used only when the file was collected on THIS
+    build of the library (mfgm_version()) and this workload size; otherwise (None, why)."""
+    import glob
+    why = "no PMC profile committed"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "pmc_traffic.json")), reverse=True):
+        rel = os.path.relpath(path, ROOT)
+        try:
+            with open(path) as fh:
+                prof = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if prof.get("workload") != {"B": B, "T": T, "d": d}:
+            why = "the committed PMC profile is for another workload size"
+            continue
+        if prof.get("library_build") != build:
+            why = f"the committed PMC profile ({rel}) was collected on library build {prof.get('library_build')!r}, this is {build!r}"
+            continue
+        try:
+            return float(prof["kernels"][kernel_name]["hbm_bytes_per_launch"]), f"{rel} (build {build})"
+        except KeyError:
+            why = f"kernel not in the committed PMC profile ({rel})"
+    return None, why
 
 
 class Harness:

@@ -4,6 +4,7 @@
 # behind roofline.traffic (headline, c3, c5) and the MFMA-utilisation pass of the config-5 sweeps.  Everything lands under
 # gpurun_out/ev/; copy what is to be judged into profiles/ (names per round).
 set -o pipefail
+ROUND=${ROUND:-r04}
 R=/root/repo
 O=$R/gpurun_out/ev
 mkdir -p $O
@@ -22,7 +23,7 @@ H="--steps 2 --warmup 1 --no-cpu-baseline --no-vdp --no-other-configs"
 pmc h_fetch FETCH_SIZE $H
 pmc h_write WRITE_SIZE $H
 python3 $R/tools/pmc_summarize.py $O/h_fetch_counter_collection.csv $O/h_write_counter_collection.csv 64 100000 6 "$V" > $O/pmc_traffic.json
-mkdir -p $R/profiles/r03_pmc && cp $O/pmc_traffic.json $R/profiles/r03_pmc/pmc_traffic.json   # bench.py reads roofline.traffic from it
+mkdir -p $R/profiles/${ROUND}_pmc && cp $O/pmc_traffic.json $R/profiles/${ROUND}_pmc/pmc_traffic.json   # bench.py reads roofline.traffic from it
 for c in c3 c5; do
     pmc ${c}_fetch FETCH_SIZE --config $c --steps 2 --warmup 1 --no-cpu-baseline
     pmc ${c}_write WRITE_SIZE --config $c --steps 2 --warmup 1 --no-cpu-baseline

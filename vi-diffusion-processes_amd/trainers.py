@@ -264,6 +264,10 @@ class CVISitesTrainer:
             self.model.update_data_sites(self.data_sites_lr)
             self.model.update_girsanov_sites(self.girsanov_sites_lr)
             el, nl, rm = self._elbo_nlpd_rmse()
+            if not math.isfinite(el):
+                # the sweeps do not synchronise the host: a pivot block that is not positive definite surfaces as a NaN bound, and a NaN
+                # compares as "not worse" in the rules below -- raise with the failing location instead of iterating on it
+                self.model.plan.check_info()
             elbos.append(el)
             nlpds.append(nl)
             rmses.append(rm)
