@@ -1563,6 +1563,7 @@ def test_cvi_dp_pipelined_steps_equal_unpipelined(amd, rng):
         m = CVISitesSDE(gsde.DoubleWellSDE(torch.eye(d, dtype=torch.float64)), grid, (grid[idx], dev(y)), MultivariateGaussian(dev(cholR)),
                         prior_initial_state=(np.zeros(d), np.eye(d)), plan=amd.Plan(B, T, d, R0=20, Rup=4))
         m.pipelined = pipe
+        m.pipeline_min_nodes = 0          # (the model pipelines from 200 000 nodes on: this chain is short)
         return m
     a, b = make(False), make(True)
     assert b._cq_state() is not None

@@ -9,6 +9,7 @@ R=/root/repo
 O=$R/gpurun_out/ev
 mkdir -p $O
 cd $R
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee $O/smoke_rc.txt
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $O/pytest_rc.txt
 python -c "import vidp_amd; print(vidp_amd._lib.load().mfgm_version().decode())" 2>/dev/null > $O/version.txt
 V="$(cat $O/version.txt)"

@@ -544,6 +544,9 @@ class CVISitesSDE(CVISitesSSM):
     # tensors, and anything that does not match (another learning rate, a re-linearisation, sites assigned by hand) simply finds no
     # record and runs the reduce itself.  Results are bit-identical either way (the record holds the numbers the reduce would write).
     pipelined = os.environ.get("VIDP_PIPELINE", "1") != "0"
+    # below this many nodes (B T) a level-0 reduce is a few microseconds: the second stream's event round trips would cost more than
+    # they hide (config 1, T = 1001: 0.133 -> 0.174 ms with it)
+    pipeline_min_nodes = 200000
     _pre = None           # the record of a separator system made ahead (dict), None when there is none
 
     def _pipe_sites_gradient(self):
@@ -657,7 +660,8 @@ class CVISitesSDE(CVISitesSSM):
         lazy = obs and not want_marginals and os.environ.get("VIDP_LAZY_MARGINALS", "1") != "0"
         if self._q is None:
             nxt = None
-            if self.pipelined and obs and getattr(self, "_pipe_lr", None) is not None and self._sde_prm.kind == 0:
+            if (self.pipelined and obs and getattr(self, "_pipe_lr", None) is not None and self._sde_prm.kind == 0
+                    and self.B * self.T >= self.pipeline_min_nodes):
                 # the level-0 reduce of the next step's first factorisation rides next to this factorisation's forward sweep
                 self._pipe_drop()
                 lin, sym = self._pipe_predict(cq)
