@@ -196,3 +196,23 @@ def test_no_shadowed_test_functions():
             if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
                 assert node.name not in seen, f"{os.path.basename(path)}: {node.name} defined at lines {seen[node.name]} and {node.lineno}"
                 seen[node.name] = node.lineno
+
+
+def test_general_inverse():
+    """linalg.general_inverse / small_inverse (cofactors for d <= 3, Gauss-Jordan with partial pivoting above) on non-symmetric blocks,
+    including ones whose leading entry is zero (pivoting needed)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(here, "vi-diffusion-processes_amd", "linalg.py")).read()
+    ns = {"torch": torch}
+    exec(src[src.index("def small_inverse"):], ns)          # the two functions are plain torch: no GPU library needed
+    g = torch.Generator().manual_seed(3)
+    for d in (1, 2, 3, 4, 6, 8):
+        M = torch.randn(5, d, d, generator=g, dtype=torch.float64) + 2.0 * torch.eye(d, dtype=torch.float64)
+        if d > 1:
+            M[0, 0, 0] = 0.0
+        X = ns["general_inverse"](M)
+        np.testing.assert_allclose((X @ M).numpy(), np.broadcast_to(np.eye(d), (5, d, d)), atol=1e-11)
+        np.testing.assert_allclose(X.numpy(), np.linalg.inv(M.numpy()), rtol=1e-9, atol=1e-11)
+

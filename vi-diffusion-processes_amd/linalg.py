@@ -115,3 +115,32 @@ def small_inverse(M):
     adj = torch.stack([torch.stack([cof[j][i] for j in range(3)], -1) for i in range(3)], -2)
     return adj / det[..., None, None]
 
+
+def general_inverse(M):
+    """Inverse of GENERAL square blocks [..., d, d] by Gauss-Jordan elimination with partial pivoting, written with element-wise /
+    gather torch operations (batched over the leading axes; d steps).  For the handful of small non-symmetric systems of the models --
+    `tf.linalg.inv(P0^{-1} + 2 psi(0))` of VDP's update_initial_statistics (vi_sde.py:241-260): psi is not symmetric, the Lagrange sweep
+    adds psi A + psi A -- where the SPD kernels (mfgm_batched_cholesky) do not apply."""
+    d = M.shape[-1]
+    if d <= 3:
+        return small_inverse(M)
+    shape = M.shape
+    A = M.reshape(-1, d, d).clone()
+    n = A.shape[0]
+    X = torch.eye(d, dtype=A.dtype, device=A.device).expand(n, d, d).clone()
+    rows = torch.arange(n, device=A.device)
+    for k in range(d):
+        piv = A[:, k:, k].abs().argmax(dim=1) + k                     # [n]
+        # swap rows k and piv
+        for T_ in (A, X):
+            rk, rp = T_[rows, k].clone(), T_[rows, piv].clone()
+            T_[rows, k], T_[rows, piv] = rp, rk
+        inv = 1.0 / A[:, k, k]
+        A[:, k] = A[:, k] * inv[:, None]
+        X[:, k] = X[:, k] * inv[:, None]
+        f = A[:, :, k].clone()
+        f[:, k] = 0.0
+        A = A - f[:, :, None] * A[:, k][:, None, :]
+        X = X - f[:, :, None] * X[:, k][:, None, :]
+    return X.reshape(shape)
+

@@ -327,10 +327,12 @@ class VariationalMarkovGP:
         P0 = torch.from_numpy(self.p0_cov).to(self.device)
         mu0 = torch.from_numpy(self.p0_mu).to(self.device)
         mean = mu0 - (P0 @ lam0[..., None])[..., 0]
-        cov = linalg.spd_inverse(linalg.spd_inverse(P0) + 2.0 * psi0)
+        # psi is not symmetric (the sweep adds psi A + psi A): a general inverse, as the reference's tf.linalg.inv (the SPD inverse used
+        # until round 3 read the lower triangle only)
+        cov = linalg.general_inverse(linalg.spd_inverse(P0) + 2.0 * psi0)
         q0_cov = self.q0_chol @ self.q0_chol.transpose(-1, -2)
         self.q0_mu = (1 - lr) * self.q0_mu + lr * mean
-        self.q0_chol = linalg.cholesky((1 - lr) * q0_cov + lr * cov)
+        self.q0_chol = linalg.cholesky(((1 - lr) * q0_cov + lr * cov).contiguous())
 
     def KL_initial_state(self):
         """KL[q(x0) || p(x0)] per trajectory (vi_sde.py:416-420)."""
@@ -535,7 +537,7 @@ class VariationalMarkovGPQuadrature(VariationalMarkovGP):
         mu0 = torch.from_numpy(self.p0_mu).to(self.device)
         mean = mu0 - (P0 @ lam0[..., None])[..., 0]
         # psi is not symmetric (the sweep adds psi A + psi A): a general inverse, as the reference's tf.linalg.inv
-        cov = linalg.small_inverse(linalg.spd_inverse(P0) + 2.0 * psi0)
+        cov = linalg.general_inverse(linalg.spd_inverse(P0) + 2.0 * psi0)
         q0_cov = self.q0_chol @ self.q0_chol.transpose(-1, -2)
         self.q0_mu = (1 - lr) * self.q0_mu + lr * mean
         self.q0_chol = linalg.cholesky(((1 - lr) * q0_cov + lr * cov).contiguous())
