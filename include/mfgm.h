@@ -283,12 +283,15 @@ int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, dou
  * update_girsanov_sites, classic_elbo: two factorisations per step).  Under a Gaussian likelihood the data sites of the NEXT step do not
  * depend on q, so the state the first factorisation of step n + 1 will see -- dyn / offsets as they are now, sites (q_next->site_lin,
  * q_next->site_sym) -- is known while the second factorisation of step n runs.
- *   q_next + side_stream: once the coarse levels of THIS factorisation are done, the level-0 reduce of q_next is launched on
- *     side_stream, next to this call's bandwidth-bound level-0 forward sweep (the two kernels share the SIMDs: 193 + 256 registers);
- *     its separator system goes to the second copy of the level-1 input region the workspace of such plans holds;
+ *   q_next (with observation sites): the level-0 reduce of q_next is made next to this call's bandwidth-bound level-0 forward sweep and
+ *     its separator system goes to the second copy of the level-1 input region the workspace of such plans holds.
+ *       side_stream == NULL: ONE kernel, two wavefronts per tile -- the forward sweep and the reduce of the same records (read from HBM
+ *         once; the reduce's spike and Gram accumulators live in LDS so that both wavefronts fit 256 registers);
+ *       side_stream != NULL: the reduce as a kernel of its own on side_stream, started once the coarse levels of this factorisation are
+ *         done (the two kernels share the SIMDs: 193 + 302 registers; the records are read twice);
  *   use_ahead != 0: the record the previous pipelined call on this plan made was for EXACTLY the state q (the caller's
- *     responsibility): the level-0 reduce of this call is skipped, `stream` waits for the work queued on side_stream, and the coarse
- *     levels read the record in place (nothing is copied: the two copies of the region swap roles).
+ *     responsibility): the level-0 reduce of this call is skipped, `stream` waits for the work queued on side_stream (if given), and the
+ *     coarse levels read the record in place (nothing is copied: the two copies of the region swap roles).
  * Results are those of mfgm_cq_factor (the record holds the same numbers the level-0 reduce would write). */
 int mfgm_cq_factor_pipelined(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
                              int* info, int use_ahead, const mfgm_cq_state* q_next, void* side_stream, void* stream);

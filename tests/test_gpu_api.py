@@ -1544,9 +1544,11 @@ def test_full_size_steps_against_the_c_port(amd):
         np.testing.assert_allclose(got[k], sv.elbo, rtol=1e-9)
 
 
-def test_cvi_dp_pipelined_steps_equal_unpipelined(amd, rng):
-    """The cross-step pipelining of CVISitesSDE (the level-0 reduce of the next step's first factorisation made ahead, on a second
-    stream, by mfgm_cq_factor_pipelined) against the same model with it switched off: ELBO after every step of a loop that keeps its
+@pytest.mark.parametrize("streams", [False, True])
+def test_cvi_dp_pipelined_steps_equal_unpipelined(amd, rng, streams):
+    """The cross-step pipelining of CVISitesSDE (the level-0 reduce of the next step's first factorisation made ahead by
+    mfgm_cq_factor_pipelined: as the second wavefront of the forward sweep's workgroups, k_forward_reduce_cq, or on a second stream,
+    k_reduce_cq_lean) against the same model with it switched off: ELBO after every step of a loop that keeps its
     learning rates (records are consumed), changes them (a record is dropped), re-linearises, evaluates the ELBO twice and updates
     the Girsanov sites twice in a row -- equal to rounding of the last bit (the record holds the numbers the reduce would write)."""
     import torch
@@ -1566,6 +1568,7 @@ def test_cvi_dp_pipelined_steps_equal_unpipelined(amd, rng):
         m.pipeline_min_nodes = 0          # (the model pipelines from 200 000 nodes on: this chain is short)
         return m
     a, b = make(False), make(True)
+    b.pipe_two_streams = streams          # the reduce made ahead: second wavefront of the forward kernel / kernel of its own on a second stream
     assert b._cq_state() is not None
     prog = [("s", 0.5, 0.1)] * 4 + [("s", 0.3, 0.1)] * 2 + [("r",)] + [("s", 0.3, 0.2)] * 2 + [("e",), ("g", 0.1), ("s", 0.3, 0.2), ("s", 0.3, 0.2)]
     got, want, used = [], [], 0

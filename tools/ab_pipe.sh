@@ -1,10 +1,13 @@
 #!/bin/bash
-# A/B of the cross-step pipelining on one box: pipelined vs VIDP_PIPELINE=0 bench lines + a kernel trace of the pipelined run.
-# usage (through gpurun, from the repo root): bash tools/ab_pipe.sh
+# A/B of the cross-step pipelining on one box: the two-wavefront kernel (default), the two-stream form (VIDP_PIPE_STREAMS=1) and no
+# pipelining (VIDP_PIPELINE=0), bench lines + a kernel trace of the default run.   usage (through gpurun): bash tools/ab_pipe.sh
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_api.py -x -q -k "pipelined or full_size_steps" > gpurun_out/r04_t2.log 2>&1; tail -3 gpurun_out/r04_t2.log
-python bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-other-configs > gpurun_out/r04_b2.json 2> gpurun_out/r04_b2.err
-VIDP_PIPELINE=0 python bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-other-configs > gpurun_out/r04_b2_nopipe.json 2>> gpurun_out/r04_b2.err
-R=$PWD; cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r04_prof2 -o p -- python3 $R/bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
-ls $R/gpurun_out/r04_prof2
+A="--steps 20 --warmup 10 --no-cpu-baseline --no-other-configs --no-vdp"
+for round in 1 2; do
+python bench.py $A > gpurun_out/r04_ab_fused_$round.json 2> gpurun_out/r04_ab.err
+VIDP_PIPE_STREAMS=1 python bench.py $A > gpurun_out/r04_ab_streams_$round.json 2>> gpurun_out/r04_ab.err
+VIDP_PIPELINE=0 python bench.py $A > gpurun_out/r04_ab_nopipe_$round.json 2>> gpurun_out/r04_ab.err
+done
+R=$PWD; cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $R/gpurun_out/r04_prof3 -o p -- python3 $R/bench.py $A > /dev/null 2>&1
+ls $R/gpurun_out/r04_prof3

@@ -306,9 +306,11 @@ int cq_factor_impl(const Plan& P0, const CqArgs& q, double* Lg, double* yg, doub
     bind_up(P, 0, ws, a0);
     dim3 grid(a0.lv.Lpad / 64), block(64);
     if (pipe && pipe->use_ahead) {
-        // the separator system of this state was made ahead, on the side stream, in the region bound above: wait for it
-        if (hipEventRecord(pipe->owner->ev[1], pipe->side) != hipSuccess) return 3;
-        if (hipStreamWaitEvent(st, pipe->owner->ev[1], 0) != hipSuccess) return 3;
+        // the separator system of this state was made ahead in the region bound above; when that happened on a side stream: wait for it
+        if (pipe->side) {
+            if (hipEventRecord(pipe->owner->ev[1], pipe->side) != hipSuccess) return 3;
+            if (hipStreamWaitEvent(st, pipe->owner->ev[1], 0) != hipSuccess) return 3;
+        }
     } else if (only_stage < 0 || only_stage == 0) {
         hipLaunchKernelGGL((k_reduce_cq<D>), grid, block, 0, st, a0, q);
         MFGM_CHECK_LAUNCH();
@@ -330,9 +332,43 @@ int cq_factor_impl(const Plan& P0, const CqArgs& q, double* Lg, double* yg, doub
             if (rc) return rc;
         }
     }
+    if (pipe && pipe->next && !pipe->side && D > 6) {
+        // d = 7, 8: the two-wavefront kernel does not fit 256 registers; without a side stream the reduce made ahead simply follows the
+        // forward sweep on this stream (correct, nothing overlapped)
+        SweepArgs an = a0;
+        bind_up(with_l1_region(P0, 1 - region), 0, ws, an);
+        pipe->owner->ahead_region = 1 - region;
+        an.part = nullptr;
+        hipLaunchKernelGGL((k_forward_cq<D>), grid, block, 0, st, a0, q);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL((k_reduce_cq_lean<D>), grid, block, 0, st, an, *pipe->next);
+        MFGM_CHECK_LAUNCH();
+        if (only_stage < 0 && (logdet || quad)) {
+            hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
+            MFGM_CHECK_LAUNCH();
+        }
+        return 0;
+    }
+    if (pipe && pipe->next && !pipe->side) {
+        // forward sweep of this factorisation and level-0 reduce of the NEXT one as the two wavefronts of one workgroup per tile
+        // (k_forward_reduce_cq): the records are read from HBM once; the reduce's separator system goes to the other level-1 region
+        SweepArgs an = a0;
+        bind_up(with_l1_region(P0, 1 - region), 0, ws, an);
+        pipe->owner->ahead_region = 1 - region;
+        CqArgs qf = q;
+        qf.site_lin2 = pipe->next->site_lin; qf.site_sym2 = pipe->next->site_sym;
+        qf.pre_Dhat = an.uDhat; qf.pre_Rsub = an.uRsub; qf.pre_S = an.uS; qf.pre_rhat = an.urhat; qf.pre_rho = an.urho;
+        hipLaunchKernelGGL((k_forward_reduce_cq<D>), grid, dim3(128), 0, st, a0, qf);
+        MFGM_CHECK_LAUNCH();
+        if (only_stage < 0 && (logdet || quad)) {
+            hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
+            MFGM_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     if (pipe && pipe->next) {
-        // the level-0 reduce of the NEXT factorisation's state, into pre_out, on the side stream: from here on the main stream runs
-        // the bandwidth-bound level-0 forward sweep (193 registers), next to whose wavefronts the lean reduce (256) fits on every SIMD
+        // the level-0 reduce of the NEXT factorisation's state, into the other level-1 region, on the side stream: from here on the main
+        // stream runs the bandwidth-bound level-0 forward sweep (193 registers), next to whose wavefronts the lean reduce (302) fits
         if (hipEventRecord(pipe->owner->ev[0], st) != hipSuccess) return 3;
         if (hipStreamWaitEvent(pipe->side, pipe->owner->ev[0], 0) != hipSuccess) return 3;
         SweepArgs an = a0;
@@ -615,8 +651,8 @@ int mfgm_cq_factor(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, dou
 int mfgm_cq_factor_pipelined(const mfgm_plan* plan, const mfgm_cq_state* q, double* L, double* y, double* logdet, double* quad, void* ws,
                              int* info, int use_ahead, const mfgm_cq_state* q_next, void* side_stream, void* stream) {
     if (!cq_ok(plan, q) || !L || !y || !ws || !info || plan->p.off_alt == 0) return 1;
-    if ((use_ahead || q_next) && (!side_stream || side_stream == stream)) return 1;
-    if (q_next && !cq_ok(plan, q_next)) return 1;
+    if (side_stream && side_stream == stream) return 1;
+    if (q_next && (!cq_ok(plan, q_next) || !q_next->slot)) return 1;
     const Plan& P = plan->p;
     for (int i = 0; i < 2; ++i)
         if (!plan->ev[i] && hipEventCreateWithFlags(&plan->ev[i], hipEventDisableTiming) != hipSuccess) return 3;

@@ -32,6 +32,11 @@ struct CqArgs {
     double* dyn_out;          // Girsanov sweep: the updated dyn (another buffer)
     double* obs_mu;           // KL sweep: marginal means / covariances at the observation nodes, [n, D] / [n, D, D]; may be null
     double* obs_cov;
+    // k_forward_reduce_cq: the sweep's second wavefront makes the level-0 reduce of the NEXT factorisation -- the same dyn / offsets with
+    // the observation sites (site_lin2, site_sym2) -- and writes that separator system to the pre_* arrays (level-1 layout)
+    const double* site_lin2;
+    const double* site_sym2;
+    double* pre_Dhat; double* pre_Rsub; double* pre_S; double* pre_rhat; double* pre_rho;
 };
 
 // elements [E0, E0 + N) of a node with E doubles
@@ -354,12 +359,15 @@ MFGM_DEV void backward_p_step(const double (&Pm)[MFGM_NTRI(D)], const double (&s
 // ---- forward -------------------------------------------------------------------------------------------------------------------
 // forward_body<D, true, false, true> on the cq state (L_{t+1,t} is never stored).  A node's record is requested one step ahead; its
 // slot two steps ahead, so that the gather of the site's linear part rides with the record.
-template <int D>
-static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q) {
+// SYNC: the body runs as one wavefront of a two-wavefront workgroup (k_forward_reduce_cq) and meets the other one at a workgroup
+// barrier once per node, so that the two stay within a node of each other and the record either of them loads first is still in the
+// CU's L1 / the XCD's L2 when the other asks for it.
+#ifndef MFGM_CQ_SYNC_EVERY
+#define MFGM_CQ_SYNC_EVERY 2       // nodes between the barriers of k_forward_reduce_cq's two wavefronts (a power of two)
+#endif
+template <int D, bool SYNC>
+MFGM_DEV void forward_cq_body(const SweepArgs& a, const CqArgs& q, const int lane, const LaneRef me) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, E3 = 3 * D;
-    const int lane = blockIdx.x * 64 + threadIdx.x;
-    if (lane >= a.lv.L) return;
-    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -488,12 +496,209 @@ static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q)
             // carried to the next node: C = (aS S) P (aS S)^T, c = (aS S) z with S = diag(theta_sub) + sOff (1 1^T - I)
             cq_carry<D>(Pm, z, sdn, has_next ? a.aS : 0.0, q.sOff, C, c);
         }
+        if constexpr (SYNC) {
+            if ((s & (MFGM_CQ_SYNC_EVERY - 1)) == MFGM_CQ_SYNC_EVERY - 1) __syncthreads();
+        }
     }
     if (a.part) {
         a.part[lane] = la.value();
         a.part[Lp + lane] = quad;
     }
     if (bad) flag_not_pd(a.info, a.lv.level, lane);
+}
+template <int D>
+static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q) {
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.lv.L) return;
+    forward_cq_body<D, false>(a, q, lane, LaneRef{(int)blockIdx.x, (int)threadIdx.x});
+}
+
+// ---- forward sweep and the NEXT factorisation's reduce as two wavefronts of one workgroup ------------------------------------------------
+// (what k_forward_cq on one stream and k_reduce_cq_lean on a second do, without the second read of the records: the pair on two streams
+// moves 3.28 GB at the memory system's ceiling, 148 B per node of it the reduce re-reading what the forward sweep has just streamed.)
+// Measured (A/Bs on one box each, tools/ab_pipe.sh, tools/ab_lib.sh): 0.544-0.566 ms per launch whatever the box, against 0.40-0.46 ms
+// for the forward sweep alone and 0.53-0.57 for the two-stream pair; step -0.02 ... -0.03 ms against the two-stream form, -0.17 ... -0.20
+// against no pipelining.  SQ counters: each wavefront 45 % active, i.e. the SIMD's VALU issue ~90 % taken by the two together (1 570
+// instructions per node, 1 255 of them fp64): the kernel is bound by instruction issue now, not by the records' traffic.  Without the
+// per-node barriers the wavefronts drift apart and the second read goes to HBM again (0.592 ms); a second record in flight for the
+// forward wavefront changes nothing (0.566 against 0.563).
+// Wavefront 0 of a workgroup is the forward sweep of a tile, wavefront 1 the reduce of the same tile for the state (q.site_lin2,
+// q.site_sym2) -> q.pre_*.  Both must fit 256 registers (two wavefronts per SIMD): the forward body does (193); the reduce keeps what it
+// cannot -- the spike W, the Gram correction Racc, rho -- in LDS, [element][lane] (conflict-free 8-byte accesses, 32 KB per workgroup,
+// four workgroups per CU), and streams them through registers a column / an element at a time.
+template <int D>
+MFGM_DEV void reduce_cq_lds_body(const SweepArgs& a, const CqArgs& q, const int lane, const LaneRef me, double* __restrict__ lds,
+                                 const int l /* physical lane: the LDS slot */) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D, E3 = 3 * D;
+    const int P = a.lv.P, R = a.lv.R;
+    const int b = lane / P, p = lane - b * P;
+    const int len = min(R, a.lv.n - p * R);
+    const bool sites = (q.slot != nullptr);
+    double* ldsW = lds;                     // [EF][64]
+    double* ldsR = lds + EF * 64;           // [ET][64]
+    double* ldsr = ldsR + ET * 64;          // [D][64]
+    int bad = 0;
+    double F[ET], h[D], sdc[D];
+    {
+        double r0[E3];
+        ld_node<E3>(q.dyn, R, 0, me, r0);
+        const int s0 = sites ? cq_slot(q.slot, R, 0, me) : -1;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) F[tix(i, j)] = (i == j) ? r0[D + i] : q.dOff;
+#pragma unroll
+        for (int i = 0; i < D; ++i) { h[i] = r0[i]; sdc[i] = r0[2 * D + i]; }
+        if (s0 >= 0) {
+#pragma unroll
+            for (int e = 0; e < ET; ++e) F[e] += q.site_sym2[e];
+#pragma unroll
+            for (int i = 0; i < D; ++i) h[i] += q.site_lin2[(size_t)s0 * D + i];
+        }
+        if (p == 0 && q.p0off) {
+#pragma unroll
+            for (int e = 0; e < ET; ++e) F[e] += q.p0off[e];
+        }
+#pragma unroll
+        for (int e = 0; e < ET; ++e) F[e] *= a.aD;
+#pragma unroll
+        for (int i = 0; i < D; ++i) h[i] *= a.aR;
+        double sl_[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) sl_[i] = 0.0;
+        if (p > 0) ld_part<E3, 2 * D, D>(q.dyn, R, R - 1, LaneRef::of(lane - 1), sl_);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) ldsW[(i * D + j) * 64 + l] = (p > 0) ? a.aS * ((i == j) ? sl_[i] : q.sOff) : 0.0;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) ldsR[e * 64 + l] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) ldsr[i * 64 + l] = 0.0;
+    }
+    for (int s = 0; s < R; ++s) {
+        if (s < len - 1) {
+            // the record of node s + 1: the forward wavefront of the workgroup asks for the same lines in its iteration s + 1
+            double rc[E3], sl[D];
+            ld_node<E3>(q.dyn, R, s + 1, me, rc);
+            const int sc = sites ? cq_slot(q.slot, R, s + 1, me) : -1;
+            double invd[D];
+            chol_inplace<D>(F, invd, bad);
+            trsv_lower<D>(F, invd, h);                     // y := L^{-1} h
+            {
+                // W := L^{-1} W (all of it through registers once), Racc += W^T W and rho += W^T y element by element from / to LDS
+                double W[EF];
+#pragma unroll
+                for (int e = 0; e < EF; ++e) W[e] = ldsW[e * 64 + l];
+                trsm_left_lower<D>(F, invd, W);
+#pragma unroll
+                for (int e = 0; e < EF; ++e) ldsW[e * 64 + l] = W[e];
+                // (the accumulators come in as ONE batch of LDS reads: element by element each read-modify-write is a round trip of its
+                //  own, 27 dependent ones per node)
+                double Racc[ET], rho[D];
+#pragma unroll
+                for (int e = 0; e < ET; ++e) Racc[e] = ldsR[e * 64 + l];
+#pragma unroll
+                for (int i = 0; i < D; ++i) rho[i] = ldsr[i * 64 + l];
+                syrk_t_acc<D>(W, Racc);
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double t = rho[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = __builtin_fma(W[k * D + i], h[k], t);
+                    rho[i] = t;
+                }
+#pragma unroll
+                for (int e = 0; e < ET; ++e) ldsR[e * 64 + l] = Racc[e];
+#pragma unroll
+                for (int i = 0; i < D; ++i) ldsr[i * 64 + l] = rho[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double G[EF];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) G[i * D + j] = a.aS * ((i == j) ? sdc[i] : q.sOff);
+            trsm_right_lower_t<D>(F, invd, G);             // G := S L^{-T}
+            syrk_set<D>(G, F);
+#pragma unroll
+            for (int i = 0; i < D; ++i) sl[i] = 0.0;
+            if (sc >= 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) sl[i] = q.site_lin2[(size_t)sc * D + i];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double dn = (i == j) ? rc[D + i] : q.dOff;
+                    if (sc >= 0) dn += q.site_sym2[tix(i, j)];
+                    F[tix(i, j)] = __builtin_fma(a.aD, dn, -F[tix(i, j)]);
+                }
+            {                                              // W := -G W: W in as one batch, out column by column
+                double W[EF];
+#pragma unroll
+                for (int e = 0; e < EF; ++e) W[e] = ldsW[e * 64 + l];
+#pragma unroll
+                for (int c = 0; c < D; ++c)
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) t = __builtin_fma(G[i * D + k], W[k * D + c], t);
+                        ldsW[(i * D + c) * 64 + l] = -t;
+                    }
+            }
+            {
+                double t[D];
+                gemv<D>(G, h, t);
+#pragma unroll
+                for (int e = 0; e < D; ++e) h[e] = __builtin_fma(a.aR, rc[e] + sl[e], -t[e]);
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) sdc[i] = rc[2 * D + i];
+        }
+        if ((s & (MFGM_CQ_SYNC_EVERY - 1)) == MFGM_CQ_SYNC_EVERY - 1) __syncthreads();
+    }
+    double W[EF], Racc[ET], rho[D];
+#pragma unroll
+    for (int e = 0; e < EF; ++e) W[e] = ldsW[e * 64 + l];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) Racc[e] = ldsR[e * 64 + l];
+#pragma unroll
+    for (int i = 0; i < D; ++i) rho[i] = ldsr[i * 64 + l];
+    const int uP = a.up.P, uR = a.up.R;
+    {
+        const int qq = p, ul = b * uP + qq / uR, us = qq % uR;
+        st_node<ET, true>(q.pre_Dhat, uR, us, LaneRef::of(ul), F);
+        st_node<D, true>(q.pre_rhat, uR, us, LaneRef::of(ul), h);
+        if (p == P - 1) {
+            st_node_zero<ET, true>(q.pre_Rsub, uR, us, LaneRef::of(ul));
+            st_node_zero<D, true>(q.pre_rho, uR, us, LaneRef::of(ul));
+            st_node_zero<EF, true>(q.pre_S, uR, us, LaneRef::of(ul));
+        }
+    }
+    if (p > 0) {
+        const int qq = p - 1, ul = b * uP + qq / uR, us = qq % uR;
+        st_node<EF, true>(q.pre_S, uR, us, LaneRef::of(ul), W);
+        st_node<ET, true>(q.pre_Rsub, uR, us, LaneRef::of(ul), Racc);
+        st_node<D, true>(q.pre_rho, uR, us, LaneRef::of(ul), rho);
+    }
+    if (bad) flag_not_pd(a.info, a.lv.level, lane);
+}
+
+template <int D>
+static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_forward_reduce_cq(SweepArgs a, CqArgs q) {
+    constexpr int ET = MFGM_NTRI(D), EF = D * D;
+    __shared__ double lds[(EF + ET + D) * 64];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // Both wavefronts meet at R workgroup barriers, so no lane may leave early and no barrier may sit in divergent control flow: the
+    // padding lanes of the last tile repeat the work of the last live lane (same loads, same results, same values stored to the same
+    // places) instead of returning.
+    const int lane = min((int)blockIdx.x * 64 + l, a.lv.L - 1);
+    const LaneRef me{(int)blockIdx.x, lane & 63};
+    if (wave == 0) forward_cq_body<D, true>(a, q, lane, me);
+    else reduce_cq_lds_body<D>(a, q, lane, me, lds, l);
 }
 
 // ---- backward helpers ------------------------------------------------------------------------------------------------------------

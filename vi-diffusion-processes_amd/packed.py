@@ -402,7 +402,8 @@ class Plan:
         """Block Cholesky + forward substitution of the posterior precision given as a cq state: dict(L, y, logdet).
         Pipelined across the steps of the CVI-DP loop (mfgm_cq_factor_pipelined): `use_ahead` says the previous pipelined call made the
         separator system of exactly this state (the level-0 reduce is skipped); `next_sites` = (site_lin, site_sym) of the state whose
-        separator system is to be made now, on the torch stream `side`, next to this call's level-0 forward sweep."""
+        separator system is to be made now, next to this call's level-0 forward sweep: by the second wavefront of the same kernel
+        (side=None) or as a kernel of its own on the torch stream `side`."""
         out = {} if out is None else out
         L = out.get("L") if out.get("L") is not None else self.empty(TRI)
         y = out.get("y") if out.get("y") is not None else self.empty(VEC)
@@ -418,7 +419,8 @@ class Plan:
             nxt.site_lin, nxt.site_sym = next_sites[0].data_ptr(), next_sites[1].data_ptr()
         _lib.check(self.lib.mfgm_cq_factor_pipelined(self.h, ctypes.byref(cq.struct()), _ptr(L), _ptr(y), _ptr(logdet), None, _ptr(self.ws),
                                                      _ptr(self.info), 1 if use_ahead else 0, ctypes.byref(nxt) if nxt is not None else None,
-                                                     ctypes.c_void_p(side.cuda_stream), _stream()), "mfgm_cq_factor_pipelined")
+                                                     ctypes.c_void_p(side.cuda_stream) if side is not None else None, _stream()),
+                   "mfgm_cq_factor_pipelined")
         return dict(L=L, y=y, logdet=logdet)
 
     def cq_selinv_girsanov(self, cq, L, y, prm, dyn_out, only_level=-1):

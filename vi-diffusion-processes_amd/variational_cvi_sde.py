@@ -544,6 +544,9 @@ class CVISitesSDE(CVISitesSSM):
     # tensors, and anything that does not match (another learning rate, a re-linearisation, sites assigned by hand) simply finds no
     # record and runs the reduce itself.  Results are bit-identical either way (the record holds the numbers the reduce would write).
     pipelined = os.environ.get("VIDP_PIPELINE", "1") != "0"
+    # VIDP_PIPE_STREAMS=1: the reduce made ahead runs as a kernel of its own on a second stream (round 4's first form; A/B) instead of
+    # as the second wavefront of the forward sweep's workgroups (k_forward_reduce_cq: the records are read once)
+    pipe_two_streams = os.environ.get("VIDP_PIPE_STREAMS", "0") == "1"
     # below this many nodes (B T) a level-0 reduce is a few microseconds: the second stream's event round trips would cost more than
     # they hide (config 1, T = 1001: 0.133 -> 0.174 ms with it)
     pipeline_min_nodes = 200000
@@ -555,10 +558,13 @@ class CVISitesSDE(CVISitesSSM):
             self._cq_g2 = (g2, self._sym_packed(g2[0]))
         return g1, self._cq_g2[1]
 
+    _pipe_side = None     # the second stream of the two-stream form
+
     def _pipe_drop(self):
         """Forget a separator system made ahead (the stream it was made on is joined first: its buffers are about to be reused)."""
         if getattr(self, "_pre", None) is not None:
-            torch.cuda.current_stream().wait_stream(self._pipe_side)
+            if self._pipe_side is not None:
+                torch.cuda.current_stream().wait_stream(self._pipe_side)
             self._pre = None
 
     def _pipe_predict(self, cq):
@@ -567,7 +573,8 @@ class CVISitesSDE(CVISitesSSM):
         g1, g2p = self._pipe_sites_gradient()
         if getattr(self, "_pipe_bufs", None) is None:
             self._pipe_bufs = [torch.empty_like(self.data_nat1), torch.empty_like(cq.site_sym)]
-            self._pipe_side = torch.cuda.Stream(device=self.device)
+            if self.pipe_two_streams:
+                self._pipe_side = torch.cuda.Stream(device=self.device)
         lin, sym = self._pipe_bufs
         self.plan.site_lerp_to(lin, self.data_nat1, g1.contiguous(), sym, cq.site_sym, g2p, self._pipe_lr)
         return lin, sym
@@ -661,14 +668,14 @@ class CVISitesSDE(CVISitesSSM):
         if self._q is None:
             nxt = None
             if (self.pipelined and obs and getattr(self, "_pipe_lr", None) is not None and self._sde_prm.kind == 0
-                    and self.B * self.T >= self.pipeline_min_nodes):
+                    and self.B * self.T >= self.pipeline_min_nodes and self.state_dim <= 6):      # (d = 7, 8: the kernel pair does not fit)
                 # the level-0 reduce of the next step's first factorisation rides next to this factorisation's forward sweep
                 self._pipe_drop()
                 lin, sym = self._pipe_predict(cq)
                 nxt = dict(lr=self._pipe_lr, cq=cq, ver=cq.version, v1=(id(self.data_nat1), self.data_nat1._version),
                            v2=(id(cq.site_sym), cq.site_sym._version), lin=lin, sym=sym)
             f = pl.cq_factor(cq, want_logdet=True, out=self._bufs["f"], use_ahead=self._pipe_take(cq) if nxt is None else False,
-                             next_sites=(nxt["lin"], nxt["sym"]) if nxt else None, side=getattr(self, "_pipe_side", None))
+                             next_sites=(nxt["lin"], nxt["sym"]) if nxt else None, side=self._pipe_side)
             if nxt is not None:
                 nxt["epoch"] = pl.epoch
             self._pre = nxt
@@ -893,7 +900,7 @@ class CVISitesSDE(CVISitesSSM):
         if cq is not None:
             # reduce -> forward -> backward sweep that writes (1 - lr) dyn + lr theta~ into the spare buffer; the uniform off-diagonals
             # scale by (1 - lr); the data sites do not enter (they are not part of the resident state)
-            f = pl.cq_factor(cq, want_logdet=False, out=self._bufs["f"], use_ahead=self._pipe_take(cq), side=getattr(self, "_pipe_side", None))
+            f = pl.cq_factor(cq, want_logdet=False, out=self._bufs["f"], use_ahead=self._pipe_take(cq), side=self._pipe_side)
             self._bufs["f"].update(L=f["L"], y=f["y"])
             if cq.spare is None:
                 cq.spare = torch.empty_like(cq.dyn)
