@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two builds of the library on one box: default vs MFGM_LIB=$1 (alternating, 2 rounds), + fused-kernel averages under the profiler
+# A/B of two builds of the library on one box: the in-tree one vs MFGM_LIB=$1 (a path below the repo root, e.g. a variant built with other -D flags) (alternating, 2 rounds), + fused-kernel averages under the profiler
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 A="--steps 20 --warmup 10 --no-cpu-baseline --no-other-configs --no-vdp"
 ALT=$PWD/$1
