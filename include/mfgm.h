@@ -563,6 +563,17 @@ size_t mfgm_band_workspace_doubles(const mfgm_plan* plan);
 int mfgm_band_sigma_dP_sigma(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* dPd, const double* dPs, double* Xd,
                              double* Xs, double* work, void* stream);
 
+/* The same band for block sizes up to 32 on NATURAL-layout arrays (no plan): Sig [B, T, d, d] = Sigma_tt, Sub [B, T-1, d, d] =
+ * Sigma_{t+1,t}, dPd [B, T, d, d] symmetric (both triangles read), dPs [B, T-1, d, d] = dP_{t+1,t}; Xd [B, T, d, d], Xs [B, T-1, d, d].
+ * This is the native backward of the natural-gradient tape where the reference differentiates naturals_to_ssm_params through the
+ * banded ops with d up to 30 (ssm_natgrad.py:142-201; tests/integration/test_ssm_natgrad.py).  One wavefront per node / per segment,
+ * every block product a Gram product of v_mfma_f64_16x16x4_f64 tiles, Sigma_t^-1 by 4 x 4-pivot block sweeps, each recurrence in three
+ * passes over ~sqrt(T / 2.5)-node segments, both recurrences in the same launches (csrc/mfgm_wband.h): five launches whatever T.  T >= 2, d <= 32.
+ * work: scratch of mfgm_wband_workspace_doubles(B, T, d) doubles; info: device word, non-zero when a Sigma_tt is not positive definite. */
+size_t mfgm_wband_workspace_doubles(int B, int T, int d);
+int mfgm_wband_sigma_dP_sigma(int B, int T, int d, const double* Sig, const double* Sub, const double* dPd, const double* dPs, double* Xd,
+                              double* Xs, double* work, int* info, void* stream);
+
 /* forward_pass as the moment recursion of the reference (vi_sde.py:171-204), partitioned over the segments of the plan: marginal
  * means mu (VEC) and covariances Sig (SYM) of the Euler chain of the drift (-A, b) started at q(x0) = N(q0_mu[b], q0_cov[b])
  * (q0_mu [B][d], q0_cov [B][d(d+1)/2] packed lower triangles).  No factorisation: 42 doubles read twice and 27 written per node.

@@ -2,6 +2,8 @@
 GPU parity tests of the reference-named host classes (StateSpaceModel, block_tri_diag, the SSM <-> eta/theta
 transformations, CVISitesSSM) against the NumPy oracle.  fp64; tolerance 1e-6 relative (north-star: 1e-5).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -2051,6 +2053,65 @@ def test_exact_band_of_sigma_dP_sigma(amd, rng, B, T, d):
         hd, hs = tape.band_of_sigma_dP_sigma(dev(np.stack(covs)), dev(np.stack(subs)), dev(dPd), dev(dPs), plan=plan)
         assert_close(host(hd), np.stack(Xd), rtol=1e-8)
         assert_close(host(hs), np.stack(Xs), rtol=1e-8)
+
+
+@pytest.mark.parametrize("B,T,d", [(1, 40, 12), (2, 9, 16), (1, 130, 17), (1, 100, 30), (3, 5, 32), (2, 33, 9), (1, 2, 24)])
+def test_exact_band_of_sigma_dP_sigma_wide_blocks(amd, rng, B, T, d):
+    """mfgm_wband_sigma_dP_sigma (block sizes up to 32: natural-layout arrays, MFMA Gram products, segment maps for T > 32) against the
+    dense product Sigma dP Sigma on a random SPD block-tri-diagonal precision, and against the torch evaluation of the same recurrences
+    (VIDP_TAPE_TORCH_SCAN=1) -- the natural-gradient tape's backward at the reference's d = 30 (tests/integration/test_ssm_natgrad.py)."""
+    from vidp_amd import tape
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    dPd = rng.normal(size=(B, T, d, d))
+    dPd = dPd + np.swapaxes(dPd, -1, -2)
+    dPs = rng.normal(size=(B, T - 1, d, d))
+    covs, subs, Xd, Xs = [], [], [], []
+    blk = lambda M, i, j: M[i * d:(i + 1) * d, j * d:(j + 1) * d]
+    for b in range(B):
+        S = np.linalg.inv(np_btd.to_dense(diag[b], sub[b], symmetric=True))
+        X = S @ np_btd.to_dense(dPd[b], dPs[b], symmetric=True) @ S
+        covs.append(np.stack([blk(S, t, t) for t in range(T)]))
+        subs.append(np.stack([blk(S, t + 1, t) for t in range(T - 1)]))
+        Xd.append(np.stack([blk(X, t, t) for t in range(T)]))
+        Xs.append(np.stack([blk(X, t + 1, t) for t in range(T - 1)]))
+    args = (dev(np.stack(covs)), dev(np.stack(subs)), dev(dPd), dev(dPs))
+    gd, gs = tape.band_of_sigma_dP_sigma(*args)
+    assert_close(host(gd), np.stack(Xd), rtol=1e-8)
+    assert_close(host(gs), np.stack(Xs), rtol=1e-8)
+    os.environ["VIDP_TAPE_TORCH_SCAN"] = "1"
+    try:
+        td, ts = tape.band_of_sigma_dP_sigma(*args)
+    finally:
+        del os.environ["VIDP_TAPE_TORCH_SCAN"]
+    assert_close(host(gd), host(td), rtol=1e-9)
+    assert_close(host(gs), host(ts), rtol=1e-9)
+
+
+def test_wide_band_long_chain_and_failure_report(amd, rng):
+    """A chain of 3 000 nodes at d = 20 (55 segments per recurrence) against the torch scans, and ArithmeticError for a marginal
+    covariance that is not positive definite."""
+    from vidp_amd import tape
+    B, T, d = 1, 3000, 20
+    diag, sub = random_dominant_btd(rng, (B,), T, d)
+    plan = amd.Plan(B, T, d)
+    f = plan.factor(plan.pack(amd.SYM, dev(diag)), plan.pack(amd.FULL, dev(sub)), None, want_logdet=False)
+    s = plan.selinv(f["L"], f["G"], None, want_sub=True)
+    cov, csub = plan.unpack(amd.SYM, s["Sig"]), plan.unpack(amd.FULL, s["Sub"], T - 1)
+    dPd = rng.normal(size=(B, T, d, d))
+    dPd = dev(dPd + np.swapaxes(dPd, -1, -2))
+    dPs = dev(rng.normal(size=(B, T - 1, d, d)))
+    gd, gs = tape.band_of_sigma_dP_sigma(cov, csub, dPd, dPs)
+    os.environ["VIDP_TAPE_TORCH_SCAN"] = "1"
+    try:
+        td, ts = tape.band_of_sigma_dP_sigma(cov, csub, dPd, dPs)
+    finally:
+        del os.environ["VIDP_TAPE_TORCH_SCAN"]
+    assert_close(host(gd), host(td), rtol=1e-9)
+    assert_close(host(gs), host(ts), rtol=1e-9)
+    bad = cov.clone()
+    bad[0, 1234] = -bad[0, 1234]
+    with pytest.raises(ArithmeticError):
+        tape.band_of_sigma_dP_sigma(bad, csub, dPd, dPs)
 
 
 @pytest.mark.parametrize("B,T,d,R0", [(1, 1, 1, 0), (3, 2, 2, 0), (2, 37, 3, 4), (5, 130, 6, 8), (1, 700, 8, 5), (70, 20, 4, 0), (2, 5000, 6, 0)])

@@ -40,6 +40,8 @@ EXPORTS = {
     "mfgm_congruence_scan": (ctypes.c_int, [ctypes.c_void_p] * 6),
     "mfgm_band_workspace_doubles": (ctypes.c_size_t, [ctypes.c_void_p]),
     "mfgm_band_sigma_dP_sigma": (ctypes.c_int, [ctypes.c_void_p] * 9),
+    "mfgm_wband_workspace_doubles": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "mfgm_wband_sigma_dP_sigma": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 9),
     "mfgm_site_lerp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_double, ctypes.c_void_p]),
     "mfgm_site_lerp_to": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_double,

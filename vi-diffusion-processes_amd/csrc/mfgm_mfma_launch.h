@@ -4,6 +4,7 @@
 // tiles need the AGPR half of the register file, cannot be.
 #include "mfgm_internal.h"
 #include "mfgm_mfma_inv.h"
+#include "mfgm_wband.h"
 
 #define MFGM_CAT_(a, b) a##b
 #define MFGM_CAT(a, b) MFGM_CAT_(a, b)
@@ -82,6 +83,38 @@ int MFGM_CAT(mfma_ssm_to_naturals_, MFGM_MFMA_NT)(int B, int T, int d, const dou
     dim3 grid(B * T), block(64);
     if (lin) hipLaunchKernelGGL((km_ssm_to_naturals<MFGM_MFMA_NT, true>), grid, block, 0, st, B, T, d, A, off, chol, cD, cS, lin, diag, sub, part);
     else hipLaunchKernelGGL((km_ssm_to_naturals<MFGM_MFMA_NT, false>), grid, block, 0, st, B, T, d, A, off, chol, cD, cS, lin, diag, sub, part);
+    MFGM_CHECK_LAUNCH();
+    return 0;
+}
+
+// band of Sigma dP Sigma (mfgm_wband.h): node pass, the two recurrences (three passes each when a chain has more than one segment), node pass
+int MFGM_CAT(wband_run_, MFGM_MFMA_NT)(const WBandArgs& a, const WScanArgs& s0, hipStream_t st) {
+    constexpr int NT = MFGM_MFMA_NT;
+    const dim3 nodes(a.B * a.T), block(64);
+    hipLaunchKernelGGL((kwb_prepare<NT>), nodes, block, 0, st, a);
+    MFGM_CHECK_LAUNCH();
+    WScanPair w;
+    for (int rev = 0; rev < 2; ++rev) {
+        w.s[rev] = s0;
+        w.s[rev].reverse = rev;
+        w.s[rev].PhiT = rev ? a.PhiR : a.PhiL;
+        w.s[rev].Q = rev ? a.QR : a.QL;
+        w.s[rev].X = rev ? a.Rr : a.Lr;
+        // each recurrence has its own third of the segment arrays
+        const size_t m = (size_t)a.B * s0.P * a.d * a.d;
+        w.s[rev].segT = s0.segT + (size_t)rev * 3 * m;
+        w.s[rev].segQ = w.s[rev].segT + m;
+        w.s[rev].segX = w.s[rev].segQ + m;
+    }
+    if (s0.P > 1) {
+        hipLaunchKernelGGL((kwb_scan_maps<NT>), dim3(a.B * s0.P, 2), block, 0, st, w);
+        MFGM_CHECK_LAUNCH();
+        hipLaunchKernelGGL((kwb_scan_tops<NT>), dim3(a.B, 2), block, 0, st, w);
+        MFGM_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL((kwb_scan_sweep<NT>), dim3(a.B * s0.P, 2), block, 0, st, w);
+    MFGM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((kwb_finish<NT>), nodes, block, 0, st, a);
     MFGM_CHECK_LAUNCH();
     return 0;
 }

@@ -152,6 +152,24 @@ def _congruence_scan(Phi, Q, reverse=False, plan=None):
     return Q
 
 
+def _wband(cov, csub, dPd, dPs):
+    """mfgm_wband_sigma_dP_sigma on natural-layout tensors; ArithmeticError when a Sigma_tt is not positive definite."""
+    from . import _lib
+    from .packed import _ptr, _stream
+    lib = _lib.load()
+    B, T, d, _ = cov.shape
+    f64 = dict(dtype=torch.float64, device=cov.device)
+    work = torch.empty(int(lib.mfgm_wband_workspace_doubles(B, T, d)), **f64)
+    info = torch.zeros(1, dtype=torch.int32, device=cov.device)
+    Xd, Xs = torch.empty((B, T, d, d), **f64), torch.empty((B, T - 1, d, d), **f64)
+    args = [x.contiguous() for x in (cov, csub, 0.5 * (dPd + _T(dPd)), dPs)]
+    _lib.check(lib.mfgm_wband_sigma_dP_sigma(B, T, d, *[_ptr(x) for x in args], _ptr(Xd), _ptr(Xs), _ptr(work), _ptr(info), _stream()),
+               "mfgm_wband_sigma_dP_sigma")
+    if int(info.item()) != 0:
+        raise ArithmeticError("a marginal covariance is not positive definite (band of Sigma dP Sigma)")
+    return Xd, Xs
+
+
 def band_of_sigma_dP_sigma(cov, csub, dPd, dPs, plan=None):
     """Diagonal and sub-diagonal blocks of  X = Sigma dP Sigma  for the covariance Sigma of a Gauss-Markov chain given by its band
     (cov [B,T,d,d] = Sigma_tt, csub [B,T-1,d,d] = Sigma_{t+1,t}) and a symmetric block-tri-diagonal dP (dPd [B,T,d,d] symmetric,
@@ -164,6 +182,9 @@ def band_of_sigma_dP_sigma(cov, csub, dPd, dPs, plan=None):
         Xd, Xs = plan.band_of_sigma_dP_sigma(plan.pack(SYM, cov.contiguous()), plan.pack(FULL, csub.contiguous()),
                                              plan.pack(SYM, dPd.contiguous()), plan.pack(FULL, dPs.contiguous()))
         return plan.unpack(SYM, Xd), plan.unpack(FULL, Xs, T - 1)
+    if cov.is_cuda and 1 < T and d <= 32 and os.environ.get("VIDP_TAPE_TORCH_SCAN", "0") != "1":
+        # block sizes up to 32 (wide plans, or no plan at all): natural-layout arrays, MFMA Gram products (csrc/mfgm_wband.h)
+        return _wband(cov, csub, dPd, dPs)
     loc = cov @ dPd @ cov                                               # Sigma_t dP_tt Sigma_t
     if T == 1:
         return loc, csub
