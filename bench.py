@@ -367,10 +367,13 @@ def bench_vdp(h, data_rank):
         lean = not m.store_multipliers
         psi0, lam0 = (torch.empty((B, d, d), dtype=torch.float64, device=device), torch.empty((B, d), dtype=torch.float64, device=device))
 
+        # the seg array the loop's Lagrange calls ran on (their segment scans are what the final sweep starts from)
+        lseg = m._lseg if getattr(m, "_lseg", None) is not None else m._seg
+
         def final():
             if lean:
                 rc = lib.mfgm_packed_vdp_lagrange_update0(pl.h, ctypes.byref(prm), _ptr(mS[0]), _ptr(mS[1]), _ptr(A2), _ptr(b2), _ptr(m._yR),
-                                                          _ptr(m._dobsS), _ptr(psi0), _ptr(lam0), _ptr(m._seg), *m._jump_args(), 1, _stream())
+                                                          _ptr(m._dobsS), _ptr(psi0), _ptr(lam0), _ptr(lseg), *m._jump_args(), 1, _stream())
             else:
                 rc = lib.mfgm_packed_vdp_lagrange_update_final(pl.h, ctypes.byref(prm), _ptr(mS[0]), _ptr(mS[1]), _ptr(A2), _ptr(b2),
                                                                _ptr(m._yR), _ptr(m._dobsS), _ptr(m.psi_lagrange), _ptr(m.lambda_lagrange),

@@ -583,6 +583,14 @@ int mfgm_wband_sigma_dP_sigma(int B, int T, int d, const double* Sig, const doub
 int mfgm_packed_vdp_marginals(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
                               const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* e_over_dt, double* seg,
                               void* ws, void* stream);
+/* mfgm_packed_vdp_marginals that also prepares the Lagrange sweep of the same iteration (vi_markov_gp_trainer.py:55-57: forward_pass,
+ * update_lagrange, update_param on one (A, b)): its first pass has every A_t in registers and is bound by reading them, so it forms
+ * the linear parts of that sweep's segment maps on the side (accumulators in LDS) and leaves them in lagrange_seg -- a second array of
+ * mfgm_vdp_workspace_doubles(plan) doubles, distinct from seg, to be handed to mfgm_packed_vdp_lagrange_update0(..., mode = 2) as
+ * its seg.  Saves one pass over A (8 d^2 bytes per node). */
+int mfgm_packed_vdp_marginals_products(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
+                                       const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* e_over_dt, double* seg,
+                                       double* lagrange_seg, void* ws, void* stream);
 
 /* update_lagrange (vi_sde.py:289-347): psi (FULL) and lambda (VEC) on nodes 0..T-2.  yR (VEC) = R^{-1} y and dobsS (SYM) =
  * -1/2 R^{-1} at the observation nodes, zero elsewhere (jump conditions of a Gaussian likelihood, vi_sde.py:262-287).
@@ -604,11 +612,13 @@ int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params
 /* The same with the multipliers kept at NODE 0 only: psi0 [B, d, d], lam0 [B, d] (natural layout) instead of the packed arrays.  In the
  * trainer's loop (vi_markov_gp_trainer.py:56-58: update_lagrange, update_param, update_initial_statistics) every other multiplier has
  * been consumed by the fused parameter update when the sweep leaves its node; only psi(0), lambda(0) are read afterwards
- * (vi_sde.py:241-260).  Saves the d^2 + d stores per node nobody loads (42 of 153 doubles at d = 6).  final_only != 0: the last kernel
- * alone (roofline timing; seg must hold the segment scans of a full call). */
+ * (vi_sde.py:241-260).  Saves the d^2 + d stores per node nobody loads (42 of 153 doubles at d = 6).  mode 0: all passes; 1: the last
+ * kernel alone (roofline timing; seg must hold the segment scans of a full call); 2: all passes but the first one, the products of
+ * (I - 2 dt A_t) / (I - dt A_t) over each segment, which a preceding mfgm_packed_vdp_marginals_products on the SAME (Am, bm) has left
+ * in seg. */
 int mfgm_packed_vdp_lagrange_update0(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
                                      double* bm, const double* yR, const double* dobsS, double* psi0, double* lam0, double* seg,
-                                     const int* obs_count, const double* dobs_const, int final_only, void* stream);
+                                     const int* obs_count, const double* dobs_const, int mode, void* stream);
 /* Profiling / roofline entry point: the LAST kernel of mfgm_packed_vdp_lagrange_update alone (the final sweep that also replaces
  * (Am, bm)); seg must hold the segment scans of a full call with the same arguments. */
 int mfgm_packed_vdp_lagrange_update_final(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

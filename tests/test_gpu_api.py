@@ -1330,7 +1330,8 @@ def test_cq_marginals_on_demand(amd, rng, monkeypatch):
             np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
 
 
-@pytest.mark.parametrize("d,B,T,stab,kind", [(1, 2, 60, False, "dw"), (2, 2, 700, False, "ou"), (3, 1, 140, True, "dw"), (6, 2, 90, True, "dw")])
+@pytest.mark.parametrize("d,B,T,stab,kind", [(1, 2, 60, False, "dw"), (2, 2, 700, False, "ou"), (3, 1, 140, True, "dw"), (6, 2, 90, True, "dw"),
+                                             (5, 3, 400, False, "ou"), (7, 1, 50, False, "ou")])
 def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind):
     """update_lagrange_and_param (one set of sweeps) against update_lagrange followed by update_param, three consecutive iterations."""
     import torch

@@ -322,14 +322,28 @@ MFGM_DEV void vdp_advance(const VdpParams& pr, const double (&T)[D * D], const d
 // seg: one record per lane (segment), contiguous -- Phi [d^2], Qacc [ET], macc [d], then the boundary values m [d], S [ET] at the
 // segment's first node -- so that the scan kernel reads the consecutive segments of a lane as one run (with one array per element,
 // strided by the lane count, every load of the scan was a cache line of its own: 0.29 ms, 0.16 ms like this).
-template <int D, int PASS>
+// PROD (PASS 1 only): the pass also leaves the linear parts of the Lagrange sweep's segment maps (k_vdp_lagrange_products: Mpsi, Mlam,
+// products of I - 2 dt A_t / I - dt A_t over the segment's transitions t >= 1) in `lseg`, the seg array of the Lagrange call that
+// follows on the SAME (A, b).  They depend on A alone and this pass has A in registers with the vector ALU a quarter busy (it is bound by
+// reading A): the two d x d accumulators live in LDS (one wavefront per SIMD, 2 d^2 x 64 doubles = 36 KB per workgroup at d = 6), worked
+// a row / a column at a time, and the 8 d^2 bytes per node of the products pass are not read again (config 3: 0.18 ms of 1.95).
+template <int D, int PASS, bool PROD = false>
 __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
                                                      const double* __restrict__ bm, double* __restrict__ mug,
                                                      double* __restrict__ Sigg, double* __restrict__ seg,
-                                                     double* __restrict__ part /* PASS 3, optional: per-lane sum of the E_sde terms */) {
+                                                     double* __restrict__ part /* PASS 3, optional: per-lane sum of the E_sde terms */,
+                                                     double* __restrict__ lseg = nullptr) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
+    static_assert(!PROD || PASS == 1, "the Lagrange products ride in pass 1");
+    __shared__ double prod_lds[PROD ? 2 * EF * 64 : 1];
+    double* const Mp = prod_lds + threadIdx.x;                 // element e at Mp[e * 64]
+    double* const Ml = prod_lds + (PROD ? EF * 64 : 0) + threadIdx.x;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
+    if (PROD) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) { Mp[e * 64] = (e % (D + 1) == 0) ? 1.0 : 0.0; Ml[e * 64] = (e % (D + 1) == 0) ? 1.0 : 0.0; }
+    }
     const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = lv.P, R = lv.R, n = lv.n;
     const int p = lane % P;
@@ -377,6 +391,36 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
                     double dm[D], dS[ET];
                     esde += vdp_energy<D, false>(pr, m, S, T, o, dm, dS);
                 }
+                if (PROD && p * R + s >= 1) {
+                    // ascending order of the same products: Mpsi <- (I - 2 dt A_t) Mpsi (a column at a time), Mlam <- Mlam (I - dt A_t)
+                    // (a row at a time); T still holds A_t here
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        double c[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) c[k] = Mp[(k * D + j) * 64];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int k = 0; k < D; ++k) t = __builtin_fma(T[i * D + k], c[k], t);
+                            Mp[(i * D + j) * 64] = __builtin_fma(-2.0 * pr.dt, t, c[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double r[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) r[k] = Ml[(i * D + k) * 64];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int k = 0; k < D; ++k) t = __builtin_fma(r[k], T[k * D + j], t);
+                            Ml[(i * D + j) * 64] = __builtin_fma(-pr.dt, t, r[j]);
+                        }
+                    }
+                }
                 vdp_transition<D>(pr, T, o);
                 vdp_advance<D>(pr, T, o, m, S);
                 if (PASS == 1) {
@@ -396,6 +440,14 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
         for (int e = 0; e < ET; ++e) seg[(size_t)lane * STR + (EF + e)] = S[e];
 #pragma unroll
         for (int i = 0; i < D; ++i) seg[(size_t)lane * STR + (EF + ET + i)] = m[i];
+        if (PROD) {
+            constexpr int LSTR = 4 * EF + 2 * D;              // the Lagrange sweep's segment record (k_vdp_lagrange_products)
+#pragma unroll
+            for (int e = 0; e < EF; ++e) {
+                lseg[(size_t)lane * LSTR + e] = Mp[e * 64];
+                lseg[(size_t)lane * LSTR + (2 * EF + e)] = Ml[e * 64];
+            }
+        }
     }
 }
 

@@ -133,6 +133,8 @@ class VariationalMarkovGP:
     # the reference's forward_pass computes); "precision" = precision blocks + factorisation + selected inverse; "ssm" = the same over
     # explicit SSM arrays.  VIDP_VDP_FORWARD selects; the three agree to rounding (tests/test_gpu_api.py).
     forward_mode = os.environ.get("VIDP_VDP_FORWARD", "moments")
+    # the moment recursion's first pass also makes the A-only pass of the Lagrange sweep that follows (VIDP_VDP_FUSE_PRODUCTS=0: not)
+    fuse_products = os.environ.get("VIDP_VDP_FUSE_PRODUCTS", "1") != "0"
 
     def _forward_packed_moments(self, prm):
         pl, d = self.plan, self.state_dim
@@ -143,9 +145,19 @@ class VariationalMarkovGP:
             self._q0_key = (self.q0_mu, self.q0_chol)
         mu, Sig = pl.empty(VEC), pl.empty(SYM)        # fresh outputs: callers keep the marginals of earlier passes
         e = torch.empty(self.B, dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.mfgm_packed_vdp_marginals(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(self._q0_dev[0]),
-                                                      _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig), _ptr(e), _ptr(self._seg),
-                                                      _ptr(pl.ws), _stream()), "mfgm_packed_vdp_marginals")
+        if self.fuse_products:
+            # the first pass also forms the A-only part of the Lagrange sweep's segment maps (valid while (A, b) stay as they are)
+            if getattr(self, "_lseg", None) is None:
+                self._lseg = torch.empty_like(self._seg)
+            _lib.check(self.lib.mfgm_packed_vdp_marginals_products(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b),
+                                                                   _ptr(self._q0_dev[0]), _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig),
+                                                                   _ptr(e), _ptr(self._seg), _ptr(self._lseg), _ptr(pl.ws), _stream()),
+                       "mfgm_packed_vdp_marginals_products")
+            self._products_of = (self.A, self._param_version)
+        else:
+            _lib.check(self.lib.mfgm_packed_vdp_marginals(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(self._q0_dev[0]),
+                                                          _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig), _ptr(e), _ptr(self._seg),
+                                                          _ptr(pl.ws), _stream()), "mfgm_packed_vdp_marginals")
         self._mS = (mu, Sig)
         # E_sde of exactly these marginals under the current (A, b), a by-product of the final sweep; valid until the variational or
         # drift parameters change (self._esde_of is compared by identity in E_sde)
@@ -294,6 +306,9 @@ class VariationalMarkovGP:
         other psi_t / lambda_t when it leaves node t, and update_initial_statistics -- the one later reader in the loop -- needs node 0;
         `psi_lagrange` / `lambda_lagrange` are then NOT current until update_lagrange (or a call with store_multipliers=True) runs.
         """
+        po = getattr(self, "_products_of", None)
+        have_products = po is not None and po[0] is self.A and po[1] == self._param_version
+        self._products_of = None
         self._param_version += 1
         pl = self.plan
         m, S = mS if mS is not None else self._mS
@@ -311,7 +326,8 @@ class VariationalMarkovGP:
         psi0, lam0 = self._mult0_bufs
         _lib.check(self.lib.mfgm_packed_vdp_lagrange_update0(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
                                                              _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(psi0), _ptr(lam0),
-                                                             _ptr(self._seg), *self._jump_args(), 0, _stream()),
+                                                             _ptr(self._lseg if have_products else self._seg), *self._jump_args(),
+                                                             2 if have_products else 0, _stream()),
                    "mfgm_packed_vdp_lagrange_update0")
         self._mult0 = (psi0, lam0)          # what update_initial_statistics reads until the arrays are current again
 
