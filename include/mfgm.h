@@ -584,13 +584,19 @@ int mfgm_packed_vdp_marginals(const mfgm_plan* plan, const mfgm_vdp_params* prm,
                               const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* e_over_dt, double* seg,
                               void* ws, void* stream);
 /* mfgm_packed_vdp_marginals that also prepares the Lagrange sweep of the same iteration (vi_markov_gp_trainer.py:55-57: forward_pass,
- * update_lagrange, update_param on one (A, b)): its first pass has every A_t in registers and is bound by reading them, so it forms
- * the linear parts of that sweep's segment maps on the side (accumulators in LDS) and leaves them in lagrange_seg -- a second array of
- * mfgm_vdp_workspace_doubles(plan) doubles, distinct from seg, to be handed to mfgm_packed_vdp_lagrange_update0(..., mode = 2) as
- * its seg.  Saves one pass over A (8 d^2 bytes per node). */
+ * update_lagrange, update_param on one (A, b)), leaving the results in lagrange_seg -- a second array of
+ * mfgm_vdp_workspace_doubles(plan) doubles, distinct from seg, to be handed to mfgm_packed_vdp_lagrange_update0 as its seg:
+ *   yR == NULL: the first pass, which has every A_t in registers and is bound by reading them, forms the linear parts of that sweep's
+ *     segment maps on the side (accumulators in LDS); the Lagrange call runs with mode = 2.  Saves one pass over A (8 d^2 bytes / node).
+ *   yR != NULL (with dobsS or obs_count / dobs_const, as in the Lagrange calls; prm->clip as there): the final sweep, which produces
+ *     (m_t, S_t) with (A_t, b_t) in registers, accumulates the affine offsets of the segment maps as well (the descending recurrence's
+ *     segment map summed in ascending order, csrc/mfgm_vdp.h); the Lagrange call runs with mode = 3 and starts at its segment scan.
+ * What rides in the sweeps depends on d (registers and LDS): everything for d <= 5, the products for d = 6 (the offsets pass follows the
+ * final sweep as a launch of this call), neither for d = 7, 8 (both passes follow).  The contract is the same. */
 int mfgm_packed_vdp_marginals_products(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
                                        const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* e_over_dt, double* seg,
-                                       double* lagrange_seg, void* ws, void* stream);
+                                       double* lagrange_seg, const double* yR, const double* dobsS, const int* obs_count,
+                                       const double* dobs_const, void* ws, void* stream);
 
 /* update_lagrange (vi_sde.py:289-347): psi (FULL) and lambda (VEC) on nodes 0..T-2.  yR (VEC) = R^{-1} y and dobsS (SYM) =
  * -1/2 R^{-1} at the observation nodes, zero elsewhere (jump conditions of a Gaussian likelihood, vi_sde.py:262-287).
@@ -615,7 +621,8 @@ int mfgm_packed_vdp_lagrange_update(const mfgm_plan* plan, const mfgm_vdp_params
  * (vi_sde.py:241-260).  Saves the d^2 + d stores per node nobody loads (42 of 153 doubles at d = 6).  mode 0: all passes; 1: the last
  * kernel alone (roofline timing; seg must hold the segment scans of a full call); 2: all passes but the first one, the products of
  * (I - 2 dt A_t) / (I - dt A_t) over each segment, which a preceding mfgm_packed_vdp_marginals_products on the SAME (Am, bm) has left
- * in seg. */
+ * in seg; 3: from the segment scan on -- that call was given the jump terms and has left the offsets of the segment maps too (then
+ * (mu, Sig) must be the marginals it produced). */
 int mfgm_packed_vdp_lagrange_update0(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
                                      double* bm, const double* yR, const double* dobsS, double* psi0, double* lam0, double* seg,
                                      const int* obs_count, const double* dobs_const, int mode, void* stream);

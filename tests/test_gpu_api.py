@@ -1345,9 +1345,11 @@ def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind)
     # a small observation noise makes the multipliers large enough for stabilize_system to clip them
     lik_chol = (0.02 if stab else 0.5) * np.eye(d)
 
-    def run(fused, lean=False):
+    def run(fused, lean=False, level=2):
         q = torch.eye(d, dtype=torch.float64)
         VariationalMarkovGP.dense_jumps = not fused      # the two-call form also reads the dense jump-condition array
+        # what the moment recursion makes for the Lagrange call on the side: 0 nothing, 1 the A-only products, 2 the offsets too
+        VariationalMarkovGP.fuse_lagrange = level
         g = VariationalMarkovGP((grid[idx], dev(y)), gsde.DoubleWellSDE(q) if kind == "dw" else gsde.OrnsteinUhlenbeckSDE(0.9, q), grid,
                                 MultivariateGaussian(dev(lik_chol)), prior_initial_state=(np.zeros(d), 0.5 * np.eye(d)),
                                 stabilize_system=stab, plan=amd.Plan(B, T, d, R0=8, Rup=3))
@@ -1377,8 +1379,14 @@ def test_vdp_lagrange_sweep_with_parameter_update(amd, rng, d, B, T, stab, kind)
 
     try:
         ra, rb, rc = run(True), run(False), run(True, lean=True)
+        rc1, rc0 = run(True, lean=True, level=1), run(True, lean=True, level=0)
     finally:
         VariationalMarkovGP.dense_jumps = False
+        VariationalMarkovGP.fuse_lagrange = 2
+    for sc, s1, s0 in zip(rc, rc1, rc0):
+        for xc, x1, x0 in zip(sc, s1, s0):
+            np.testing.assert_allclose(x1, x0, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(x0).max()))
+            np.testing.assert_allclose(xc, x0, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(x0).max()))
     for sa, sb, sc in zip(ra, rb, rc):
         for xa, xb in zip(sa, sb):
             assert np.isfinite(xb).all()

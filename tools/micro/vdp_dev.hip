@@ -9,7 +9,8 @@ void inst(LevelDesc lv, VdpParams pr, double* p, int* c) {
 }
 void inst2(LevelDesc lv, VdpParams pr, double* p, int* c) {
     hipLaunchKernelGGL((k_vdp_marginals<6, 1>), dim3(1), dim3(64), 0, 0, lv, pr, p, p, p, p, p, p, p);
-    hipLaunchKernelGGL((k_vdp_marginals<6, 1, true>), dim3(1), dim3(64), 0, 0, lv, pr, p, p, p, p, p, p, p);
+    hipLaunchKernelGGL((k_vdp_marginals<6, 1, 1>), dim3(1), dim3(64), 0, 0, lv, pr, p, p, p, p, p, p, p);
+    hipLaunchKernelGGL((k_vdp_marginals<6, 3, 2>), dim3(1), dim3(64), 0, 0, lv, pr, p, p, p, p, p, p, p, p, p, c, p);
     hipLaunchKernelGGL((k_vdp_marginals<6, 3>), dim3(1), dim3(64), 0, 0, lv, pr, p, p, p, p, p, p, p);
     hipLaunchKernelGGL((k_vdp_lagrange<6, 1>), dim3(1), dim3(64), 0, 0, lv, pr, p, p, p, p, p, p, p, p, p, c, p);
     hipLaunchKernelGGL((k_vdp_lagrange_products<6>), dim3(1), dim3(64), 0, 0, lv, pr, p, p);

@@ -62,7 +62,7 @@ EXPORTS = {
     "mfgm_packed_vdp_to_ssm": (ctypes.c_int, [ctypes.c_void_p] * 8),
     "mfgm_packed_vdp_to_naturals": (ctypes.c_int, [ctypes.c_void_p] * 10),
     "mfgm_packed_vdp_marginals": (ctypes.c_int, [ctypes.c_void_p] * 12),
-    "mfgm_packed_vdp_marginals_products": (ctypes.c_int, [ctypes.c_void_p] * 13),
+    "mfgm_packed_vdp_marginals_products": (ctypes.c_int, [ctypes.c_void_p] * 17),
     "mfgm_packed_vdp_esde": (ctypes.c_int, [ctypes.c_void_p] * 11),
     "mfgm_packed_vdp_lagrange": (ctypes.c_int, [ctypes.c_void_p] * 14),
     "mfgm_packed_vdp_update_param": (ctypes.c_int, [ctypes.c_void_p] * 9),

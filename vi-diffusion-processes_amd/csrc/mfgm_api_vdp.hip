@@ -12,7 +12,7 @@ namespace {
 template <int D>
 int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, const double* a1, const double* a2, const double* a3,
              const double* a4, const double* a5, double* o0, double* o1, double* o2, double* ws, hipStream_t st,
-             const int* obs_count = nullptr, const double* dobs_const = nullptr) {
+             const int* obs_count = nullptr, const double* dobs_const = nullptr, const double* x0 = nullptr, const double* x1 = nullptr) {
     const LevelDesc& lv = P.lv[0];
     dim3 grid(lv.Lpad / 64), block(64);
     if (what == 0) {
@@ -23,17 +23,20 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         else hipLaunchKernelGGL((k_vdp_esde<D, false>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, part, o1, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, o0, (double*)nullptr);
-    } else if (what == 2 || what == 5 || what == 8 || what == 10) {
+    } else if (what == 2 || what == 5 || what == 8 || what == 10 || what == 11) {
         // segment summaries, per-chain scan of the segment maps, final sweep (what == 5: the sweep also makes update_param)
         double* Aw = const_cast<double*>(a2);
         double* bw = const_cast<double*>(a3);
-        // what == 10: what == 8 with the linear parts of the segment maps already in o2 (k_vdp_marginals<D, 1, true>)
-        if (what != 10) {
+        // what == 10: what == 8 with the linear parts of the segment maps already in o2 (k_vdp_marginals<D, 1, 1>);
+        // what == 11: with the affine offsets as well (k_vdp_marginals<D, 3, 2>): the call starts at the segment scan
+        if (what != 10 && what != 11) {
             hipLaunchKernelGGL((k_vdp_lagrange_products<D>), grid, block, 0, st, lv, pr, a2, o2);
             MFGM_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
-        MFGM_CHECK_LAUNCH();
+        if (what != 11) {
+            hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
+            MFGM_CHECK_LAUNCH();
+        }
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 0>), dim3(P.B), dim3(kScanBlock), 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 1>), dim3(P.B), dim3(kScanBlock), 0, st, lv, o2);
@@ -54,23 +57,32 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
         // a4 (optional) = E_sde / dt per trajectory [B], then ws holds the per-lane partials; a5 (optional) = the seg array of the
         // Lagrange call that follows on the same (A, b): pass 1 leaves the linear parts of its segment maps there
         double* part = a4 ? ws + P.off_part[0] : nullptr;
-        if (a5 && D <= 6) {
-            hipLaunchKernelGGL((k_vdp_marginals<D, 1, true>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, (double*)nullptr, const_cast<double*>(a5));
-        } else {
-            // d = 7, 8: the LDS accumulators (50 / 64 KB per wavefront) would halve the occupancy of the pass -- same contract, own pass
-            hipLaunchKernelGGL((k_vdp_marginals<D, 1>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, (double*)nullptr, (double*)nullptr);
-            if (a5) {
-                MFGM_CHECK_LAUNCH();
-                hipLaunchKernelGGL((k_vdp_lagrange_products<D>), grid, block, 0, st, lv, pr, a0, const_cast<double*>(a5));
-            }
-        }
+        // x0 (optional, with a5) = R^-1 y at the observation nodes (x1 = dobsS or obs_count / dobs_const as in the Lagrange calls): the
+        // final sweep then makes that call's first pass too
+        // d <= 5: everything rides in the sweeps; d = 6: the offsets pass does not fit next to the final sweep (256 + 256 registers and
+        // 612 B of scratch: 1.2 ms against 0.33 + 0.43 apart) and follows it as a launch of its own; d = 7, 8: the LDS accumulators of
+        // the products (50 / 64 KB per wavefront) would halve the occupancy of the first pass, so both passes follow.  Same contract.
+        const bool lag1 = a5 && (D == 6 || (D < 6 && !x0)), lag2 = a5 && x0 && D <= 5;
+        if (lag1) hipLaunchKernelGGL((k_vdp_marginals<D, 1, 1>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, (double*)nullptr, const_cast<double*>(a5));
+        else hipLaunchKernelGGL((k_vdp_marginals<D, 1>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, (double*)nullptr);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_vdp_marginals_scan<D>), dim3(P.B), dim3(kScanBlock), 0, st, lv, a2, a3, o2);
         MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((k_vdp_marginals<D, 3>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, part, (double*)nullptr);
+        if (lag2) hipLaunchKernelGGL((k_vdp_marginals<D, 3, 2>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, part, const_cast<double*>(a5), x0, x1,
+                                     obs_count, dobs_const);
+        else hipLaunchKernelGGL((k_vdp_marginals<D, 3>), grid, block, 0, st, lv, pr, a0, a1, o0, o1, o2, part);
         if (part) {
             MFGM_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, part, lv.P, 0, const_cast<double*>(a4), (double*)nullptr);
+        }
+        if (a5 && D > 6) {
+            MFGM_CHECK_LAUNCH();
+            hipLaunchKernelGGL((k_vdp_lagrange_products<D>), grid, block, 0, st, lv, pr, a0, const_cast<double*>(a5));
+        }
+        if (a5 && x0 && !lag2) {
+            MFGM_CHECK_LAUNCH();
+            hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, o0, o1, const_cast<double*>(a0), const_cast<double*>(a1), x0, x1,
+                               (double*)nullptr, (double*)nullptr, const_cast<double*>(a5), obs_count, dobs_const);
         }
     } else if (what == 4) {
         hipLaunchKernelGGL((k_vdp_to_naturals<D>), grid, block, 0, st, lv, pr, a0, a1, a2, a3, o0, o1, o2);
@@ -200,13 +212,16 @@ int mfgm_packed_vdp_marginals(const mfgm_plan* plan, const mfgm_vdp_params* prm,
 
 int mfgm_packed_vdp_marginals_products(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* Am, const double* bm,
                                        const double* q0_mu, const double* q0_cov, double* mu, double* Sig, double* e_over_dt, double* seg,
-                                       double* lagrange_seg, void* ws, void* stream) {
+                                       double* lagrange_seg, const double* yR, const double* dobsS, const int* obs_count,
+                                       const double* dobs_const, void* ws, void* stream) {
     if (!plan || !prm || !Am || !bm || !q0_mu || !q0_cov || !mu || !Sig || !seg || !lagrange_seg || lagrange_seg == seg || (e_over_dt && !ws))
         return 1;
+    if ((obs_count != nullptr) != (dobs_const != nullptr) || (yR && !obs_count && !dobsS) || (!yR && (dobsS || obs_count))) return 1;
     const Plan& P = plan->p;
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
-    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(6, P, pr, Am, bm, q0_mu, q0_cov, e_over_dt, lagrange_seg, mu, Sig, seg, (double*)ws, st)));
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(6, P, pr, Am, bm, q0_mu, q0_cov, e_over_dt, lagrange_seg, mu, Sig, seg, (double*)ws, st, obs_count, dobs_const,
+                                       yR, dobsS)));
 }
 
 int mfgm_packed_vdp_esde(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, const double* Am,
@@ -254,12 +269,12 @@ int mfgm_packed_vdp_lagrange_update_final(const mfgm_plan* plan, const mfgm_vdp_
 int mfgm_packed_vdp_lagrange_update0(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig, double* Am,
                                      double* bm, const double* yR, const double* dobsS, double* psi0, double* lam0, double* seg,
                                      const int* obs_count, const double* dobs_const, int mode, void* stream) {
-    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !psi0 || !lam0 || !seg || mode < 0 || mode > 2) return 1;
+    if (!plan || !prm || !mu || !Sig || !Am || !bm || !yR || !psi0 || !lam0 || !seg || mode < 0 || mode > 3) return 1;
     if ((obs_count != nullptr) != (dobs_const != nullptr) || (!obs_count && !dobsS)) return 1;
     const Plan& P = plan->p;
     VdpParams pr; memcpy(&pr, prm, sizeof(pr));
     hipStream_t st = (hipStream_t)stream;
-    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(mode == 1 ? 9 : (mode == 2 ? 10 : 8), P, pr, mu, Sig, Am, bm, yR, dobsS, psi0, lam0, seg, nullptr, st, obs_count, dobs_const)));
+    MFGM_DISPATCH_D(P.d, (vdp_impl<DD>(mode == 1 ? 9 : (mode == 2 ? 10 : (mode == 3 ? 11 : 8)), P, pr, mu, Sig, Am, bm, yR, dobsS, psi0, lam0, seg, nullptr, st, obs_count, dobs_const)));
 }
 
 int mfgm_packed_vdp_update_param(const mfgm_plan* plan, const mfgm_vdp_params* prm, const double* mu, const double* Sig,

@@ -322,27 +322,45 @@ MFGM_DEV void vdp_advance(const VdpParams& pr, const double (&T)[D * D], const d
 // seg: one record per lane (segment), contiguous -- Phi [d^2], Qacc [ET], macc [d], then the boundary values m [d], S [ET] at the
 // segment's first node -- so that the scan kernel reads the consecutive segments of a lane as one run (with one array per element,
 // strided by the lane count, every load of the scan was a cache line of its own: 0.29 ms, 0.16 ms like this).
-// PROD (PASS 1 only): the pass also leaves the linear parts of the Lagrange sweep's segment maps (k_vdp_lagrange_products: Mpsi, Mlam,
-// products of I - 2 dt A_t / I - dt A_t over the segment's transitions t >= 1) in `lseg`, the seg array of the Lagrange call that
-// follows on the SAME (A, b).  They depend on A alone and this pass has A in registers with the vector ALU a quarter busy (it is bound by
-// reading A): the two d x d accumulators live in LDS (one wavefront per SIMD, 2 d^2 x 64 doubles = 36 KB per workgroup at d = 6), worked
-// a row / a column at a time, and the 8 d^2 bytes per node of the products pass are not read again (config 3: 0.18 ms of 1.95).
-template <int D, int PASS, bool PROD = false>
+// LAG: what the pass does for the Lagrange call that follows on the SAME (A, b) and on the marginals this recursion produces; results go
+// to `lseg`, that call's seg array.
+//   LAG 1 (PASS 1): the linear parts of the Lagrange sweep's segment maps (k_vdp_lagrange_products: Mpsi, Mlam, products of
+//     I - 2 dt A_t / I - dt A_t over the segment's transitions t >= 1).  They depend on A alone and this pass has A in registers with
+//     the vector ALU a quarter busy (it is bound by reading A): the two d x d accumulators live in LDS (one wavefront per SIMD,
+//     2 d^2 x 64 doubles = 36 KB per workgroup at d = 6), worked a row / a column at a time, and the 8 d^2 bytes per node of the
+//     products pass are not read again (config 3: 0.18 ms of 1.95).
+//   LAG 2 (PASS 3): the whole of the Lagrange sweep's PASS 1 as well -- the affine offsets (Cpsi, Clam) of the segment maps.  The
+//     descending recurrence  psi <- psi X_t + c_t,  lam <- Y_t lam + e_t  (X_t = I - 2 dt A_t, Y_t = I - dt A_t, c_t = dt dE/dS - d_obs_S,
+//     e_t = dt dE/dm - d_obs_m) has the segment map  psi_out = psi_in (X_hi .. X_lo) + sum_s c_s (X_{s-1} .. X_lo), which an ASCENDING
+//     sweep accumulates as  Cpsi += c_s Mp,  Mp <- X_s Mp  (Clam += Ml e_s,  Ml <- Ml Y_s): this sweep visits the nodes in that order
+//     with (m_t, S_t, A_t, b_t) in registers, and its energy term is the value of the function whose gradient c_t, e_t need.  The
+//     Lagrange call then starts at its segment scan: PASS 1 and the products pass (0.43 + 0.18 ms of config 3's 1.95) are not run and
+//     their 600 + 288 bytes per node not read.
+template <int D, int PASS, int LAG = 0>
 __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr, const double* __restrict__ Am,
                                                      const double* __restrict__ bm, double* __restrict__ mug,
                                                      double* __restrict__ Sigg, double* __restrict__ seg,
                                                      double* __restrict__ part /* PASS 3, optional: per-lane sum of the E_sde terms */,
-                                                     double* __restrict__ lseg = nullptr) {
+                                                     double* __restrict__ lseg = nullptr, const double* __restrict__ yR = nullptr,
+                                                     const double* __restrict__ dobsS = nullptr, const int* __restrict__ obs_count = nullptr,
+                                                     const double* __restrict__ dobs_const = nullptr) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
-    static_assert(!PROD || PASS == 1, "the Lagrange products ride in pass 1");
-    __shared__ double prod_lds[PROD ? 2 * EF * 64 : 1];
+    static_assert(LAG == 0 || (LAG == 1 && PASS == 1) || (LAG == 2 && PASS == 3), "products ride in pass 1, the whole first Lagrange pass in pass 3");
+    __shared__ double prod_lds[LAG ? 2 * EF * 64 : 1];
     double* const Mp = prod_lds + threadIdx.x;                 // element e at Mp[e * 64]
-    double* const Ml = prod_lds + (PROD ? EF * 64 : 0) + threadIdx.x;
+    double* const Ml = prod_lds + (LAG ? EF * 64 : 0) + threadIdx.x;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
-    if (PROD) {
+    if (LAG) {
 #pragma unroll
         for (int e = 0; e < EF; ++e) { Mp[e * 64] = (e % (D + 1) == 0) ? 1.0 : 0.0; Ml[e * 64] = (e % (D + 1) == 0) ? 1.0 : 0.0; }
+    }
+    double Cpsi[LAG == 2 ? EF : 1], Clam[LAG == 2 ? D : 1];
+    if (LAG == 2) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) Cpsi[e] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) Clam[i] = 0.0;
     }
     const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
     const int P = lv.P, R = lv.R, n = lv.n;
@@ -365,10 +383,15 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
         for (int e = 0; e < ET; ++e) S[e] = bnd[(size_t)lane * STR + (D + e)];
     }
     double An[EF], bn[D];
+    int cntn = 0;
     double esde = 0.0;
+    auto load_jump = [&](int s) {        // the observation count of node s (LAG 2), requested with that node's A, b
+        if (LAG == 2 && obs_count) cntn = obs_count[((size_t)me.tile * R + s) * 64 + me.l];
+    };
     if (nt > 0) {
         ld_node<EF>(Am, R, 0, me, An);
         ld_node<D>(bm, R, 0, me, bn);
+        load_jump(0);
     }
     for (int s = 0; s < R; ++s) {
         if (s < len) {
@@ -382,16 +405,104 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
                 for (int e = 0; e < EF; ++e) T[e] = An[e];
 #pragma unroll
                 for (int i = 0; i < D; ++i) o[i] = bn[i];
-                if (s + 1 < nt) {
-                    ld_node<EF>(Am, R, s + 1, me, An);
-                    ld_node<D>(bm, R, s + 1, me, bn);
-                }
-                if (PASS == 3 && part) {
+                const int cnt = cntn;
+                auto request_next = [&]() {
+                    if (s + 1 < nt) {
+                        ld_node<EF>(Am, R, s + 1, me, An);
+                        ld_node<D>(bm, R, s + 1, me, bn);
+                        load_jump(s + 1);
+                    }
+                };
+                if (LAG != 2) request_next();
+                if (PASS == 3 && LAG != 2 && part) {
                     // E_sde term of this transition (k_vdp_esde) while (m_t, S_t, A_t, b_t) are in registers
                     double dm[D], dS[ET];
                     esde += vdp_energy<D, false>(pr, m, S, T, o, dm, dS);
                 }
-                if (PROD && p * R + s >= 1) {
+                if (LAG == 2) {
+                    // the energy term with its gradients; at t >= 1 the offsets of the Lagrange segment map take c_t, e_t (k_vdp_lagrange)
+                    double dm[D], dS[ET];
+                    esde += vdp_energy<D, true>(pr, m, S, T, o, dm, dS);
+                    // the next node's inputs are requested HERE, not before the energy term, whose temporaries and the 48 doubles
+                    // in flight do not fit the register file together (716 B of scratch, 1.2 ms); what is left of this node's work
+                    // (~1 100 fp64 instructions) covers the latency
+                    __builtin_amdgcn_sched_barrier(0);
+                    request_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p * R + s >= 1) {
+                        if (pr.clip > 0.0) {        // vi_sde.py:312-323
+#pragma unroll
+                            for (int i = 0; i < D; ++i) dm[i] = vdp_stab(dm[i], pr.clip);
+#pragma unroll
+                            for (int e = 0; e < ET; ++e) dS[e] = vdp_stab(dS[e], pr.clip);
+                        }
+                        // e_t = dt dE/dm - d_obs_m  (in dm),  c_t = dt dE/dS - d_obs_S  (in dS)
+#pragma unroll
+                        for (int i = 0; i < D; ++i) dm[i] *= pr.dt;
+#pragma unroll
+                        for (int e = 0; e < ET; ++e) dS[e] *= pr.dt;
+                        if (!obs_count || cnt != 0) {
+                            // the jump terms: zero except at observation nodes (whole wavefronts when the segments are aligned with the
+                            // observation grid), so R^-1 y and the observation block are read here, not with every node
+                            double yr[D], dob[ET];
+                            ld_node<D>(yR, R, s, me, yr);
+                            if (obs_count) {
+#pragma unroll
+                                for (int e = 0; e < ET; ++e) dob[e] = (double)cnt * dobs_const[e];
+                            } else {
+                                ld_node<ET>(dobsS, R, s, me, dob);
+                            }
+                            if (pr.clip > 0.0) {
+#pragma unroll
+                                for (int e = 0; e < ET; ++e) dob[e] = vdp_stab(dob[e], pr.clip);
+                            }
+#pragma unroll
+                            for (int i = 0; i < D; ++i) {
+                                double dom = yr[i];
+#pragma unroll
+                                for (int k = 0; k < D; ++k) dom = __builtin_fma(2.0 * dob[six(i, k)], m[k], dom);
+                                if (pr.clip > 0.0) dom = vdp_stab(dom, pr.clip);
+                                dm[i] -= dom;
+                            }
+#pragma unroll
+                            for (int e = 0; e < ET; ++e) dS[e] -= dob[e];
+                        }
+                        // Cpsi += c Mp, then Mp <- (I - 2 dt A) Mp, a column at a time
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            double c[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) c[k] = Mp[(k * D + j) * 64];
+#pragma unroll
+                            for (int i = 0; i < D; ++i) {
+                                double t = 0.0, u = Cpsi[i * D + j];
+#pragma unroll
+                                for (int k = 0; k < D; ++k) {
+                                    t = __builtin_fma(T[i * D + k], c[k], t);
+                                    u = __builtin_fma(dS[six(i, k)], c[k], u);
+                                }
+                                Cpsi[i * D + j] = u;
+                                Mp[(i * D + j) * 64] = __builtin_fma(-2.0 * pr.dt, t, c[i]);
+                            }
+                        }
+                        // Clam += Ml e, then Ml <- Ml (I - dt A), a row at a time
+#pragma unroll
+                        for (int i = 0; i < D; ++i) {
+                            double r[D], u = Clam[i];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) { r[k] = Ml[(i * D + k) * 64]; u = __builtin_fma(r[k], dm[k], u); }
+                            Clam[i] = u;
+#pragma unroll
+                            for (int j = 0; j < D; ++j) {
+                                double t = 0.0;
+#pragma unroll
+                                for (int k = 0; k < D; ++k) t = __builtin_fma(r[k], T[k * D + j], t);
+                                Ml[(i * D + j) * 64] = __builtin_fma(-pr.dt, t, r[j]);
+                            }
+                        }
+                    }
+                }
+                if (LAG == 1 && p * R + s >= 1) {
                     // ascending order of the same products: Mpsi <- (I - 2 dt A_t) Mpsi (a column at a time), Mlam <- Mlam (I - dt A_t)
                     // (a row at a time); T still holds A_t here
 #pragma unroll
@@ -433,6 +544,17 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
         }
     }
     if (PASS == 3 && part) part[lane] = esde;
+    if (LAG == 2) {
+        constexpr int LSTR = 4 * EF + 2 * D;                  // the Lagrange sweep's segment record: Mpsi, Cpsi, Mlam, Clam, boundary values
+#pragma unroll
+        for (int e = 0; e < EF; ++e) {
+            lseg[(size_t)lane * LSTR + e] = Mp[e * 64];
+            lseg[(size_t)lane * LSTR + (EF + e)] = Cpsi[e];
+            lseg[(size_t)lane * LSTR + (2 * EF + e)] = Ml[e * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) lseg[(size_t)lane * LSTR + (3 * EF + i)] = Clam[i];
+    }
     if (PASS == 1) {
 #pragma unroll
         for (int e = 0; e < EF; ++e) seg[(size_t)lane * STR + e] = Phi[e];
@@ -440,7 +562,7 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
         for (int e = 0; e < ET; ++e) seg[(size_t)lane * STR + (EF + e)] = S[e];
 #pragma unroll
         for (int i = 0; i < D; ++i) seg[(size_t)lane * STR + (EF + ET + i)] = m[i];
-        if (PROD) {
+        if (LAG == 1) {
             constexpr int LSTR = 4 * EF + 2 * D;              // the Lagrange sweep's segment record (k_vdp_lagrange_products)
 #pragma unroll
             for (int e = 0; e < EF; ++e) {

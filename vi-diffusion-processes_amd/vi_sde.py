@@ -133,8 +133,9 @@ class VariationalMarkovGP:
     # the reference's forward_pass computes); "precision" = precision blocks + factorisation + selected inverse; "ssm" = the same over
     # explicit SSM arrays.  VIDP_VDP_FORWARD selects; the three agree to rounding (tests/test_gpu_api.py).
     forward_mode = os.environ.get("VIDP_VDP_FORWARD", "moments")
-    # the moment recursion's first pass also makes the A-only pass of the Lagrange sweep that follows (VIDP_VDP_FUSE_PRODUCTS=0: not)
-    fuse_products = os.environ.get("VIDP_VDP_FUSE_PRODUCTS", "1") != "0"
+    # the moment recursion also makes the first passes of the Lagrange sweep that follows (VIDP_VDP_FUSE_LAGRANGE: 0 none, 1 the A-only
+    # products pass, 2 the offsets pass too -- inside the final sweep for d <= 5, as a launch of that call for d >= 6)
+    fuse_lagrange = int(os.environ.get("VIDP_VDP_FUSE_LAGRANGE", "2"))
 
     def _forward_packed_moments(self, prm):
         pl, d = self.plan, self.state_dim
@@ -145,15 +146,17 @@ class VariationalMarkovGP:
             self._q0_key = (self.q0_mu, self.q0_chol)
         mu, Sig = pl.empty(VEC), pl.empty(SYM)        # fresh outputs: callers keep the marginals of earlier passes
         e = torch.empty(self.B, dtype=torch.float64, device=self.device)
-        if self.fuse_products:
-            # the first pass also forms the A-only part of the Lagrange sweep's segment maps (valid while (A, b) stay as they are)
+        if self.fuse_lagrange:
+            # the sweeps also make the first passes of the Lagrange call that follows (valid while (A, b) and these marginals stand):
+            # level 1 the A-only products of its segment maps, level 2 the affine offsets as well
             if getattr(self, "_lseg", None) is None:
                 self._lseg = torch.empty_like(self._seg)
+            jump = (_ptr(self._yR), _ptr(self._dobsS), *self._jump_args()) if self.fuse_lagrange >= 2 else (None, None, None, None)
             _lib.check(self.lib.mfgm_packed_vdp_marginals_products(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b),
                                                                    _ptr(self._q0_dev[0]), _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig),
-                                                                   _ptr(e), _ptr(self._seg), _ptr(self._lseg), _ptr(pl.ws), _stream()),
-                       "mfgm_packed_vdp_marginals_products")
-            self._products_of = (self.A, self._param_version)
+                                                                   _ptr(e), _ptr(self._seg), _ptr(self._lseg), *jump, _ptr(pl.ws),
+                                                                   _stream()), "mfgm_packed_vdp_marginals_products")
+            self._products_of = (self.A, self._param_version, mu if self.fuse_lagrange >= 2 else None, bool(prm.clip > 0.0))
         else:
             _lib.check(self.lib.mfgm_packed_vdp_marginals(pl.h, ctypes.byref(prm), _ptr(self.A), _ptr(self.b), _ptr(self._q0_dev[0]),
                                                           _ptr(self._q0_dev[1]), _ptr(mu), _ptr(Sig), _ptr(e), _ptr(self._seg),
@@ -312,6 +315,8 @@ class VariationalMarkovGP:
         self._param_version += 1
         pl = self.plan
         m, S = mS if mS is not None else self._mS
+        # 3: the offsets of the segment maps are there too (made on these very marginals, same stabilisation)
+        mode = 0 if not have_products else (3 if (po[2] is m and po[3] == bool(self._params(lr=lr).clip > 0.0)) else 2)
         if self.store_multipliers if store_multipliers is None else store_multipliers:
             _lib.check(self.lib.mfgm_packed_vdp_lagrange_update(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
                                                                 _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(self.psi_lagrange),
@@ -327,7 +332,7 @@ class VariationalMarkovGP:
         _lib.check(self.lib.mfgm_packed_vdp_lagrange_update0(pl.h, ctypes.byref(self._params(lr=lr)), _ptr(m), _ptr(S), _ptr(self.A),
                                                              _ptr(self.b), _ptr(self._yR), _ptr(self._dobsS), _ptr(psi0), _ptr(lam0),
                                                              _ptr(self._lseg if have_products else self._seg), *self._jump_args(),
-                                                             2 if have_products else 0, _stream()),
+                                                             mode, _stream()),
                    "mfgm_packed_vdp_lagrange_update0")
         self._mult0 = (psi0, lam0)          # what update_initial_statistics reads until the arrays are current again
 
