@@ -688,11 +688,13 @@ def bench_cvidp(h, data_rank):
     def step():
         model.update_data_sites(args.lr_data)
         model.update_girsanov_sites(args.lr_girsanov)
-        e_traj = model.classic_elbo_per_trajectory()
         if not first_elbo:
+            e_traj = model.classic_elbo_per_trajectory()     # the parity probe against the C port's first step
             first_elbo.append(e_traj.clone())
-        e = vdist.allreduce_sum_(e_traj.sum())           # the only collective: scalar ELBO sum over ranks
-        elbos.append(e)
+            e = e_traj.sum()
+        else:
+            e = model.classic_elbo()                         # the reference's call (cvi_dp_trainer.py:75): the sum over trajectories
+        elbos.append(vdist.allreduce_sum_(e))                # the only collective: scalar ELBO sum over ranks
 
     def fence():
         torch.cuda.synchronize()
