@@ -95,20 +95,28 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
 }  // namespace
 
 namespace {
+// one recurrence (n = 1) or two independent ones in the same launches (n = 2; each with its own seg array)
 template <int D>
-int congruence_scan_impl(const Plan& P, const double* Phi, const double* Q, double* X, double* seg, hipStream_t st) {
+int congruence_scan_impl(const Plan& P, int n, const double* const* Phi, const double* const* Q, double* const* X, double* const* seg, hipStream_t st) {
     constexpr int ET = MFGM_NTRI(D), STR = 2 * (D + ET) + D * D;
     const LevelDesc& lv = P.lv[0];
-    double* zeros = seg + (size_t)STR * lv.Lpad;          // q0 = (0, 0) of every chain
+    double* zeros = seg[0] + (size_t)STR * lv.Lpad;          // q0 = (0, 0) of every chain
     if (hipMemsetAsync(zeros, 0, (size_t)P.B * (D + ET) * sizeof(double), st) != hipSuccess) return 3;
-    dim3 grid(lv.Lpad / 64), block(64);
-    hipLaunchKernelGGL((k_congruence_scan<D, 1>), grid, block, 0, st, lv, Phi, Q, X, seg);
+    ScanSets sets;
+    for (int k = 0; k < 2; ++k) sets.s[k] = ScanSet{Phi[k % n], Q[k % n], X[k % n], seg[k % n]};
+    dim3 grid(lv.Lpad / 64, n), block(64);
+    hipLaunchKernelGGL((k_congruence_scan<D, 1>), grid, block, 0, st, lv, sets);
     MFGM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_vdp_marginals_scan<D>), dim3(P.B), dim3(kScanBlock), 0, st, lv, (const double*)zeros, (const double*)(zeros + (size_t)P.B * D), seg);
+    hipLaunchKernelGGL((k_vdp_marginals_scan<D>), dim3(P.B, n), dim3(kScanBlock), 0, st, lv, (const double*)zeros, (const double*)(zeros + (size_t)P.B * D),
+                       seg[0], seg[n - 1]);
     MFGM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_congruence_scan<D, 3>), grid, block, 0, st, lv, Phi, Q, X, seg);
+    hipLaunchKernelGGL((k_congruence_scan<D, 3>), grid, block, 0, st, lv, sets);
     MFGM_CHECK_LAUNCH();
     return 0;
+}
+template <int D>
+int congruence_scan_impl(const Plan& P, const double* Phi, const double* Q, double* X, double* seg, hipStream_t st) {
+    return congruence_scan_impl<D>(P, 1, &Phi, &Q, &X, &seg, st);
 }
 }  // namespace
 
@@ -138,9 +146,12 @@ int band_impl(const Plan& P, const double* Sig, const double* Sub, const double*
     dim3 grid(lv.Lpad / 64), block(64);
     hipLaunchKernelGGL((k_band_prepare<D>), grid, block, 0, st, lv, a);
     MFGM_CHECK_LAUNCH();
-    int rc = congruence_scan_impl<D>(P, a.PhiL, a.QL, Lr, seg, st);
-    if (rc) return rc;
-    rc = congruence_scan_impl<D>(P, a.PhiR, a.QR, Rr, seg, st);
+    // the ascending and the descending recurrence are independent: same launches, own seg arrays
+    const double* Phis[2] = {a.PhiL, a.PhiR};
+    const double* Qs[2] = {a.QL, a.QR};
+    double* Xs2[2] = {Lr, Rr};
+    double* segs[2] = {seg, seg + scan_ws_doubles(P)};
+    int rc = congruence_scan_impl<D>(P, 2, Phis, Qs, Xs2, segs, st);
     if (rc) return rc;
     hipLaunchKernelGGL((k_band_finish<D>), grid, block, 0, st, lv, a);
     MFGM_CHECK_LAUNCH();
@@ -166,7 +177,7 @@ size_t mfgm_band_workspace_doubles(const mfgm_plan* plan) {
     if (!plan || plan->p.wide) return 0;
     const Plan& P = plan->p;
     const int d = P.d;
-    return 2 * packed_elems(P.lv[0], d * d) + 5 * packed_elems(P.lv[0], d * (d + 1) / 2) + scan_ws_doubles(P);
+    return 2 * packed_elems(P.lv[0], d * d) + 5 * packed_elems(P.lv[0], d * (d + 1) / 2) + 2 * scan_ws_doubles(P);
 }
 
 int mfgm_band_sigma_dP_sigma(const mfgm_plan* plan, const double* Sig, const double* Sub, const double* dPd, const double* dPs, double* Xd,

@@ -578,8 +578,10 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
 constexpr int kScanBlock = 256;       // lanes per chain in the segment-map scans: four wavefronts, K = ceil(P / 256) maps per lane
 template <int D>
 __global__ __launch_bounds__(kScanBlock) void k_vdp_marginals_scan(LevelDesc lv, const double* __restrict__ q0_mu,
-                                                                  const double* __restrict__ q0_cov, double* __restrict__ seg) {
+                                                                  const double* __restrict__ q0_cov, double* __restrict__ seg0,
+                                                                  double* __restrict__ seg1 = nullptr /* blockIdx.y == 1 */) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
+    double* __restrict__ seg = blockIdx.y ? seg1 : seg0;
     __shared__ double wtot[kScanBlock / 64][MAP];  // the composed map of each wavefront's 64 lanes
     const int b = blockIdx.x, jl = threadIdx.x, j = jl & 63, wv = jl >> 6;
     const int P = lv.P;
@@ -704,10 +706,16 @@ __global__ __launch_bounds__(kScanBlock) void k_vdp_marginals_scan(LevelDesc lv,
 // from L_{t+1} = A_t L_t A_t^T + QL and its mirror image) are of this form.  PASS 1 composes a segment's nodes into (Phi, Qacc), the
 // segment maps are chained by k_vdp_marginals_scan (mean part zero, start value 0), PASS 3 sweeps each segment from the value that
 // enters it and stores X.  The torch route (a Hillis-Steele scan, ceil(log2 T) rounds of three batched products) moves ~17 x more bytes.
+// Two independent recurrences (the ascending and the descending one of the band) ride in one launch: blockIdx.y picks the array set.
+struct ScanSet { const double* Phi; const double* Q; double* X; double* seg; };
+struct ScanSets { ScanSet s[2]; };
 template <int D, int PASS>
-__global__ __launch_bounds__(64) void k_congruence_scan(LevelDesc lv, const double* __restrict__ Phig, const double* __restrict__ Qg,
-                                                       double* __restrict__ Xg, double* __restrict__ seg) {
+__global__ __launch_bounds__(64) void k_congruence_scan(LevelDesc lv, ScanSets sets) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, MAP = EF + ET + D, STR = MAP + D + ET;
+    const double* __restrict__ Phig = sets.s[blockIdx.y].Phi;
+    const double* __restrict__ Qg = sets.s[blockIdx.y].Q;
+    double* __restrict__ Xg = sets.s[blockIdx.y].X;
+    double* __restrict__ seg = sets.s[blockIdx.y].seg;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= lv.L) return;
     const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};

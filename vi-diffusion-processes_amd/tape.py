@@ -93,9 +93,10 @@ def spd_inverse_from_chol(L):
 
 
 # ---- theta -> eta through the HIP sweeps -------------------------------------------------------------------------------------------------
-def _marginals(plan, lin, diag, sub, mean_only=False):
+def _marginals(plan, lin, diag, sub, mean_only=False, packed_out=None):
     """(mu, Sigma_tt, Sigma_{t+1,t}) natural-layout tensors of the chain with naturals (lin or None, diag, sub): pack, factor, selected
-    inverse, unpack.  mean_only: (mu, None, None) -- the sub-diagonal blocks are not formed and nothing but mu is unpacked."""
+    inverse, unpack.  mean_only: (mu, None, None) -- the sub-diagonal blocks are not formed and nothing but mu is unpacked.
+    packed_out (a list): receives the packed (Sigma_tt, Sigma_{t+1,t}) of a lane-per-segment plan, for a backward pass to reuse."""
     T = plan.T
     f = plan.factor(plan.pack(SYM, diag), plan.pack(FULL, sub) if T > 1 else plan.zeros(FULL), None if lin is None else plan.pack(VEC, lin),
                     aD=-2.0, aS=-1.0, aR=1.0, want_logdet=False)
@@ -104,6 +105,8 @@ def _marginals(plan, lin, diag, sub, mean_only=False):
     if mean_only:
         return plan.unpack(VEC, s["x"]), None, None
     mu = None if lin is None else plan.unpack(VEC, s["x"])
+    if packed_out is not None and not plan.wide and T > 1:
+        packed_out.extend([s["Sig"], s["Sub"]])
     cov = plan.unpack(SYM, s["Sig"])
     if T > 1:
         csub = plan.unpack(FULL, s["Sub"], T - 1)
@@ -170,7 +173,7 @@ def _wband(cov, csub, dPd, dPs):
     return Xd, Xs
 
 
-def band_of_sigma_dP_sigma(cov, csub, dPd, dPs, plan=None):
+def band_of_sigma_dP_sigma(cov, csub, dPd, dPs, plan=None, packed=None):
     """Diagonal and sub-diagonal blocks of  X = Sigma dP Sigma  for the covariance Sigma of a Gauss-Markov chain given by its band
     (cov [B,T,d,d] = Sigma_tt, csub [B,T-1,d,d] = Sigma_{t+1,t}) and a symmetric block-tri-diagonal dP (dPd [B,T,d,d] symmetric,
     dPs [B,T-1,d,d] = dP_{t+1,t}).  Exact (module docstring); d x d solves through vidp_amd.linalg (HIP batched Cholesky / trsm)."""
@@ -179,8 +182,9 @@ def band_of_sigma_dP_sigma(cov, csub, dPd, dPs, plan=None):
     if (plan is not None and not plan.wide and cov.is_cuda and (B, T, d) == (plan.B, plan.T, plan.d) and T > 1
             and os.environ.get("VIDP_TAPE_TORCH_SCAN", "0") != "1"):
         # the whole of it on the packed layout (csrc/mfgm_band.h): one Cholesky per node, the two recurrences, the assembly
-        Xd, Xs = plan.band_of_sigma_dP_sigma(plan.pack(SYM, cov.contiguous()), plan.pack(FULL, csub.contiguous()),
-                                             plan.pack(SYM, dPd.contiguous()), plan.pack(FULL, dPs.contiguous()))
+        # packed: the packed (Sigma_tt, Sigma_{t+1,t}) these natural tensors were unpacked from (the forward pass kept them)
+        Sp, Cp = packed if packed else (plan.pack(SYM, cov.contiguous()), plan.pack(FULL, csub.contiguous()))
+        Xd, Xs = plan.band_of_sigma_dP_sigma(Sp, Cp, plan.pack(SYM, dPd.contiguous()), plan.pack(FULL, dPs.contiguous()))
         return plan.unpack(SYM, Xd), plan.unpack(FULL, Xs, T - 1)
     if cov.is_cuda and 1 < T and d <= 32 and os.environ.get("VIDP_TAPE_TORCH_SCAN", "0") != "1":
         # block sizes up to 32 (wide plans, or no plan at all): natural-layout arrays, MFMA Gram products (csrc/mfgm_wband.h)
@@ -220,49 +224,55 @@ class NaturalsToExpectations(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lin, diag, sub, plan):
         ctx.plan = plan
-        mu, cov, csub = _marginals(plan, lin.detach(), diag.detach(), sub.detach())
+        ctx.packed = []
+        mu, cov, csub = _marginals(plan, lin.detach(), diag.detach(), sub.detach(), packed_out=ctx.packed)
         ctx.save_for_backward(lin, diag, sub, mu, cov, csub)
         return _eta(mu, cov, csub)
 
     @staticmethod
     def backward(ctx, g_lin, g_diag, g_sub):
         lin, diag, sub, mu, cov, csub = ctx.saved_tensors
-        z = lambda g, ref: torch.zeros_like(ref) if g is None else g
-        return (*fisher_vector_product(ctx.plan, diag, sub, mu, cov, csub, z(g_lin, lin), z(g_diag, diag), z(g_sub, sub)), None)
+        return (*fisher_vector_product(ctx.plan, diag, sub, mu, cov, csub, g_lin, g_diag, g_sub, packed=ctx.packed or None), None)
 
 
-def fisher_vector_product(plan, diag, sub, mu, cov, csub, g_lin, g_diag, g_sub):
+def fisher_vector_product(plan, diag, sub, mu, cov, csub, g_lin, g_diag, g_sub, packed=None):
     """F g = D eta(theta)[g] for the chain with naturals (., diag, sub), marginals (mu, cov = Sigma_tt, csub = Sigma_{t+1,t}), all in
     natural layout [B, T, ...]: the directional derivative of (mu, Sigma_tt + mu mu^T, Sigma_{t+1,t} + mu_{t+1} mu_t^T) along
-    g = (g_lin, g_diag, g_sub), which is also the vector-Jacobian product (F is symmetric).  Used by the tape and by
-    CVISitesSDE.grad_VE_wrt_prior_params (variational_cvi_sde.py:508-518)."""
-    g_diag = 0.5 * (g_diag + _T(g_diag))        # eta_diag is symmetric: only the symmetric part of its cotangent acts
-    # one host round trip for the three magnitudes (a zero cotangent part skips its work)
-    zero = torch.zeros((), dtype=g_lin.dtype, device=g_lin.device)
-    mx = torch.stack([g_lin.abs().max(), g_diag.abs().max(), g_sub.abs().max() if g_sub.numel() else zero]).tolist()
-    gmax, gm = max(mx), max(mx[1], mx[2])
-    if gmax == 0.0:
-        return torch.zeros_like(g_lin), torch.zeros_like(g_diag), torch.zeros_like(g_sub)
+    g = (g_lin, g_diag, g_sub), which is also the vector-Jacobian product (F is symmetric).  A cotangent part that is None (autograd:
+    that output is not used) is zero and its work is skipped -- without a pass over the arrays or a host round trip to find out.
+    Used by the tape and by CVISitesSDE.grad_VE_wrt_prior_params (variational_cvi_sde.py:508-518)."""
+    have_cov = g_diag is not None or g_sub is not None
+    if g_lin is None and not have_cov:
+        return torch.zeros_like(mu), torch.zeros_like(cov), torch.zeros_like(csub)
+    g_lin = torch.zeros_like(mu) if g_lin is None else g_lin
+    g_diag = torch.zeros_like(cov) if g_diag is None else 0.5 * (g_diag + _T(g_diag))   # only the symmetric part of this cotangent acts
+    g_sub = torch.zeros_like(csub) if g_sub is None else g_sub
     # d mu: one solve with the unperturbed precision
-    dmu = _marginals(plan, g_lin - _precision_times(plan, g_diag, g_sub, mu), diag, sub, mean_only=True)[0]
+    rhs = g_lin - _precision_times(plan, g_diag, g_sub, mu) if have_cov else g_lin
+    dmu = _marginals(plan, rhs, diag, sub, mean_only=True)[0]
     # d Sigma (diagonal and sub-diagonal blocks) = -band(Sigma dP Sigma)
-    dcov, dsub = torch.zeros_like(g_diag), torch.zeros_like(g_sub)
-    if gm > 0.0 and not NaturalsToExpectations.richardson:
-        Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub, plan=plan)
+    dcov, dsub = None, None
+    if have_cov and not NaturalsToExpectations.richardson:
+        Xd, Xs = band_of_sigma_dP_sigma(cov, csub, -2.0 * g_diag, -1.0 * g_sub, plan=plan, packed=packed)
         dcov, dsub = -Xd, -Xs
-    elif gm > 0.0:
-        h = NaturalsToExpectations.rel_step * float(diag.abs().max()) / gm
+    elif have_cov:
+        gm = float(torch.maximum(g_diag.abs().max(), g_sub.abs().max() if g_sub.numel() else g_diag.new_zeros(())))
+        if gm > 0.0:
+            h = NaturalsToExpectations.rel_step * float(diag.abs().max()) / gm
 
-        def central(e):
-            up = _marginals(plan, None, diag + e * g_diag, sub + e * g_sub)
-            dn = _marginals(plan, None, diag - e * g_diag, sub - e * g_sub)
-            return (up[1] - dn[1]) / (2.0 * e), (up[2] - dn[2]) / (2.0 * e)
+            def central(e):
+                up = _marginals(plan, None, diag + e * g_diag, sub + e * g_sub)
+                dn = _marginals(plan, None, diag - e * g_diag, sub - e * g_sub)
+                return (up[1] - dn[1]) / (2.0 * e), (up[2] - dn[2]) / (2.0 * e)
 
-        (c1, s1), (c2, s2) = central(h), central(0.5 * h)
-        dcov, dsub = (4.0 * c2 - c1) / 3.0, (4.0 * s2 - s1) / 3.0
-    d_diag = dcov + dmu[..., :, None] * mu[..., None, :] + mu[..., :, None] * dmu[..., None, :]
-    d_sub = dsub + dmu[:, 1:, :, None] * mu[:, :-1, None, :] + mu[:, 1:, :, None] * dmu[:, :-1, None, :]
-    return dmu, 0.5 * (d_diag + _T(d_diag)), d_sub
+            (c1, s1), (c2, s2) = central(h), central(0.5 * h)
+            dcov, dsub = (4.0 * c2 - c1) / 3.0, (4.0 * s2 - s1) / 3.0
+    outer = dmu[..., :, None] * mu[..., None, :]
+    d_diag = outer + _T(outer) if dcov is None else 0.5 * (dcov + _T(dcov)) + outer + _T(outer)
+    d_sub = dmu[:, 1:, :, None] * mu[:, :-1, None, :] + mu[:, 1:, :, None] * dmu[:, :-1, None, :]
+    if dsub is not None:
+        d_sub = d_sub + dsub
+    return dmu, d_diag, d_sub
 
 
 class LogDetPrecision(torch.autograd.Function):
