@@ -37,9 +37,7 @@ int vdp_impl(int what, const Plan& P, const VdpParams& pr, const double* a0, con
             hipLaunchKernelGGL((k_vdp_lagrange<D, 1>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
             MFGM_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 0>), dim3(P.B), dim3(kScanBlock), 0, st, lv, o2);
-        MFGM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D, 1>), dim3(P.B), dim3(kScanBlock), 0, st, lv, o2);
+        hipLaunchKernelGGL((k_vdp_lagrange_scan_wave<D>), dim3(P.B, 2), dim3(kScanBlock), 0, st, lv, o2);
         MFGM_CHECK_LAUNCH();
         if (what == 2) hipLaunchKernelGGL((k_vdp_lagrange<D, 3>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);
         else if (what == 5) hipLaunchKernelGGL((k_vdp_lagrange<D, 4>), grid, block, 0, st, lv, pr, a0, a1, Aw, bw, a4, a5, o0, o1, o2, obs_count, dobs_const);

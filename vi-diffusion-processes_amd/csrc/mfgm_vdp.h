@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(64) void k_vdp_lagrange_products(LevelDesc lv, VdpP
 //   PART 0: psi (value X, maps X -> X M + C);  PART 1: lambda (value v, maps v -> M v + C)
 
 template <int D, int PART>
-__global__ __launch_bounds__(kScanBlock) void k_vdp_lagrange_scan_wave(LevelDesc lv, double* __restrict__ seg) {
+MFGM_DEV void vdp_lagrange_scan_wave_body(const LevelDesc& lv, double* __restrict__ seg) {
     constexpr int EF = D * D, SEG = 3 * EF + D, STR = SEG + EF + D, NV = PART == 0 ? EF : D;
     __shared__ double wtot[kScanBlock / 64][EF + NV];   // the composed map of each wavefront's 64 lanes
     const int b = blockIdx.x, jl = threadIdx.x, j = jl & 63, wv = jl >> 6;
@@ -1107,6 +1107,13 @@ __global__ __launch_bounds__(kScanBlock) void k_vdp_lagrange_scan_wave(LevelDesc
             apply(mine, Mm, Cc);
         }
     }
+}
+// the psi and the lambda recurrence are independent: one launch, blockIdx.y picks the part (the lambda scan, 0.04 ms at config 3, runs
+// under the psi scan, 0.08 ms, instead of after it)
+template <int D>
+__global__ __launch_bounds__(kScanBlock) void k_vdp_lagrange_scan_wave(LevelDesc lv, double* __restrict__ seg) {
+    if (blockIdx.y == 0) vdp_lagrange_scan_wave_body<D, 0>(lv, seg);
+    else vdp_lagrange_scan_wave_body<D, 1>(lv, seg);
 }
 
 // ---- update_param ---------------------------------------------------------------------------------------------------
