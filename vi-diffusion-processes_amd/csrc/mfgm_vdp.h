@@ -327,8 +327,8 @@ MFGM_DEV void vdp_advance(const VdpParams& pr, const double (&T)[D * D], const d
 //   LAG 1 (PASS 1): the linear parts of the Lagrange sweep's segment maps (k_vdp_lagrange_products: Mpsi, Mlam, products of
 //     I - 2 dt A_t / I - dt A_t over the segment's transitions t >= 1).  They depend on A alone and this pass has A in registers with
 //     the vector ALU a quarter busy (it is bound by reading A): the two d x d accumulators live in LDS (one wavefront per SIMD,
-//     2 d^2 x 64 doubles = 36 KB per workgroup at d = 6), worked a row / a column at a time, and the 8 d^2 bytes per node of the
-//     products pass are not read again (config 3: 0.18 ms of 1.95).
+//     2 d^2 x 64 doubles = 36 KB per workgroup at d = 6) and the 8 d^2 bytes per node of the products pass are not read again
+//     (config 3: the pass goes from 0.20 to 0.28 ms and the products pass, 0.18 ms, is gone).
 //   LAG 2 (PASS 3): the whole of the Lagrange sweep's PASS 1 as well -- the affine offsets (Cpsi, Clam) of the segment maps.  The
 //     descending recurrence  psi <- psi X_t + c_t,  lam <- Y_t lam + e_t  (X_t = I - 2 dt A_t, Y_t = I - dt A_t, c_t = dt dE/dS - d_obs_S,
 //     e_t = dt dE/dm - d_obs_m) has the segment map  psi_out = psi_in (X_hi .. X_lo) + sum_s c_s (X_{s-1} .. X_lo), which an ASCENDING
@@ -503,33 +503,36 @@ __global__ __launch_bounds__(64) void k_vdp_marginals(LevelDesc lv, VdpParams pr
                     }
                 }
                 if (LAG == 1 && p * R + s >= 1) {
-                    // ascending order of the same products: Mpsi <- (I - 2 dt A_t) Mpsi (a column at a time), Mlam <- Mlam (I - dt A_t)
-                    // (a row at a time); T still holds A_t here
+                    // ascending order of the same products: Mpsi <- (I - 2 dt A_t) Mpsi, Mlam <- Mlam (I - dt A_t); T still holds A_t here.
+                    // Each accumulator is read from LDS in one batch (14 waits per node instead of 36; the pass, ~1 900 instructions per node
+                    // with the products in it, is bound by instruction issue either way: 0.28 ms against 0.20 + 0.18 apart)
+                    {
+                        double mp[EF];
 #pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        double c[D];
+                        for (int e = 0; e < EF; ++e) mp[e] = Mp[e * 64];
 #pragma unroll
-                        for (int k = 0; k < D; ++k) c[k] = Mp[(k * D + j) * 64];
+                        for (int i = 0; i < D; ++i)
 #pragma unroll
-                        for (int i = 0; i < D; ++i) {
-                            double t = 0.0;
+                            for (int j = 0; j < D; ++j) {
+                                double t = 0.0;
 #pragma unroll
-                            for (int k = 0; k < D; ++k) t = __builtin_fma(T[i * D + k], c[k], t);
-                            Mp[(i * D + j) * 64] = __builtin_fma(-2.0 * pr.dt, t, c[i]);
-                        }
+                                for (int k = 0; k < D; ++k) t = __builtin_fma(T[i * D + k], mp[k * D + j], t);
+                                Mp[(i * D + j) * 64] = __builtin_fma(-2.0 * pr.dt, t, mp[i * D + j]);
+                            }
                     }
+                    {
+                        double ml[EF];
 #pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        double r[D];
+                        for (int e = 0; e < EF; ++e) ml[e] = Ml[e * 64];
 #pragma unroll
-                        for (int k = 0; k < D; ++k) r[k] = Ml[(i * D + k) * 64];
+                        for (int i = 0; i < D; ++i)
 #pragma unroll
-                        for (int j = 0; j < D; ++j) {
-                            double t = 0.0;
+                            for (int j = 0; j < D; ++j) {
+                                double t = 0.0;
 #pragma unroll
-                            for (int k = 0; k < D; ++k) t = __builtin_fma(r[k], T[k * D + j], t);
-                            Ml[(i * D + j) * 64] = __builtin_fma(-pr.dt, t, r[j]);
-                        }
+                                for (int k = 0; k < D; ++k) t = __builtin_fma(ml[i * D + k], T[k * D + j], t);
+                                Ml[(i * D + j) * 64] = __builtin_fma(-pr.dt, t, ml[i * D + j]);
+                            }
                     }
                 }
                 vdp_transition<D>(pr, T, o);
