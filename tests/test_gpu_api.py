@@ -2162,6 +2162,28 @@ def test_tape_exact_backward_agrees_with_richardson(amd, rng):
         assert_close(a, b, rtol=1e-6, scale_atol=1e-7)
 
 
+@pytest.mark.parametrize("d", [3, 12])
+def test_tape_backward_with_unused_outputs(amd, rng, d):
+    """A loss that uses only some of (eta_lin, eta_diag, eta_sub): autograd hands the backward None for the others and the Fisher-vector
+    product skips their work (no band for a means-only loss) -- same gradients as with explicit zero cotangents, for a packed (d = 3) and
+    a wide (d = 12) plan."""
+    import torch
+    from vidp_amd import tape
+    B, T = 2, 30
+    prm = [dev(a) for a in random_ssm_params(rng, (B,), T, d)]
+    w = [dev(rng.normal(size=s)) for s in ((B, T, d), (B, T, d, d), (B, T - 1, d, d))]
+    for used in ((0,), (1,), (2,), (0, 2)):
+        def grads(explicit):
+            q = tape.TapeSSM(*[p.clone().requires_grad_(True) for p in prm])
+            e = q.expectations()
+            loss = sum((e[k] * w[k]).sum() for k in used)
+            if explicit:      # every output takes part, the unused ones with weight zero
+                loss = loss + sum((e[k] * torch.zeros_like(w[k])).sum() for k in range(3) if k not in used)
+            return [host(g) for g in torch.autograd.grad(loss, q.parameters)]
+        for a, b in zip(grads(False), grads(True)):
+            assert_close(a, b, rtol=1e-10, scale_atol=1e-11)
+
+
 @pytest.mark.parametrize("kname", ["m12", "sum"])
 def test_cvi_classic_elbo_site_gradient_vanishes_at_optimum(amd, rng, kname):
     """KA7's third clause (reference tests/integration/models/test_variational_cvi.py:93-110, kernel and likelihood frozen at :58-59):
