@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for v in default alt; do
   if [ $v = alt ]; then export MFGM_LIB=$ALT; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sl_$v -o p -- python3 $R/bench.py --config $C --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/sl_$v.json 2> $R/gpurun_out/sl_$v.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sl_$v -o p -- python3 $R/bench.py --config $C --steps 20 --warmup 3 --no-cpu-baseline --no-vdp --no-other-configs > $R/gpurun_out/sl_$v.json 2> $R/gpurun_out/sl_$v.err
   echo "== $v (exit $?)"
   f=$(find $R/gpurun_out/sl_$v -name '*kernel_stats.csv' | head -1)
   python3 - "$f" <<'PY'

@@ -66,6 +66,18 @@ int mfgm_plan_create(int B, int T, int d, int R0, int Rup, mfgm_plan** out) {
         ++l;
     }
     P.nlevels = l;
+    for (int k = 0; k < l; ++k) P.lv[k].nt = 0;
+    if (!P.wide) {
+        // Cache policy of the level-0 arrays (LevelDesc::nt, ld_node / st_node): streamed when one array of d x d blocks is larger than
+        // half the 256 MB of Infinity Cache -- then nothing a pass writes is still cached when the next pass reads it, and dirty lines
+        // left behind are written back under the next pass's traffic.  Used by the CVI-DP sweeps (mfgm_cq.h): headline step -1.0 ...
+        // -1.4 % in three same-box A/Bs (MFGM_NT=2 against 0), KL sweep -2.5 ... -6 %; models that fit the caches keep the default
+        // policy (config 2 is 3.5 % slower without it).  MFGM_NT=0 / 1 / 2 forces it.
+        const double bytes = 8.0 * (double)B * (double)T * (double)d * (double)d;
+        int nt = bytes >= 128.0 * 1024.0 * 1024.0 ? 2 : 0;
+        if (const char* e = getenv("MFGM_NT")) nt = std::max(0, std::min(2, atoi(e)));
+        P.lv[0].nt = nt;
+    }
     P.seg_lo = 0;
     P.seg_hi = P.lv[0].P;
     size_t off = 0;

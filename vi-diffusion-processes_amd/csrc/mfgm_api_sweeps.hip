@@ -339,7 +339,8 @@ int cq_factor_impl(const Plan& P0, const CqArgs& q, double* Lg, double* yg, doub
         bind_up(with_l1_region(P0, 1 - region), 0, ws, an);
         pipe->owner->ahead_region = 1 - region;
         an.part = nullptr;
-        hipLaunchKernelGGL((k_forward_cq<D>), grid, block, 0, st, a0, q);
+        if (a0.lv.nt >= 2) hipLaunchKernelGGL((k_forward_cq<D, 2>), grid, block, 0, st, a0, q);
+        else hipLaunchKernelGGL((k_forward_cq<D>), grid, block, 0, st, a0, q);
         MFGM_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_reduce_cq_lean<D>), grid, block, 0, st, an, *pipe->next);
         MFGM_CHECK_LAUNCH();
@@ -358,7 +359,8 @@ int cq_factor_impl(const Plan& P0, const CqArgs& q, double* Lg, double* yg, doub
         CqArgs qf = q;
         qf.site_lin2 = pipe->next->site_lin; qf.site_sym2 = pipe->next->site_sym;
         qf.pre_Dhat = an.uDhat; qf.pre_Rsub = an.uRsub; qf.pre_S = an.uS; qf.pre_rhat = an.urhat; qf.pre_rho = an.urho;
-        hipLaunchKernelGGL((k_forward_reduce_cq<D>), grid, dim3(128), 0, st, a0, qf);
+        if (a0.lv.nt >= 1) hipLaunchKernelGGL((k_forward_reduce_cq<D, 1>), grid, dim3(128), 0, st, a0, qf);
+        else hipLaunchKernelGGL((k_forward_reduce_cq<D>), grid, dim3(128), 0, st, a0, qf);
         MFGM_CHECK_LAUNCH();
         if (only_stage < 0 && (logdet || quad)) {
             hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, ws + P.off_part[0], P.lv[0].P, P.lv[0].Lpad, logdet, quad);
@@ -379,7 +381,8 @@ int cq_factor_impl(const Plan& P0, const CqArgs& q, double* Lg, double* yg, doub
         MFGM_CHECK_LAUNCH();
     }
     if (only_stage < 0 || only_stage == 1) {
-        hipLaunchKernelGGL((k_forward_cq<D>), grid, block, 0, st, a0, q);
+        if (a0.lv.nt >= 2) hipLaunchKernelGGL((k_forward_cq<D, 2>), grid, block, 0, st, a0, q);
+        else hipLaunchKernelGGL((k_forward_cq<D>), grid, block, 0, st, a0, q);
         MFGM_CHECK_LAUNCH();
     }
     if (only_stage < 0 && (logdet || quad)) {
@@ -419,7 +422,8 @@ int cq_selinv_girsanov_impl(const Plan& P, const CqArgs& q, const double* Lg, co
     bind_up(P, 0, ws, a);
     double* fix = ws + P.off_part[0];
     dim3 grid(a.lv.Lpad / 64), block(64);
-    hipLaunchKernelGGL((k_backward_girsanov_cq<D>), grid, block, 0, st, a, pr, q, fix);
+    if (a.lv.nt >= 2) hipLaunchKernelGGL((k_backward_girsanov_cq<D, 2>), grid, block, 0, st, a, pr, q, fix);
+    else hipLaunchKernelGGL((k_backward_girsanov_cq<D>), grid, block, 0, st, a, pr, q, fix);
     MFGM_CHECK_LAUNCH();
     hipLaunchKernelGGL((k_girsanov_fixup_cq<D>), grid, block, 0, st, a.lv, q.dyn_out, (const double*)fix);
     MFGM_CHECK_LAUNCH();
@@ -441,7 +445,8 @@ int cq_selinv_kl_impl(const Plan& P, const CqArgs& q, const double* Lg, const do
     a.Sigg = Sig; a.mug = x;
     a.part = ws + P.off_part[0];
     bind_up(P, 0, ws, a);
-    hipLaunchKernelGGL((k_backward_kl_cq<D>), dim3(a.lv.Lpad / 64), dim3(64), 0, st, a, pr, q);
+    if (a.lv.nt >= 2) hipLaunchKernelGGL((k_backward_kl_cq<D, 2>), dim3(a.lv.Lpad / 64), dim3(64), 0, st, a, pr, q);
+    else hipLaunchKernelGGL((k_backward_kl_cq<D>), dim3(a.lv.Lpad / 64), dim3(64), 0, st, a, pr, q);
     MFGM_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sum_partials, dim3(P.B), dim3(256), 0, st, a.part, a.lv.P, 0, kl, (double*)nullptr);
     MFGM_CHECK_LAUNCH();

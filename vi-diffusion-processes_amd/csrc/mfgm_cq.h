@@ -43,14 +43,24 @@ struct CqArgs {
 template <int E, int E0, int N>
 MFGM_DEV void ld_part(const double* __restrict__ base, int R, int s, LaneRef w, double (&out)[N]) {
     const double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64) + (size_t)E0 * 64;
+    if (w.nt >= 2) {
 #pragma unroll
-    for (int e = 0; e < N; ++e) out[e] = p[e * 64 + w.l];
+        for (int e = 0; e < N; ++e) out[e] = __builtin_nontemporal_load(p + e * 64 + w.l);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) out[e] = p[e * 64 + w.l];
+    }
 }
 template <int E, int E0, int N>
 MFGM_DEV void st_part(double* __restrict__ base, int R, int s, LaneRef w, const double (&v)[N]) {
     double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64) + (size_t)E0 * 64;
+    if (w.nt >= 1) {
 #pragma unroll
-    for (int e = 0; e < N; ++e) p[e * 64 + w.l] = v[e];
+        for (int e = 0; e < N; ++e) __builtin_nontemporal_store(v[e], p + e * 64 + w.l);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) p[e * 64 + w.l] = v[e];
+    }
 }
 MFGM_DEV int cq_slot(const int* __restrict__ slot, int R, int s, LaneRef w) { return slot[((size_t)w.tile * R + s) * 64 + w.l]; }
 
@@ -506,7 +516,9 @@ MFGM_DEV void forward_cq_body(const SweepArgs& a, const CqArgs& q, const int lan
     }
     if (bad) flag_not_pd(a.info, a.lv.level, lane);
 }
-template <int D>
+// NT: cache policy of the level-0 arrays (LevelDesc::nt, ld_node / st_node) as a compile-time constant -- behind a run-time branch
+// the compiler merges the two copies of a load and drops the hint.
+template <int D, int NT = 0>
 static __global__ __launch_bounds__(64) void k_forward_cq(SweepArgs a, CqArgs q) {
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
@@ -687,7 +699,7 @@ MFGM_DEV void reduce_cq_lds_body(const SweepArgs& a, const CqArgs& q, const int 
     if (bad) flag_not_pd(a.info, a.lv.level, lane);
 }
 
-template <int D>
+template <int D, int NT = 0>
 static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_forward_reduce_cq(SweepArgs a, CqArgs q) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D;
     __shared__ double lds[(EF + ET + D) * 64];
@@ -696,7 +708,7 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
     // padding lanes of the last tile repeat the work of the last live lane (same loads, same results, same values stored to the same
     // places) instead of returning.
     const int lane = min((int)blockIdx.x * 64 + l, a.lv.L - 1);
-    const LaneRef me{(int)blockIdx.x, lane & 63};
+    const LaneRef me{(int)blockIdx.x, lane & 63, NT >= 1 ? 1 : 0};     // streamed stores only: the second reader of a record is served from the cache
     if (wave == 0) forward_cq_body<D, true>(a, q, lane, me);
     else reduce_cq_lds_body<D>(a, q, lane, me, lds, l);
 }
@@ -778,12 +790,12 @@ MFGM_DEV void cq_store_lin(const SdeParams& pr, const CqArgs& q, int R, int s, L
 
 // ---- backward sweep fused with the Girsanov-site update (k_backward_girsanov on the cq state) --------------------------------------
 // fix: [D][Lpad] hand-over of lr (We - W J m) from a segment's last interior node to its separator (k_girsanov_fixup_cq adds it)
-template <int D>
+template <int D, int NT = 0>
 static __global__ __launch_bounds__(64) void k_backward_girsanov_cq(SweepArgs a, SdeParams pr, CqArgs q, double* fix) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, E3 = 3 * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
-    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x, NT};
     const int P = a.lv.P, R = a.lv.R, Lp = a.lv.Lpad, n = a.lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);
@@ -925,12 +937,12 @@ MFGM_DEV void cq_store_obs(const CqArgs& q, int slot, const double (&x)[D], cons
     }
 }
 
-template <int D>
+template <int D, int NT = 0>
 static __global__ __launch_bounds__(64) void k_backward_kl_cq(SweepArgs a, SdeParams pr, CqArgs q) {
     constexpr int ET = MFGM_NTRI(D), EF = D * D, E3 = 3 * D;
     const int lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.lv.L) return;
-    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x};
+    const LaneRef me{(int)blockIdx.x, (int)threadIdx.x, NT};
     const int P = a.lv.P, R = a.lv.R, n = a.lv.n;
     const int b = lane / P, p = lane - b * P;
     const int len = min(R, n - p * R);

@@ -25,6 +25,8 @@ struct LevelDesc {
     int L;      // lanes = B * P
     int Lpad;   // lanes padded to a multiple of 64
     int level;  // index of this level in its plan (0 = finest): part of the location a not-positive-definite report carries
+    int nt;     // lane-per-segment plans, level 0: cache policy of the per-node arrays -- 0 default, 1 non-temporal stores, 2 loads too
+                // (arrays far larger than the 256 MB of L2 + Infinity Cache are streamed: see ld_node in mfgm_sweeps.h)
 };
 
 constexpr int kMaxLevels = 8;

@@ -20,6 +20,7 @@ namespace mfgm {
 // element is reached with an immediate offset e*512 from it (no per-element vector address math).
 struct LaneRef {
     int tile, l;
+    int nt = 0;      // cache policy of the level-0 arrays this lane streams (LevelDesc::nt; a compile-time constant where it is not 0)
     MFGM_DEV static LaneRef of(int lane) { return LaneRef{lane >> 6, lane & 63}; }
 };
 // NM marks an array of a level above the finest one (plan workspace).  Those levels use the SAME lane-interleaved layout as level 0,
@@ -51,9 +52,18 @@ MFGM_DEV void ld_node(const double* __restrict__ base, int R, int s, LaneRef w, 
 #pragma unroll
         for (int e = 0; e < E; ++e) out[e] = p[e * 64];
     } else {
+        // Level-0 arrays of the large models (GBs, written by one pass and read by the next after everything else has gone through the
+        // caches) are streamed with the non-temporal policy; models that fit the caches keep the default one (config 2 is 3.5 % slower
+        // without it).  Plan creation decides (LevelDesc::nt, mfgm_plan_create), the CVI-DP sweeps carry the value as a template
+        // parameter: behind a run-time branch the compiler merges the two copies of a load and drops the hint (no `nt` in the ISA).
         const double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+        if (w.nt >= 2) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) out[e] = p[e * 64 + w.l];
+            for (int e = 0; e < E; ++e) out[e] = __builtin_nontemporal_load(p + e * 64 + w.l);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) out[e] = p[e * 64 + w.l];
+        }
     }
 }
 template <int E, bool NM = false>
@@ -64,8 +74,13 @@ MFGM_DEV void st_node(double* __restrict__ base, int R, int s, LaneRef w, const 
         for (int e = 0; e < E; ++e) p[e * 64] = v[e];
     } else {
         double* p = base + ((size_t)w.tile * R + s) * (size_t)(E * 64);
+        if (w.nt >= 1) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) p[e * 64 + w.l] = v[e];
+            for (int e = 0; e < E; ++e) __builtin_nontemporal_store(v[e], p + e * 64 + w.l);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) p[e * 64 + w.l] = v[e];
+        }
     }
 }
 template <int E, bool NM = false>
