@@ -772,19 +772,23 @@ def bench_cvidp(h, data_rank):
                                                    _ptr(cq.spare), _ptr(plan.ws), _stream()) == 0
 
             E3, slot = 3 * d, 0.5      # the int slot per node counts as half a double
+            # the cache-policy variant of the sweeps this plan runs (mfgm_plan_create: streamed when one d x d array is >= 128 MB;
+            # MFGM_NT overrides) -- part of the kernels' names in the profiler's tables
+            nt = int(os.environ.get("MFGM_NT", 2 if 8.0 * B * T * d * d >= 128 * 2 ** 20 else 0))
+            ntv = 2 if nt >= 2 else 0
             cand = [
-                (f"void mfgm::k_forward_cq<{d}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot) + (ET + d), lambda: stage(1),
+                (f"void mfgm::k_forward_cq<{d}, {ntv}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot) + (ET + d), lambda: stage(1),
                  "level 0 forward: block Cholesky + forward substitution; reads the cq record and the slot, writes L and y"),
                 (f"void mfgm::k_reduce_cq<{d}>(mfgm::SweepArgs, mfgm::CqArgs)", 2, (E3 + slot), lambda: stage(0),
                  "level 0 reduce: segment elimination; reads the cq record and the slot"
                  + (" (timed alone; in the pipelined loop one of the step's two reduces runs as k_reduce_cq_lean on a second stream, "
                     "next to the forward sweep of the previous factorisation: share_of_step counts it as if it ran alone)"
                     if model.pipelined else "")),
-                (f"void mfgm::k_backward_kl_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs)", 1,
+                (f"void mfgm::k_backward_kl_cq<{d}, {ntv}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs)", 1,
                  (ET + d + d + slot) + (0 if lazy else ET + d), backward,
                  "level 0 backward + KL sum: selected inverse, back-substitution, E_q[log p]; reads L, y, diag theta_sub, slot; writes "
                  + ("the marginals at the observation nodes only" if lazy else "Sigma, mu")),
-                (f"void mfgm::k_backward_girsanov_cq<{d}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs, double*)", 1, (ET + d + E3) + E3, girsanov,
+                (f"void mfgm::k_backward_girsanov_cq<{d}, {ntv}>(mfgm::SweepArgs, mfgm::SdeParams, mfgm::CqArgs, double*)", 1, (ET + d + E3) + E3, girsanov,
                  "level 0 backward fused with the Girsanov-site update; reads L, y, the cq record, writes the new record"),
             ]
         else:

@@ -13,7 +13,7 @@ import json
 d=json.load(open("/root/repo/gpurun_out/sq_pass.json"))
 for k,v in d.get("kernels",d).items():
     if not isinstance(v,dict) or "SQ_WAVE_CYCLES" not in v: continue
-    if not any(x in k for x in ("_cq<6>","forward_reduce")): continue
+    if not any(x in k for x in ("_cq<6","forward_reduce")): continue
     w=v["SQ_WAVE_CYCLES"]
     print(k[:48].ljust(48), "active %.2f wait_inst %.2f wait_any %.2f  valu/wave-cycle %.3f  gui %.0f" % (v["SQ_ACTIVE_INST_ANY"]/w, v["SQ_WAIT_INST_ANY"]/w, v["SQ_WAIT_ANY"]/w, v["SQ_INSTS_VALU"]/w, v["GRBM_GUI_ACTIVE"]))
 PY
